@@ -1,0 +1,159 @@
+/*
+ * puresound_hip.h -- C ABI of libpuresound_hip.so: the MI355X (gfx950) implementation of the
+ * PureSound separator forward path (encoder -> Conv-TasNet masker -> mask -> decoder -> clamp).
+ *
+ * The reference (mcw519/PureSound) is pure Python/PyTorch and has no FFI; the seam a maintainer
+ * would bind is the nn.Module contract.  Each entry point below names the reference method whose
+ * arithmetic it replaces (file:line under the reference tree).  INTEGRATION.md shows the ctypes
+ * stub that binds them from the files under puresound/nnet/.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *   - tensors are fp32; activations use the padded layout [N][C][ldt] with ldt % 128 == 0,
+ *     ldt >= T, row-major, frames contiguous ("frame-major rows");
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue work,
+ *     they never allocate, synchronise or copy to the host, so they can be captured in a hipGraph;
+ *   - return value: 0 on success, a negative PS_E_* code on argument errors, a positive hipError_t
+ *     on launch failure; ps_last_error() gives a thread-local message;
+ *   - inputs are never modified unless a parameter is documented in/out.
+ */
+#ifndef PURESOUND_HIP_H
+#define PURESOUND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_ABI_VERSION 1
+
+#define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
+#define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
+#define PS_E_UNSUPPORTED (-3) /* valid in the reference, not implemented here (says which) */
+
+/* normalisation that follows a convolution; applied in the CONSUMER's prologue */
+#define PS_NORM_NONE 0   /* identity */
+#define PS_NORM_GLOBAL 1 /* gLN / gGN: per-utterance mean,var over [C,T] (lobe/norm.py:20-34,96) */
+#define PS_NORM_AFFINE 2 /* per-channel scale/shift only (eval BatchNorm1d folded; lobe/norm.py:94) */
+
+#define PS_ACT_LINEAR 0
+#define PS_ACT_RELU 1
+#define PS_ACT_SIGMOID 2
+
+#define PS_OUT_CLAMP 0   /* clamp_(-1,1)  (base_nn.py:415-416) */
+#define PS_OUT_SIGMOID 1 /* sigmoid       (base_nn.py:418-419) */
+#define PS_OUT_NONE 2    /* raw decoder output (module-level FreeEncDec.inverse) */
+
+int ps_abi_version(void);
+const char* ps_last_error(void);
+
+/* Number of doubles a stats buffer needs: partial (sum, sum-of-squares) slabs per utterance.
+ * Stats are handed from the producing kernel to the consuming kernel as per-workgroup partials
+ * (deterministic; no atomics).  ps_stats_parts() is an upper bound for any kernel here. */
+int ps_stats_parts(int channels, int frames);
+
+/* round up T to the padded row length the kernels require */
+int ps_padded_frames(int frames);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout helpers: compact [N][C][T] <-> padded [N][C][ldt].
+ * ------------------------------------------------------------------------------------------- */
+int ps_pad_rows_f32(const float* src, float* dst, int64_t rows, int T, int ldt, void* stream);
+int ps_unpad_rows_f32(const float* src, float* dst, int64_t rows, int T, int ldt, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * FreeEncDec.forward (puresound/nnet/lobe/encoder.py:71-83):
+ *   feats[n][c][t] = act( sum_j w[c][j] * wav[n][t*hop + j] ),  T = floor((L-win)/hop)+1
+ * w is the checkpoint tensor encoder.weight [C][1][win] as stored.  relu = output_active.
+ * ------------------------------------------------------------------------------------------- */
+int ps_free_encode_f32(const float* wav, const float* w, float* feats, int N, int L, int C, int win,
+                       int hop, int T, int ldt, int relu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * get_mask + apply_tf_masks(real,real) + FreeEncDec.inverse + _wav_output_constrain
+ * (base_nn.py:81-95, 146-159, 414-424; lobe/encoder.py:85-94):
+ *   e = feats * act(mask)            (mask == NULL: e = feats)
+ *   out[n][s] = constrain( sum_c sum_{t: 0 <= s-t*hop < win} w[c][s-t*hop] * e[n][c][t] )
+ * w is decoder.weight [C][1][win].  out is compact [N][Lout], Lout = (T-1)*hop+win.
+ * ------------------------------------------------------------------------------------------- */
+int ps_free_decode_f32(const float* feats, const float* mask, int mask_act, const float* w, float* out,
+                       int N, int C, int T, int ldt, int win, int hop, int out_mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused 1x1 convolution (the Conv-TasNet channel-mixing GEMM; exact-fp32 MFMA):
+ *   a[k][t]   = prologue(x[n][k][t])                       -- norm-apply + PReLU of the PRODUCER
+ *   y[n][m][t] = sum_k W[m][k] * a[k][t] + bias[m] (+ bias_n[n][m]) (+ res[n][m][t])
+ *   ostats[n][part] = partial (sum, sumsq) of y over valid (m < M, t < T)
+ * Replaces: TCN.in_conv conv (conv_tasnet.py:43-46), DepthwiseSeparableConv1d.pointwise conv
+ * (lobe/cnn.py:75-79), TCN.out_conv + residual (conv_tasnet.py:65,87-88), together with the
+ * GlobLN / GroupNorm(1) / BatchNorm1d(eval) + PReLU that precede them (lobe/norm.py:20-34,94,96).
+ *
+ * wt is the weight TRANSPOSED and zero padded to [Kp][Mp], Kp = ceil16(K), Mp = ceil256(M).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ps_prologue {
+  int norm;              /* PS_NORM_* */
+  int prelu;             /* 1: apply PReLU(slope[0]) after the norm */
+  const double* stats;   /* [N][parts][2] partials written by the producer (PS_NORM_GLOBAL) */
+  int parts;
+  double count;          /* number of elements the statistics cover (C*T of the producer) */
+  float eps;
+  const float* gamma;    /* [K] gain  (PS_NORM_GLOBAL) or folded scale (PS_NORM_AFFINE) */
+  const float* beta;     /* [K] bias  (PS_NORM_GLOBAL) or folded shift (PS_NORM_AFFINE) */
+  const float* slope;    /* [1] PReLU slope */
+} ps_prologue;
+
+int ps_conv1x1_f32(const float* x, const float* wt, float* y, int N, int K, int M, int T, int ldt,
+                   const ps_prologue* pro, const float* bias, const float* bias_n /* [N][M] or NULL */,
+                   const float* res /* [N][M][ldt] or NULL; may alias y */, double* ostats /* or NULL */,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused depthwise dilated convolution (lobe/cnn.py:62-74, 97):
+ *   a = prologue(x);  y[n][h][t] = b[h] + sum_j w[h][j] * a[n][h][t + j*dilation - left]  (0 outside [0,T))
+ * left = ((P-1)/2)*dilation non-causal, (P-1)*dilation causal (the reference pads both sides and
+ * trims the tail after the pointwise conv, lobe/cnn.py:58-60,100-101 -- same result).
+ * w is depthwise.0.weight [H][1][P].
+ * ------------------------------------------------------------------------------------------- */
+int ps_dwconv_f32(const float* x, const float* w, const float* b, float* y, int N, int H, int T, int ldt,
+                  int P, int dilation, int left, const ps_prologue* pro, double* ostats, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-utterance embedding bias for TCN blocks built with emb_dim > 0 (conv_tasnet.py:80-85):
+ * the reference repeats dvec over T and concatenates it to x; the constant channels contribute
+ *   bias_n[n][m] = sum_e W[m][C+e] * dvec_hat[n][e],  dvec_hat = dvec / max(||dvec||_2, 1e-12) if normalize
+ * (F.normalize, conv_tasnet.py:348-349).  w_embed is [M][E] (the trailing E columns of in_conv.0.weight).
+ * ------------------------------------------------------------------------------------------- */
+int ps_embed_bias_f32(const float* dvec, const float* w_embed, float* bias_n, int N, int E, int M,
+                      int normalize, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One "normal" TCN block and the whole Conv-TasNet masker (conv_tasnet.py:67-90, 338-359).
+ * All weights are device pointers in the packed forms documented above.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ps_tcn_block {
+  int C, H, P, dilation, causal;
+  int in_norm, dw_norm, pw_norm; /* PS_NORM_GLOBAL or PS_NORM_AFFINE */
+  const float* in_wt;            /* [ceil16(C)][ceil256(H)] */
+  const float* in_embed_w;       /* [H][E] or NULL */
+  int E;
+  const float *in_gamma, *in_beta, *in_slope;
+  const float *dw_w, *dw_b, *dw_gamma, *dw_beta, *dw_slope;
+  const float *pw_wt, *pw_b, *pw_gamma, *pw_beta, *pw_slope; /* pw_wt [ceil16(H)][ceil256(H)] */
+  const float *out_wt, *out_b;                                /* out_wt [ceil16(H)][ceil256(C)] */
+} ps_tcn_block;
+
+/* bytes of scratch ps_conv_tasnet_f32 needs for a batch (3 hidden maps + stats + embed bias) */
+size_t ps_conv_tasnet_workspace_bytes(int N, int C, int H, int T);
+
+/* x_in [N][C][ldt] is read only; x_out [N][C][ldt] receives the mask logits (pre-constraint).
+ * dvec [N][E] may be NULL; blocks_host is a HOST array (it only carries launch arguments). */
+int ps_conv_tasnet_f32(const ps_tcn_block* blocks_host, int n_blocks, const float* x_in, float* x_out,
+                       const float* dvec, int embed_norm, int N, int T, int ldt, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PURESOUND_HIP_H */

@@ -1,0 +1,408 @@
+"""CPU oracle for the separator forward path -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+This file restates, in plain tensor arithmetic on the CPU, the algorithm that
+mcw519/PureSound runs for ``SoTaskWrapModule.inference`` (encoder -> Conv-TasNet
+masker -> mask -> decoder -> clamp).  It exists only so that tests, the smoke
+check and ``bench.py``'s ``cpu_baseline`` leg have something to compare the HIP
+path against.  Nothing under ``puresound_amd/`` may import it.
+
+Every function is state_dict driven: it takes the flat ``{key: tensor}`` mapping
+of a reference checkpoint plus a key prefix, so the same weights can be fed to
+the reference (when generating ``tests/golden``), to this oracle and to the HIP
+path.  All arithmetic runs in the dtype of the inputs (fp32 for parity, fp64 to
+estimate the reference's own rounding noise).
+
+Pinning: ``tests/golden/make_golden.py`` imports the real reference from
+/root/reference, feeds it formula-generated weights and stores inputs/outputs;
+``tests/test_oracle_golden.py`` checks this file against those vectors.  The
+reference's own tests hold no value vectors for this path,
+so the fixtures generated from the imported reference are the pin.
+
+The restatement deliberately avoids ``F.conv1d`` / ``nn.GroupNorm`` / ``F.fold``
+so it is an independent statement of the maths, not the same ATen calls.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+SD = Dict[str, torch.Tensor]
+
+
+# ---------------------------------------------------------------------------
+# elementary pieces
+# ---------------------------------------------------------------------------
+def prelu(x: torch.Tensor, slope: torch.Tensor) -> torch.Tensor:
+    """nn.PReLU() with one shared slope (reference: conv_tasnet.py:48, cnn.py:73,78)."""
+    return torch.where(x >= 0, x, slope.to(x.dtype).reshape(1, -1, 1) * x)
+
+
+def conv1x1(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Conv1d(kernel_size=1) on [N,K,T] with weight [M,K,1] (conv_tasnet.py:44-46,65; cnn.py:76)."""
+    y = torch.matmul(w[:, :, 0].to(x.dtype), x)
+    if b is not None:
+        y = y + b.to(x.dtype).reshape(1, -1, 1)
+    return y
+
+
+def glob_ln(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """GlobLN (lobe/norm.py:20-34): stats over every dim but batch, two-pass variance."""
+    dims = list(range(1, x.dim()))
+    mean = x.mean(dim=dims, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=dims, keepdim=True)
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    return gamma.to(x.dtype).reshape(shape) * ((x - mean) / torch.sqrt(var + eps)) + beta.to(x.dtype).reshape(shape)
+
+
+def group_norm1(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """gGN = nn.GroupNorm(1, C, eps=1e-8) (lobe/norm.py:96): same maths as GlobLN, keys weight/bias."""
+    return glob_ln(x, weight, bias, eps)
+
+
+def chan_ln(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """ChanLN (lobe/norm.py:37-50): per-frame stats over the channel axis, biased variance."""
+    mean = x.mean(dim=1, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=1, keepdim=True)
+    return gamma.to(x.dtype).reshape(1, -1, 1) * ((x - mean) / torch.sqrt(var + eps)) + beta.to(x.dtype).reshape(1, -1, 1)
+
+
+def batch_norm_eval(x: torch.Tensor, sd: SD, p: str, eps: float = 1e-5) -> torch.Tensor:
+    """nn.BatchNorm1d in eval mode (lobe/norm.py:94): running stats -> per-channel affine."""
+    rm = sd[p + "running_mean"].to(x.dtype).reshape(1, -1, 1)
+    rv = sd[p + "running_var"].to(x.dtype).reshape(1, -1, 1)
+    w = sd[p + "weight"].to(x.dtype).reshape(1, -1, 1)
+    b = sd[p + "bias"].to(x.dtype).reshape(1, -1, 1)
+    return (x - rm) / torch.sqrt(rv + eps) * w + b
+
+
+def apply_norm(x: torch.Tensor, sd: SD, p: str, kind: str) -> torch.Tensor:
+    """get_norm dispatch (lobe/norm.py:100-112)."""
+    if kind == "gLN":
+        return glob_ln(x, sd[p + "gamma"], sd[p + "beta"])
+    if kind == "cLN":
+        return chan_ln(x, sd[p + "gamma"], sd[p + "beta"])
+    if kind == "gGN":
+        return group_norm1(x, sd[p + "weight"], sd[p + "bias"])
+    if kind == "bN1d":
+        return batch_norm_eval(x, sd, p)
+    raise NameError("Could not interpret normalization identifier")
+
+
+def dilated_conv(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dilation: int, padding: int) -> torch.Tensor:
+    """Conv1d(k taps, dilation, zero padding both sides).  w is [M, K/groups, P].
+
+    Depthwise when w.shape[1] == 1 (cnn.py:62-71), dense otherwise (conv_tasnet.py:133-142).
+    Output length T + 2*padding - (P-1)*dilation.
+    """
+    n, k, t = x.shape
+    m, kg, p = w.shape
+    xp = torch.zeros(n, k, t + 2 * padding, dtype=x.dtype)
+    xp[:, :, padding:padding + t] = x
+    t_out = t + 2 * padding - (p - 1) * dilation
+    y = torch.zeros(n, m, t_out, dtype=x.dtype)
+    for j in range(p):
+        seg = xp[:, :, j * dilation:j * dilation + t_out]
+        if kg == 1 and m == k:
+            y = y + w[:, 0, j].to(x.dtype).reshape(1, -1, 1) * seg
+        else:
+            y = y + torch.matmul(w[:, :, j].to(x.dtype), seg)
+    if b is not None:
+        y = y + b.to(x.dtype).reshape(1, -1, 1)
+    return y
+
+
+# ---------------------------------------------------------------------------
+# lobes: encoders / decoders
+# ---------------------------------------------------------------------------
+def num_frames(length: int, win: int, hop: int) -> int:
+    return (length - win) // hop + 1
+
+
+def frame(wav: torch.Tensor, win: int, hop: int) -> torch.Tensor:
+    """[N,L] -> [N,T,win] strided framing, T = floor((L-win)/hop)+1."""
+    return wav.unfold(-1, win, hop)
+
+
+def overlap_add_sum(frames: torch.Tensor, hop: int) -> torch.Tensor:
+    """[N,T,win] -> [N,(T-1)*hop+win]; overlapping samples are SUMMED
+    (ConvTranspose1d, encoder.py:62-69; fold, stft.py:103-106)."""
+    n, t, win = frames.shape
+    out = torch.zeros(n, (t - 1) * hop + win, dtype=frames.dtype)
+    for i in range(t):
+        out[:, i * hop:i * hop + win] += frames[:, i]
+    return out
+
+
+def overlap_add_sum_fast(frames: torch.Tensor, hop: int) -> torch.Tensor:
+    """Same as overlap_add_sum, without the per-frame Python loop (for long inputs)."""
+    n, t, win = frames.shape
+    out = torch.zeros(n, (t - 1) * hop + win, dtype=frames.dtype)
+    idx = (torch.arange(t).reshape(-1, 1) * hop + torch.arange(win).reshape(1, -1)).reshape(-1)
+    out.index_add_(1, idx, frames.reshape(n, -1))
+    return out
+
+
+def free_encode(wav: torch.Tensor, w: torch.Tensor, hop: int, relu: bool = False) -> torch.Tensor:
+    """FreeEncDec.forward (lobe/encoder.py:71-83): Conv1d(1->C, k=win, stride=hop, bias=False) [+ReLU]."""
+    win = w.shape[-1]
+    fr = frame(wav, win, hop)  # [N,T,win]
+    feats = torch.matmul(w[:, 0, :].to(wav.dtype), fr.transpose(1, 2))  # [N,C,T]
+    return torch.relu(feats) if relu else feats
+
+
+def free_decode(feats: torch.Tensor, w: torch.Tensor, hop: int) -> torch.Tensor:
+    """FreeEncDec.inverse (lobe/encoder.py:85-94): ConvTranspose1d(C->1, k=win, stride=hop, bias=False)."""
+    fr = torch.matmul(feats.transpose(1, 2), w[:, 0, :].to(feats.dtype))  # [N,T,win]
+    return overlap_add_sum_fast(fr, hop)
+
+
+def stft_encode(wav: torch.Tensor, wsin: torch.Tensor, wcos: torch.Tensor, hop: int) -> torch.Tensor:
+    """ConvSTFT.forward, output_format="Complex" (lobe/encoder.py:358-382):
+    real = conv(x,wcos), imag = -conv(x,wsin), stacked on a trailing axis -> [N,F,T,2]."""
+    win = wsin.shape[-1]
+    fr = frame(wav, win, hop).transpose(1, 2)  # [N,win,T]
+    re = torch.matmul(wcos[:, 0, :].to(wav.dtype), fr)
+    im = torch.matmul(wsin[:, 0, :].to(wav.dtype), fr)
+    return torch.stack((re, -im), dim=-1)
+
+
+def window_sumsquare(window: torch.Tensor, n_frames: int, hop: int) -> torch.Tensor:
+    """torch_window_sumsquare (lobe/stft.py:109-115): overlap-added window**2."""
+    w2 = (window.flatten() ** 2).reshape(1, 1, -1).repeat(1, n_frames, 1)
+    return overlap_add_sum_fast(w2, hop).flatten()
+
+
+def istft_decode(spec: torch.Tensor, sd: SD, p: str, hop: int) -> torch.Tensor:
+    """ConvSTFT.inverse (lobe/encoder.py:393-456) with extend_fbins (lobe/stft.py:118-125).
+
+    spec [N,F,T,2] with F = n_fft/2+1.  Hermitian-extend to n_fft bins, inverse DFT as two
+    dense products against kernel_{cos,sin}_inv, multiply by the window, divide by n_fft,
+    summing overlap-add, then divide by the window-sum-square wherever it exceeds 1e-10.
+    """
+    kc = sd[p + "kernel_cos_inv"][:, 0, :, 0].to(spec.dtype)  # [n_fft(bins), n_fft(samples)]
+    ks = sd[p + "kernel_sin_inv"][:, 0, :, 0].to(spec.dtype)
+    win = sd[p + "window_mask"].flatten().to(spec.dtype)  # [n_fft]
+    n_fft = kc.shape[0]
+    re, im = spec[..., 0], spec[..., 1]  # [N,F,T]
+    re_full = torch.cat((re, re[:, 1:-1].flip(1)), dim=1)  # [N,n_fft,T]
+    im_full = torch.cat((im, -im[:, 1:-1].flip(1)), dim=1)
+    # conv2d(X[N,1,bins,T], K[n_fft_out, 1, bins, 1]) == K[out,bins] @ X[bins,T]; K indexed [out=?]
+    # kernel_*_inv is [bins, 1, samples, 1] used as conv2d weight [out_ch=bins_index0, in=1, kh=samples...]
+    # i.e. out[o, t] = sum_h K[o, h] * X[h, t] with o = dim0 and h = dim2 of the buffer.
+    a1 = torch.matmul(kc, re_full)
+    b2 = torch.matmul(ks, im_full)
+    real = (a1 - b2) * win.reshape(1, -1, 1)
+    real = real / n_fft
+    out = overlap_add_sum_fast(real.transpose(1, 2).contiguous(), hop)
+    wsum = window_sumsquare(win, spec.shape[2], hop)
+    nz = wsum > 1e-10
+    out[:, nz] = out[:, nz] / wsum[nz]
+    return out
+
+
+def create_fourier_tables(n_fft: int):
+    """create_fourier_kernels(freq_scale="no") (lobe/stft.py:91-96,100): float64 sin/cos -> fp32."""
+    s = torch.arange(n_fft, dtype=torch.float64)
+    k = torch.arange(n_fft // 2 + 1, dtype=torch.float64).reshape(-1, 1)
+    ang = 2 * math.pi * k * s / n_fft
+    return torch.sin(ang).to(torch.float32), torch.cos(ang).to(torch.float32)
+
+
+# ---------------------------------------------------------------------------
+# Conv-TasNet blocks
+# ---------------------------------------------------------------------------
+def ds_conv(x: torch.Tensor, sd: SD, p: str, kernel: int, dilation: int, causal: bool, norm: str) -> torch.Tensor:
+    """DepthwiseSeparableConv1d.forward without hid_channels/skip (lobe/cnn.py:84-106)."""
+    padding = (kernel - 1) * dilation if causal else ((kernel - 1) // 2) * dilation
+    y = dilated_conv(x, sd[p + "depthwise.0.weight"], sd[p + "depthwise.0.bias"], dilation, padding)
+    y = prelu(apply_norm(y, sd, p + "depthwise.1.", norm), sd[p + "depthwise.2.weight"])
+    y = conv1x1(y, sd[p + "pointwise.0.weight"], sd[p + "pointwise.0.bias"])
+    y = prelu(apply_norm(y, sd, p + "pointwise.1.", norm), sd[p + "pointwise.2.weight"])
+    if causal:
+        y = y[..., :-padding]
+    return y
+
+
+def tcn_block(x: torch.Tensor, sd: SD, p: str, kernel: int, dilation: int, causal: bool,
+              tcn_norm: str, dconv_norm: str, embed: Optional[torch.Tensor] = None,
+              taps: Optional[dict] = None) -> torch.Tensor:
+    """TCN.forward (conv_tasnet.py:67-90)."""
+    res = x
+    if embed is not None:
+        e = embed.to(x.dtype).unsqueeze(2).expand(-1, -1, x.shape[2])
+        x = torch.cat([x, e], dim=1)
+    y = conv1x1(x, sd[p + "in_conv.0.weight"])
+    if taps is not None:
+        taps["in_conv_raw"] = y
+    y = prelu(apply_norm(y, sd, p + "in_conv.1.", tcn_norm), sd[p + "in_conv.2.weight"])
+    y = ds_conv(y, sd, p + "dconv.0.", kernel, dilation, causal, dconv_norm)
+    y = conv1x1(y, sd[p + "out_conv.weight"], sd[p + "out_conv.bias"])
+    return y + res
+
+
+def gated_tcn_block(x: torch.Tensor, sd: SD, p: str, kernel: int, dilation: int, causal: bool,
+                    tcn_norm: str, use_film: bool, embed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GatedTCN.forward (conv_tasnet.py:178-215)."""
+    padd = (kernel - 1) * dilation // 2 if not causal else (kernel - 1) * dilation
+    res = x
+    h = conv1x1(x, sd[p + "in_conv.weight"])
+    if embed is not None:
+        if not use_film:
+            e = embed.to(x.dtype).unsqueeze(-1).expand(-1, -1, h.shape[2])
+            h_r = torch.cat([h, e], dim=1)
+        else:
+            condi = embed.to(x.dtype).unsqueeze(-1)
+            h_r = conv1x1(condi, sd[p + "cond_scale.weight"]) * h + conv1x1(condi, sd[p + "cond_bias.weight"])
+    else:
+        h_r = h
+    left = dilated_conv(h, sd[p + "left_conv.0.weight"], None, dilation, padd)
+    left = prelu(apply_norm(left, sd, p + "left_conv.1.", tcn_norm), sd[p + "left_conv.2.weight"])
+    right = dilated_conv(h_r, sd[p + "right_conv.0.weight"], None, dilation, padd)
+    right = prelu(apply_norm(right, sd, p + "right_conv.1.", tcn_norm), sd[p + "right_conv.2.weight"])
+    right = torch.sigmoid(right)
+    y = conv1x1(left * right, sd[p + "out_conv.weight"])
+    if causal:
+        return y[..., :-padd] + res
+    return y + res
+
+
+def conv_tasnet(x: torch.Tensor, sd: SD, p: str, args: dict, dvec: Optional[torch.Tensor] = None,
+                taps: Optional[dict] = None) -> torch.Tensor:
+    """ConvTasNet.forward (conv_tasnet.py:338-359).  ``args`` is the dict ``get_args`` returns (:361-377)."""
+    if args["embed_norm"] and dvec is not None:
+        dvec = dvec / dvec.norm(p=2, dim=1, keepdim=True).clamp_min(1e-12)  # F.normalize
+    layer = args["tcn_layer"].lower()
+    if layer not in ("normal", "gated"):
+        raise NameError
+    assert args["per_tcn_stack"] == len(args["tcn_with_embed"])
+    for r in range(args["repeat_tcn"]):
+        for i in range(args["per_tcn_stack"]):
+            bp = f"{p}tcn_list.{r}.{i}."
+            e = dvec if args["tcn_with_embed"][i] else None
+            d = args["tcn_dilated_basic"] ** i
+            if layer == "normal":
+                x = tcn_block(x, sd, bp, args["tcn_kernel"], d, args["causal"], args["tcn_norm"],
+                              args["dconv_norm"], e)
+            else:
+                x = gated_tcn_block(x, sd, bp, args["tcn_kernel"], d, args["causal"], args["tcn_norm"],
+                                    args.get("use_film", False), e)
+            if taps is not None and r == 0 and i == 0:
+                taps["block0"] = x
+    return x
+
+
+# ---------------------------------------------------------------------------
+# speaker branch (config 3)
+# ---------------------------------------------------------------------------
+def attentive_stats_pooling(x: torch.Tensor, sd: SD, p: str, eps: float = 1e-12) -> torch.Tensor:
+    """AttentiveStatisticsPooling.forward with lengths=None (lobe/pooling.py:87-126) -> [N,2C,1]."""
+    a = conv1x1(x, sd[p + "tdnn.0.weight"], sd[p + "tdnn.0.bias"])
+    a = batch_norm_eval(torch.relu(a), sd, p + "tdnn.2.")
+    a = conv1x1(torch.tanh(a), sd[p + "conv.weight"], sd[p + "conv.bias"])
+    a = torch.softmax(a, dim=2)
+    mean = (a * x).sum(2)
+    std = torch.sqrt((a * (x - mean.unsqueeze(2)) ** 2).sum(2).clamp(eps))
+    return torch.cat((mean, std), dim=1).unsqueeze(2)
+
+
+# ---------------------------------------------------------------------------
+# task wrapper
+# ---------------------------------------------------------------------------
+def get_mask(mask: torch.Tensor, constraint: str) -> torch.Tensor:
+    """EncDecMaskerBaseModel.get_mask (base_nn.py:81-95)."""
+    c = constraint.lower()
+    if c == "linear":
+        return mask
+    if c == "relu":
+        return torch.relu(mask)
+    if c == "sigmoid":
+        return torch.sigmoid(mask)
+    raise NotImplementedError
+
+
+def apply_tf_masks(tf_rep: torch.Tensor, mask: torch.Tensor, mask_type: str, f_type: str) -> torch.Tensor:
+    """apply_tf_masks (base_nn.py:41-79): (real,real) product; (complex,complex) complex product
+    of channel-halved re/im -> [N,C/2,T,2] (_mul_c, base_nn.py:97-112)."""
+    mt, ft = mask_type.lower(), f_type.lower()
+    if mt == "complex" and ft == "complex":
+        re, im = torch.chunk(tf_rep, 2, dim=1)
+        mre, mim = torch.chunk(mask, 2, dim=1)
+        return torch.stack([re * mre - im * mim, re * mim + im * mre], dim=-1)
+    if mt == "real" and ft == "real":
+        return tf_rep * mask
+    if mt == "polar" and ft == "polar":
+        raise NotImplementedError("polar masks are not restated in the oracle yet")
+    if mt == "real" and ft == "complex":
+        # the reference reads `mask` before assignment here (base_nn.py:127)
+        raise UnboundLocalError("local variable 'mask' referenced before assignment")
+    raise NameError
+
+
+def output_constrain(wav: torch.Tensor, mode: str) -> torch.Tensor:
+    """_wav_output_constrain (base_nn.py:414-424)."""
+    m = mode.lower()
+    if m == "linear":
+        return wav.clamp(min=-1, max=1)
+    if m == "sigmoid":
+        return torch.sigmoid(wav)
+    raise NameError("Non support type.")
+
+
+def encode_features(wav: torch.Tensor, sd: SD, enc: dict, p: str = "encoder.") -> torch.Tensor:
+    """SoTaskWrapModule._get_feature for one waveform batch (base_nn.py:319-345)."""
+    if enc["kind"] == "free":
+        return free_encode(wav, sd[p + "encoder.weight"], enc["hop"], enc.get("relu", False))
+    if enc["kind"] == "stft":
+        spec = stft_encode(wav, sd[p + "encoder.wsin"], sd[p + "encoder.wcos"], enc["hop"])
+        re, im = spec[..., 0], spec[..., 1]
+        if enc.get("drop_first_bin", False):
+            re, im = re[:, 1:], im[:, 1:]
+        return torch.cat([re, im], dim=1)
+    raise ValueError(enc["kind"])
+
+
+def decode_waveform(enh: torch.Tensor, sd: SD, enc: dict, p: str = "encoder.") -> torch.Tensor:
+    """SoTaskWrapModule._get_waveform (base_nn.py:379-396)."""
+    if enc["kind"] == "free":
+        return free_decode(enh, sd[p + "decoder.weight"], enc["hop"])
+    if enh.dim() != 4:
+        re, im = torch.chunk(enh, 2, dim=1)
+        enh = torch.stack([re, im], dim=-1)
+    if enc.get("drop_first_bin", False):
+        pad = torch.zeros(enh.shape[0], 1, enh.shape[2], 2, dtype=enh.dtype)
+        enh = torch.cat([pad, enh], dim=1)
+    return istft_decode(enh, sd, p + "encoder.", enc["hop"])
+
+
+def speaker_embedding(enroll_feats: torch.Tensor, sd: SD, spk: dict, p: str = "speaker_net.") -> torch.Tensor:
+    """Speaker net of td_tse_conv_tasnet_v0 (egs/tse/model.py:118-135; base_nn.py:697-705):
+    n_tcn TCN blocks -> attentive stats pooling -> Conv1d(2C->E,1,bias=False) -> squeeze(-1)."""
+    x = enroll_feats
+    n = spk["n_tcn"]
+    for i in range(n):
+        x = tcn_block(x, sd, f"{p}{i}.", spk.get("kernel", 3), 2 ** i, False, "gLN", "gGN")
+    x = attentive_stats_pooling(x, sd, f"{p}{n}.")
+    x = conv1x1(x, sd[f"{p}{n + 1}.weight"])
+    return x.squeeze(-1)
+
+
+def inference(noisy: torch.Tensor, sd: SD, cfg: dict, enroll: Optional[torch.Tensor] = None,
+              taps: Optional[dict] = None) -> torch.Tensor:
+    """SoTaskWrapModule.inference (base_nn.py:690-722).
+
+    cfg = {"encoder": {...}, "masker": get_args dict, "mask_constraint", "f_type", "mask_type",
+           "output_constraint", optional "speaker_net": {...}}.
+    """
+    feats = encode_features(noisy, sd, cfg["encoder"])
+    dvec = None
+    if enroll is not None:
+        dvec = speaker_embedding(encode_features(enroll, sd, cfg["encoder"]), sd, cfg["speaker_net"])
+    mask = conv_tasnet(feats, sd, "masker.", cfg["masker"], dvec, taps)
+    mask = get_mask(mask, cfg.get("mask_constraint", "linear"))
+    enh = apply_tf_masks(feats, mask, cfg.get("mask_type", "real"), cfg.get("f_type", "real"))
+    wav = decode_waveform(enh, sd, cfg["encoder"])
+    if taps is not None:
+        taps.update(feats=feats, mask=mask, enh=enh, wav_preclamp=wav, dvec=dvec)
+    return output_constrain(wav, cfg.get("output_constraint", "linear"))

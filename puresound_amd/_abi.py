@@ -1,0 +1,111 @@
+"""ctypes binding of libpuresound_hip.so (the C ABI declared in include/puresound_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpuresound_hip.so")
+ABI_VERSION = 1
+
+PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
+PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
+PS_OUT = {"linear": 0, "sigmoid": 1, "none": 2}
+
+_f = C.POINTER(C.c_float)
+_d = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+
+class Prologue(C.Structure):
+    _fields_ = [("norm", C.c_int), ("prelu", C.c_int), ("stats", _vp), ("parts", C.c_int),
+                ("count", C.c_double), ("eps", C.c_float), ("gamma", _vp), ("beta", _vp), ("slope", _vp)]
+
+
+class TcnBlock(C.Structure):
+    _fields_ = [("C", C.c_int), ("H", C.c_int), ("P", C.c_int), ("dilation", C.c_int), ("causal", C.c_int),
+                ("in_norm", C.c_int), ("dw_norm", C.c_int), ("pw_norm", C.c_int),
+                ("in_wt", _vp), ("in_embed_w", _vp), ("E", C.c_int),
+                ("in_gamma", _vp), ("in_beta", _vp), ("in_slope", _vp),
+                ("dw_w", _vp), ("dw_b", _vp), ("dw_gamma", _vp), ("dw_beta", _vp), ("dw_slope", _vp),
+                ("pw_wt", _vp), ("pw_b", _vp), ("pw_gamma", _vp), ("pw_beta", _vp), ("pw_slope", _vp),
+                ("out_wt", _vp), ("out_b", _vp)]
+
+
+# name -> (restype, argtypes); every symbol include/puresound_hip.h declares
+SIGNATURES = {
+    "ps_abi_version": (C.c_int, []),
+    "ps_last_error": (C.c_char_p, []),
+    "ps_stats_parts": (C.c_int, [C.c_int, C.c_int]),
+    "ps_padded_frames": (C.c_int, [C.c_int]),
+    "ps_pad_rows_f32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
+    "ps_unpad_rows_f32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
+    "ps_free_encode_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
+    "ps_free_decode_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp] + [C.c_int] * 7 + [_vp]),
+    "ps_conv1x1_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 5 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
+    "ps_dwconv_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp]),
+    "ps_embed_bias_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "ps_conv_tasnet_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "ps_conv_tasnet_f32": (C.c_int, [C.POINTER(TcnBlock), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, _vp, C.c_size_t, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the HIP library; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C puresound_amd/csrc`. puresound_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.ps_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libpuresound_hip.so ABI {handle.ps_abi_version()} != binding {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().ps_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device(t: torch.Tensor, what: str) -> None:
+    """The product path is HIP only: refuse CPU tensors loudly instead of falling back."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: puresound_amd runs on a ROCm device only (got a {t.device} tensor); "
+                           f"there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{what}: fp32 tensors only (got {t.dtype})")
+
+
+def padded_frames(t: int) -> int:
+    return (t + 127) // 128 * 128
+
+
+def stats_parts(channels: int, frames: int) -> int:
+    gemm = ((frames + 127) // 128) * ((channels + 255) // 256)
+    dw = ((frames + 1023) // 1024) * ((channels + 15) // 16)
+    return max(gemm, dw)

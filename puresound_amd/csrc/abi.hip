@@ -1,0 +1,189 @@
+// C-ABI glue: error reporting, sizing helpers and the network-level drivers that enqueue one TCN block
+// (conv_tasnet.py:67-90 of mcw519/PureSound) and the whole Conv-TasNet masker (conv_tasnet.py:338-359).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "ps_common.h"
+
+namespace ps {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace ps
+
+using namespace ps;
+
+extern "C" int ps_abi_version(void) { return PS_ABI_VERSION; }
+extern "C" const char* ps_last_error(void) { return g_err; }
+
+extern "C" int ps_padded_frames(int frames) { return frames <= 0 ? 0 : ceil_div(frames, kTileT) * kTileT; }
+
+extern "C" int ps_stats_parts(int channels, int frames) {
+  if (channels <= 0 || frames <= 0) return 0;
+  const int gemm = ceil_div(frames, 128) * ceil_div(channels, 256);
+  const int dw = ceil_div(frames, 1024) * ceil_div(channels, 16);
+  return gemm > dw ? gemm : dw;
+}
+
+// Workspace carve-up for ps_conv_tasnet_f32:
+//   y1, y2, y3 : 3 x [N][H][ldt] fp32
+//   stats      : 3 x [N][parts][2] fp64
+//   bias_n     : [N][H] fp32 (only with an embedding)
+struct TasnetWs {
+  float *y1, *y2, *y3, *bias_n;
+  double *s1, *s2, *s3;
+  int parts;
+  size_t bytes;
+};
+
+static TasnetWs carve(void* base, int N, int H, int T) {
+  TasnetWs w{};
+  const int ldt = ps_padded_frames(T);
+  // parts must cover producers with up to max(C,H) channels; H is what every stats producer emits
+  w.parts = ps_stats_parts(H, T);
+  const size_t map = align_up((size_t)N * H * ldt * sizeof(float), 256);
+  const size_t st = align_up((size_t)N * w.parts * 2 * sizeof(double), 256);
+  const size_t bn = align_up((size_t)N * H * sizeof(float), 256);
+  char* p = (char*)base;
+  w.y1 = (float*)p; p += map;
+  w.y2 = (float*)p; p += map;
+  w.y3 = (float*)p; p += map;
+  w.s1 = (double*)p; p += st;
+  w.s2 = (double*)p; p += st;
+  w.s3 = (double*)p; p += st;
+  w.bias_n = (float*)p; p += bn;
+  w.bytes = (size_t)(p - (char*)base);
+  return w;
+}
+
+extern "C" size_t ps_conv_tasnet_workspace_bytes(int N, int C, int H, int T) {
+  (void)C;
+  if (N <= 0 || H <= 0 || T <= 0) return 0;
+  return carve(nullptr, N, H, T).bytes;
+}
+
+static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, const float* dvec, int embed_norm,
+                     int N, int T, int ldt, const TasnetWs& w, void* stream) {
+  int rc;
+  const float eps = 1e-8f;  // GlobLN.eps and gGN's eps (lobe/norm.py:10,96); folded BN carries its own
+  const double count = (double)b.H * (double)T;
+  const int gemm_parts_h = ceil_div(T, 128) * ceil_div(b.H, 256);
+  const int dw_parts = ceil_div(T, 1024) * ceil_div(b.H, 16);
+
+  // 1) in_conv (no bias) [+ per-utterance embedding bias]; stats of y1
+  const float* bias_n = nullptr;
+  if (b.in_embed_w) {
+    if (!dvec) {
+      set_error("ps_conv_tasnet_f32: block expects an embedding (E=%d) but dvec is NULL", b.E);
+      return PS_E_INVALID;
+    }
+    rc = ps_embed_bias_f32(dvec, b.in_embed_w, w.bias_n, N, b.E, b.H, embed_norm, stream);
+    if (rc) return rc;
+    bias_n = w.bias_n;
+  }
+  rc = ps_conv1x1_f32(x_in, b.in_wt, w.y1, N, b.C, b.H, T, ldt, nullptr, nullptr, bias_n, nullptr,
+                      b.in_norm == PS_NORM_GLOBAL ? w.s1 : nullptr, stream);
+  if (rc) return rc;
+
+  // 2) depthwise: prologue = in_conv's norm + PReLU; stats of y2
+  ps_prologue p1{};
+  p1.norm = b.in_norm;
+  p1.prelu = 1;
+  p1.stats = w.s1;
+  p1.parts = gemm_parts_h;
+  p1.count = count;
+  p1.eps = eps;
+  p1.gamma = b.in_gamma;
+  p1.beta = b.in_beta;
+  p1.slope = b.in_slope;
+  const int left = b.causal ? (b.P - 1) * b.dilation : ((b.P - 1) / 2) * b.dilation;
+  rc = ps_dwconv_f32(w.y1, b.dw_w, b.dw_b, w.y2, N, b.H, T, ldt, b.P, b.dilation, left, &p1,
+                     b.dw_norm == PS_NORM_GLOBAL ? w.s2 : nullptr, stream);
+  if (rc) return rc;
+
+  // 3) pointwise: prologue = depthwise norm + PReLU; stats of y3
+  ps_prologue p2{};
+  p2.norm = b.dw_norm;
+  p2.prelu = 1;
+  p2.stats = w.s2;
+  p2.parts = dw_parts;
+  p2.count = count;
+  p2.eps = eps;
+  p2.gamma = b.dw_gamma;
+  p2.beta = b.dw_beta;
+  p2.slope = b.dw_slope;
+  rc = ps_conv1x1_f32(w.y2, b.pw_wt, w.y3, N, b.H, b.H, T, ldt, &p2, b.pw_b, nullptr, nullptr,
+                      b.pw_norm == PS_NORM_GLOBAL ? w.s3 : nullptr, stream);
+  if (rc) return rc;
+
+  // 4) out_conv + bias + residual: prologue = pointwise norm + PReLU
+  ps_prologue p3{};
+  p3.norm = b.pw_norm;
+  p3.prelu = 1;
+  p3.stats = w.s3;
+  p3.parts = gemm_parts_h;
+  p3.count = count;
+  p3.eps = eps;
+  p3.gamma = b.pw_gamma;
+  p3.beta = b.pw_beta;
+  p3.slope = b.pw_slope;
+  return ps_conv1x1_f32(w.y3, b.out_wt, x_out, N, b.H, b.C, T, ldt, &p3, b.out_b, nullptr, x_in, nullptr, stream);
+}
+
+extern "C" int ps_conv_tasnet_f32(const ps_tcn_block* blocks, int n_blocks, const float* x_in, float* x_out,
+                                  const float* dvec, int embed_norm, int N, int T, int ldt, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!blocks || n_blocks <= 0 || !x_in || !x_out || !workspace || N <= 0 || T <= 0) {
+    set_error("ps_conv_tasnet_f32: null pointer or non-positive size");
+    return PS_E_INVALID;
+  }
+  if (x_in == x_out) {
+    set_error("ps_conv_tasnet_f32: x_in must not alias x_out (the input is never modified)");
+    return PS_E_INVALID;
+  }
+  if (ldt != ps_padded_frames(T)) {
+    set_error("ps_conv_tasnet_f32: ldt=%d must be ps_padded_frames(T=%d)=%d", ldt, T, ps_padded_frames(T));
+    return PS_E_ALIGN;
+  }
+  const int C = blocks[0].C, H = blocks[0].H;
+  for (int i = 0; i < n_blocks; ++i) {
+    const ps_tcn_block& b = blocks[i];
+    if (b.C != C || b.H != H || b.P <= 0 || b.dilation <= 0) {
+      set_error("ps_conv_tasnet_f32: block %d has inconsistent sizes (C=%d H=%d P=%d dilation=%d)", i, b.C, b.H, b.P,
+                b.dilation);
+      return PS_E_INVALID;
+    }
+    if (b.causal && (b.in_norm == PS_NORM_GLOBAL || b.dw_norm == PS_NORM_GLOBAL || b.pw_norm == PS_NORM_GLOBAL)) {
+      // reference: AssertionError in DepthwiseSeparableConv1d (lobe/cnn.py:40-44)
+      set_error("ps_conv_tasnet_f32: block %d: global norms conflict with causal=1", i);
+      return PS_E_INVALID;
+    }
+  }
+  if (workspace_bytes < ps_conv_tasnet_workspace_bytes(N, C, H, T)) {
+    set_error("ps_conv_tasnet_f32: workspace too small (%zu < %zu)", workspace_bytes,
+              ps_conv_tasnet_workspace_bytes(N, C, H, T));
+    return PS_E_INVALID;
+  }
+  if ((uintptr_t)workspace & 255) {
+    set_error("ps_conv_tasnet_f32: workspace must be 256-byte aligned");
+    return PS_E_ALIGN;
+  }
+  const TasnetWs w = carve(workspace, N, H, T);
+  // block 0 reads the caller's input and writes x_out; later blocks update x_out in place (each
+  // workgroup reads exactly the residual elements it overwrites).
+  for (int i = 0; i < n_blocks; ++i) {
+    const int rc = run_block(blocks[i], i == 0 ? x_in : x_out, x_out, dvec, embed_norm, N, T, ldt, w, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}

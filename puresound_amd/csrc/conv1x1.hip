@@ -1,0 +1,246 @@
+// Fused 1x1 convolution for the Conv-TasNet TCN blocks: exact-fp32 MFMA GEMM with the producer's
+// normalisation + PReLU applied while staging the activation tile, and bias / residual / partial
+// statistics in the epilogue.
+//
+//   y[n][m][t] = sum_k W[m][k] * pro(x[n][k][t]) + bias[m] (+ bias_n[n][m]) (+ res[n][m][t])
+//
+// Reference arithmetic replaced: conv_tasnet.py:43-49,65,85-88 and lobe/cnn.py:75-79 of mcw519/PureSound.
+//
+// Mapping to CDNA4: D = A*B with A = W (rows = output channel m) and B = activations (cols = frame t),
+// v_mfma_f32_32x32x2_f32.  Both operands are staged k-major in LDS ([k][m] and [k][t]) so that the 32
+// lanes of a half-wave read 32 consecutive dwords (conflict-free ds_read_b32); the weight is stored
+// pre-transposed in HBM for that reason.  A 256-thread workgroup owns a 256(m) x 128(t) output tile;
+// each of its 4 waves owns 64(m) x 128(t) = 2x4 MFMA tiles (128 accumulator VGPRs), so one k-pair costs
+// 2+4 LDS reads for 8 MFMAs.  K is consumed in steps of 16 through a 2-deep LDS ring; the global loads
+// of step s+1 are issued before the MFMAs of step s and written to LDS after them (one barrier per step).
+#include "ps_common.h"
+
+namespace ps {
+
+constexpr int BM = 256;
+constexpr int BT = 128;
+constexpr int BK = 16;
+
+struct Conv1x1Args {
+  const float* x;
+  const float* wt;
+  float* y;
+  const float* bias;
+  const float* bias_n;
+  const float* res;
+  double* ostats;
+  ps_prologue pro;
+  int K, M, T, ldt, Mp;
+};
+
+__global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BT];
+  __shared__ double red[8];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int n = blockIdx.z;
+  const int m0 = blockIdx.y * BM;
+  const int t0 = blockIdx.x * BT;
+
+  const NormScalars ns = load_norm_scalars(a.pro, n, red);
+  const bool transform = a.pro.norm != PS_NORM_NONE || a.pro.prelu;
+  const float slope = a.pro.prelu ? a.pro.slope[0] : 1.f;
+
+  const float* xg = a.x + (size_t)n * a.K * a.ldt + t0;
+  const float* wg = a.wt + m0;
+
+  // staging coordinates
+  const int a_row = tid >> 6;         // +4j, j = 0..3
+  const int a_col = (tid & 63) * 4;   // 0..252
+  const int b_row = tid >> 5;         // +8j, j = 0..1
+  const int b_col = (tid & 31) * 4;   // 0..124
+
+  f32x4 ra[4], rb[2];
+  float sc[2], sh[2], mu[2];
+
+  auto load_step = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      ra[j] = *reinterpret_cast<const f32x4*>(wg + (size_t)(k0 + a_row + 4 * j) * a.Mp + a_col);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + b_row + 8 * j;
+      if (k < a.K) {
+        rb[j] = *reinterpret_cast<const f32x4*>(xg + (size_t)k * a.ldt + b_col);
+        if (a.pro.norm != PS_NORM_NONE) {
+          sc[j] = a.pro.gamma[k] * ns.rstd;
+          sh[j] = a.pro.beta[k];
+        } else {
+          sc[j] = 1.f;
+          sh[j] = 0.f;
+        }
+        mu[j] = 1.f;  // marks "row valid"
+      } else {
+        rb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sc[j] = 0.f;
+        sh[j] = 0.f;
+        mu[j] = 0.f;
+      }
+    }
+  };
+
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&As[buf][a_row + 4 * j][a_col]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 v = rb[j];
+      if (transform) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = (v[e] - ns.mean) * sc[j] + sh[j];
+          u = prelu(u, slope);
+          v[e] = mu[j] != 0.f ? u : 0.f;
+        }
+      }
+      *reinterpret_cast<f32x4*>(&Bs[buf][b_row + 8 * j][b_col]) = v;
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ti][r] = 0.f;
+
+  const int nsteps = (a.K + BK - 1) / BK;
+  const bool wave_active = (m0 + wave * 64) < a.M;  // wave-uniform: skip MFMAs on all-padding rows
+  const int lr = lane & 31;
+  const int lk = lane >> 5;
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) load_step((s + 1) * BK);
+    if (wave_active) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int k = 2 * kk + lk;
+        float av[2], bv[4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) av[mi] = As[buf][k][wave * 64 + mi * 32 + lr];
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) bv[ti] = Bs[buf][k][ti * 32 + lr];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti)
+            acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ti], acc[mi][ti], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nsteps) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, residual, store, partial statistics -------------------------------------
+  double ssum = 0.0, ssq = 0.0;
+  if (wave_active) {
+    float* yg = a.y + (size_t)n * a.M * a.ldt;
+    const float* rg = a.res ? a.res + (size_t)n * a.M * a.ldt : nullptr;
+    const float* bn = a.bias_n ? a.bias_n + (size_t)n * a.M : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      float fsum = 0.f, fsq = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wave * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row < a.M) {
+          float bsum = a.bias ? a.bias[row] : 0.f;
+          if (bn) bsum += bn[row];
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti) {
+            const int col = t0 + ti * 32 + lr;
+            if (col < a.T) {
+              float v = acc[mi][ti][r] + bsum;
+              fsum += v;
+              fsq += v * v;
+              const size_t off = (size_t)row * a.ldt + col;
+              if (rg) v += rg[off];
+              yg[off] = v;
+            }
+          }
+        }
+      }
+      ssum += (double)fsum;
+      ssq += (double)fsq;
+    }
+  }
+  if (a.ostats) {
+    block_sum2(ssum, ssq, red);
+    if (tid == 0) {
+      const int parts = gridDim.x * gridDim.y;
+      double* dst = a.ostats + ((size_t)n * parts + blockIdx.y * gridDim.x + blockIdx.x) * 2;
+      dst[0] = ssum;
+      dst[1] = ssq;
+    }
+  }
+}
+
+}  // namespace ps
+
+extern "C" int ps_conv1x1_f32(const float* x, const float* wt, float* y, int N, int K, int M, int T, int ldt,
+                              const ps_prologue* pro, const float* bias, const float* bias_n,
+                              const float* res, double* ostats, void* stream) {
+  using namespace ps;
+  if (!x || !wt || !y || N <= 0 || K <= 0 || M <= 0 || T <= 0) {
+    set_error("ps_conv1x1_f32: null pointer or non-positive size (N=%d K=%d M=%d T=%d)", N, K, M, T);
+    return PS_E_INVALID;
+  }
+  if (ldt < T || ldt % kTileT != 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)wt & 15)) {
+    set_error("ps_conv1x1_f32: ldt=%d must be a multiple of %d >= T=%d and pointers 16-byte aligned", ldt,
+              kTileT, T);
+    return PS_E_ALIGN;
+  }
+  Conv1x1Args a{};
+  a.x = x;
+  a.wt = wt;
+  a.y = y;
+  a.bias = bias;
+  a.bias_n = bias_n;
+  a.res = res;
+  a.ostats = ostats;
+  if (pro) {
+    a.pro = *pro;
+    if (a.pro.norm == PS_NORM_GLOBAL && (!a.pro.stats || a.pro.parts <= 0 || a.pro.count <= 0 || !a.pro.gamma ||
+                                         !a.pro.beta)) {
+      set_error("ps_conv1x1_f32: PS_NORM_GLOBAL prologue needs stats/parts/count/gamma/beta");
+      return PS_E_INVALID;
+    }
+    if (a.pro.norm == PS_NORM_AFFINE && (!a.pro.gamma || !a.pro.beta)) {
+      set_error("ps_conv1x1_f32: PS_NORM_AFFINE prologue needs gamma/beta");
+      return PS_E_INVALID;
+    }
+    if (a.pro.prelu && !a.pro.slope) {
+      set_error("ps_conv1x1_f32: prelu prologue needs slope");
+      return PS_E_INVALID;
+    }
+  } else {
+    a.pro.norm = PS_NORM_NONE;
+  }
+  a.K = K;
+  a.M = M;
+  a.T = T;
+  a.ldt = ldt;
+  a.Mp = (M + BM - 1) / BM * BM;
+  dim3 grid((T + BT - 1) / BT, (M + BM - 1) / BM, N);
+  hipLaunchKernelGGL(conv1x1_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("ps_conv1x1_f32: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}

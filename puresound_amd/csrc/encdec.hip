@@ -1,0 +1,292 @@
+// Learned filterbank encoder / decoder (FreeEncDec, lobe/encoder.py:71-94 of mcw519/PureSound), the
+// mask application + output constraint fused into the decoder (base_nn.py:81-95,146-159,414-424),
+// the padded-layout helpers and the per-utterance embedding bias (conv_tasnet.py:80-85,348-349).
+#include "ps_common.h"
+
+namespace ps {
+
+// ------------------------------------------------------------------------------------------------
+// Encoder: feats[n][c][t] = act(sum_j w[c][j] * wav[n][t*hop + j]).
+// One thread per frame (lanes along t -> coalesced 256-B stores per channel), the frame's window is
+// held in registers (WIN known at compile time) and the filter taps are wave-uniform, so they come
+// in through the scalar cache.  The write of feats (C*4 bytes per frame) dominates: HBM-bound.
+// WIN == 0 selects the run-time window fallback (window re-read through L1).
+// ------------------------------------------------------------------------------------------------
+constexpr int ENC_CCHUNK = 64;
+
+template <int WIN>
+__global__ __launch_bounds__(256) void free_encode_kernel(const float* __restrict__ wav,
+                                                          const float* __restrict__ w,
+                                                          float* __restrict__ feats, int L, int C, int win,
+                                                          int hop, int T, int ldt, int relu) {
+  const int n = blockIdx.z;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int c0 = blockIdx.y * ENC_CCHUNK;
+  const int c1 = min(c0 + ENC_CCHUNK, C);
+  const bool live = t < T;
+  const float* xs = wav + (size_t)n * L + (size_t)(live ? t : 0) * hop;
+  float* out = feats + ((size_t)n * C) * ldt + t;
+  if (WIN > 0) {
+    float xr[WIN > 0 ? WIN : 1];
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) xr[j] = live ? xs[j] : 0.f;
+    for (int c = c0; c < c1; ++c) {
+      const float* wc = w + (size_t)c * WIN;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < WIN; ++j) s = fmaf(wc[j], xr[j], s);
+      if (relu) s = fmaxf(s, 0.f);
+      if (live) out[(size_t)c * ldt] = s;
+    }
+  } else {
+    if (!live) return;
+    for (int c = c0; c < c1; ++c) {
+      const float* wc = w + (size_t)c * win;
+      float s = 0.f;
+      for (int j = 0; j < win; ++j) s = fmaf(wc[j], xs[j], s);
+      if (relu) s = fmaxf(s, 0.f);
+      out[(size_t)c * ldt] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder: e = feats * act(mask); frame_out[t][j] = sum_c w[c][j] * e[c][t]; out = constrain(OLA-sum).
+// One thread per frame accumulates its WIN outputs over all channels (coalesced reads of feats and
+// mask, scalar-cache filter taps); the workgroup overlap-adds through LDS.  A workgroup computes
+// R-1 = ceil(WIN/HOP)-1 halo frames on its left so every output sample is written by exactly one
+// workgroup (no atomics, deterministic).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mask_act(float m, int act) {
+  if (act == PS_ACT_RELU) return fmaxf(m, 0.f);
+  if (act == PS_ACT_SIGMOID) return 1.f / (1.f + expf(-m));
+  return m;
+}
+
+__device__ __forceinline__ float out_constrain(float v, int mode) {
+  if (mode == PS_OUT_CLAMP) return fminf(fmaxf(v, -1.f), 1.f);
+  if (mode == PS_OUT_SIGMOID) return 1.f / (1.f + expf(-v));
+  return v;
+}
+
+template <int WIN, int HOP>
+__global__ __launch_bounds__(256) void free_decode_kernel(const float* __restrict__ feats,
+                                                          const float* __restrict__ mask, int mask_mode,
+                                                          const float* __restrict__ w, float* __restrict__ out,
+                                                          int C, int T, int ldt, int out_mode) {
+  constexpr int R = (WIN + HOP - 1) / HOP;
+  constexpr int BTF = 256 - (R - 1);  // frames owned per workgroup
+  __shared__ float ola[(256 + R) * HOP];
+  const int n = blockIdx.y;
+  const int tl = threadIdx.x;
+  const int tfirst = blockIdx.x * BTF - (R - 1);  // first (halo) frame of this workgroup
+  const int t = tfirst + tl;
+  const bool live = t >= 0 && t < T;
+  const int Lout = (T - 1) * HOP + WIN;
+
+  float acc[WIN];
+#pragma unroll
+  for (int j = 0; j < WIN; ++j) acc[j] = 0.f;
+  if (live) {
+    const float* f = feats + (size_t)n * C * ldt + t;
+    const float* m = mask ? mask + (size_t)n * C * ldt + t : nullptr;
+    for (int c = 0; c < C; ++c) {
+      float e = f[(size_t)c * ldt];
+      if (m) e *= mask_act(m[(size_t)c * ldt], mask_mode);
+      const float* wc = w + (size_t)c * WIN;
+#pragma unroll
+      for (int j = 0; j < WIN; ++j) acc[j] = fmaf(wc[j], e, acc[j]);
+    }
+  }
+  // overlap-add in R conflict-free phases: phase r adds acc[r*HOP .. r*HOP+HOP) at slot (tl + r)
+  for (int i = tl; i < (256 + R) * HOP; i += 256) ola[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int j = 0; j < HOP; ++j) {
+      if (r * HOP + j < WIN) ola[(tl + r) * HOP + j] += acc[r * HOP + j];
+    }
+    __syncthreads();
+  }
+  // owned samples: [t_own0*HOP, t_own1*HOP), the last workgroup also owns the tail up to Lout
+  const int t_own0 = blockIdx.x * BTF;
+  const int last = (t_own0 + BTF >= T);
+  const int s0 = t_own0 * HOP;
+  const int s1 = last ? Lout : (t_own0 + BTF) * HOP;
+  float* o = out + (size_t)n * Lout;
+  for (int s = s0 + tl; s < s1; s += 256) {
+    // slot index in ola: sample s lives at (s - tfirst*HOP)
+    o[s] = out_constrain(ola[s - tfirst * HOP], out_mode);
+  }
+}
+
+// Run-time (win, hop) fallback: one thread per output sample.
+__global__ __launch_bounds__(256) void free_decode_generic_kernel(const float* __restrict__ feats,
+                                                                  const float* __restrict__ mask, int mask_mode,
+                                                                  const float* __restrict__ w,
+                                                                  float* __restrict__ out, int C, int T, int ldt,
+                                                                  int win, int hop, int out_mode) {
+  const int n = blockIdx.y;
+  const int Lout = (T - 1) * hop + win;
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= Lout) return;
+  int t_hi = s / hop;
+  if (t_hi > T - 1) t_hi = T - 1;
+  // smallest frame t with t*hop + win > s
+  const int t_lo = (s - win + 1 <= 0) ? 0 : (s - win + 1 + hop - 1) / hop;
+  float accv = 0.f;
+  for (int t = t_lo; t <= t_hi; ++t) {
+    const int j = s - t * hop;
+    const float* f = feats + (size_t)n * C * ldt + t;
+    const float* m = mask ? mask + (size_t)n * C * ldt + t : nullptr;
+    for (int c = 0; c < C; ++c) {
+      float e = f[(size_t)c * ldt];
+      if (m) e *= mask_act(m[(size_t)c * ldt], mask_mode);
+      accv = fmaf(w[(size_t)c * win + j], e, accv);
+    }
+  }
+  out[(size_t)n * Lout + s] = out_constrain(accv, out_mode);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       int64_t rows, int T, int ldt) {
+  const int64_t row = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (row < rows && t < ldt) dst[row * ldt + t] = t < T ? src[row * T + t] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void unpad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         int64_t rows, int T, int ldt) {
+  const int64_t row = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (row < rows && t < T) dst[row * T + t] = src[row * ldt + t];
+}
+
+// bias_n[n][m] = sum_e W[m][e] * dvec_hat[n][e]; one wave per (n, m).
+__global__ __launch_bounds__(256) void embed_bias_kernel(const float* __restrict__ dvec,
+                                                         const float* __restrict__ w, float* __restrict__ bias_n,
+                                                         int E, int M, int normalize) {
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const float* d = dvec + (size_t)n * E;
+  float nrm = 0.f, dot = 0.f;
+  for (int e = lane; e < E; e += 64) {
+    const float v = d[e];
+    nrm = fmaf(v, v, nrm);
+    if (m < M) dot = fmaf(w[(size_t)m * E + e], v, dot);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    nrm += __shfl_xor(nrm, off, 64);
+    dot += __shfl_xor(dot, off, 64);
+  }
+  if (lane == 0 && m < M) {
+    const float scale = normalize ? 1.f / fmaxf(sqrtf(nrm), 1e-12f) : 1.f;
+    bias_n[(size_t)n * M + m] = dot * scale;
+  }
+}
+
+static int check_launch(const char* who) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", who, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+}  // namespace ps
+
+using namespace ps;
+
+extern "C" int ps_pad_rows_f32(const float* src, float* dst, int64_t rows, int T, int ldt, void* stream) {
+  if (!src || !dst || rows <= 0 || T <= 0 || ldt < T || rows > 0x7fffffff) {
+    set_error("ps_pad_rows_f32: bad argument");
+    return PS_E_INVALID;
+  }
+  // grid.y is limited to 65535: fold rows
+  const int64_t chunk = 65535;
+  for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+    const int64_t nr = rows - r0 < chunk ? rows - r0 : chunk;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((ldt + 255) / 256, (unsigned)nr), dim3(256), 0, (hipStream_t)stream,
+                       src + r0 * T, dst + r0 * ldt, nr, T, ldt);
+  }
+  return check_launch("ps_pad_rows_f32");
+}
+
+extern "C" int ps_unpad_rows_f32(const float* src, float* dst, int64_t rows, int T, int ldt, void* stream) {
+  if (!src || !dst || rows <= 0 || T <= 0 || ldt < T || rows > 0x7fffffff) {
+    set_error("ps_unpad_rows_f32: bad argument");
+    return PS_E_INVALID;
+  }
+  const int64_t chunk = 65535;
+  for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+    const int64_t nr = rows - r0 < chunk ? rows - r0 : chunk;
+    hipLaunchKernelGGL(unpad_rows_kernel, dim3((T + 255) / 256, (unsigned)nr), dim3(256), 0, (hipStream_t)stream,
+                       src + r0 * ldt, dst + r0 * T, nr, T, ldt);
+  }
+  return check_launch("ps_unpad_rows_f32");
+}
+
+extern "C" int ps_free_encode_f32(const float* wav, const float* w, float* feats, int N, int L, int C, int win,
+                                  int hop, int T, int ldt, int relu, void* stream) {
+  if (!wav || !w || !feats || N <= 0 || C <= 0 || win <= 0 || hop <= 0 || L < win) {
+    set_error("ps_free_encode_f32: bad argument (N=%d L=%d C=%d win=%d hop=%d)", N, L, C, win, hop);
+    return PS_E_INVALID;
+  }
+  if (T != (L - win) / hop + 1 || ldt < T || ldt % kTileT != 0) {
+    set_error("ps_free_encode_f32: T=%d must equal floor((L-win)/hop)+1=%d, ldt=%d a multiple of %d >= T", T,
+              (L - win) / hop + 1, ldt, kTileT);
+    return PS_E_INVALID;
+  }
+  dim3 grid((T + 255) / 256, (C + ENC_CCHUNK - 1) / ENC_CCHUNK, N);
+  hipStream_t s = (hipStream_t)stream;
+  if (win == 32)
+    hipLaunchKernelGGL(free_encode_kernel<32>, grid, dim3(256), 0, s, wav, w, feats, L, C, win, hop, T, ldt, relu);
+  else if (win == 16)
+    hipLaunchKernelGGL(free_encode_kernel<16>, grid, dim3(256), 0, s, wav, w, feats, L, C, win, hop, T, ldt, relu);
+  else
+    hipLaunchKernelGGL(free_encode_kernel<0>, grid, dim3(256), 0, s, wav, w, feats, L, C, win, hop, T, ldt, relu);
+  return check_launch("ps_free_encode_f32");
+}
+
+extern "C" int ps_free_decode_f32(const float* feats, const float* mask, int mask_act, const float* w, float* out,
+                                  int N, int C, int T, int ldt, int win, int hop, int out_mode, void* stream) {
+  if (!feats || !w || !out || N <= 0 || C <= 0 || T <= 0 || win <= 0 || hop <= 0 || ldt < T) {
+    set_error("ps_free_decode_f32: bad argument (N=%d C=%d T=%d win=%d hop=%d)", N, C, T, win, hop);
+    return PS_E_INVALID;
+  }
+  if (mask_act < PS_ACT_LINEAR || mask_act > PS_ACT_SIGMOID || out_mode < PS_OUT_CLAMP || out_mode > PS_OUT_NONE) {
+    set_error("ps_free_decode_f32: unknown mask_act=%d or out_mode=%d", mask_act, out_mode);
+    return PS_E_INVALID;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (win == 32 && hop == 16) {
+    constexpr int BTF = 255;
+    hipLaunchKernelGGL((free_decode_kernel<32, 16>), dim3((T + BTF - 1) / BTF, N), dim3(256), 0, s, feats, mask,
+                       mask_act, w, out, C, T, ldt, out_mode);
+  } else if (win == 16 && hop == 8) {
+    constexpr int BTF = 255;
+    hipLaunchKernelGGL((free_decode_kernel<16, 8>), dim3((T + BTF - 1) / BTF, N), dim3(256), 0, s, feats, mask,
+                       mask_act, w, out, C, T, ldt, out_mode);
+  } else {
+    const int Lout = (T - 1) * hop + win;
+    hipLaunchKernelGGL(free_decode_generic_kernel, dim3((Lout + 255) / 256, N), dim3(256), 0, s, feats, mask,
+                       mask_act, w, out, C, T, ldt, win, hop, out_mode);
+  }
+  return check_launch("ps_free_decode_f32");
+}
+
+extern "C" int ps_embed_bias_f32(const float* dvec, const float* w_embed, float* bias_n, int N, int E, int M,
+                                 int normalize, void* stream) {
+  if (!dvec || !w_embed || !bias_n || N <= 0 || E <= 0 || M <= 0) {
+    set_error("ps_embed_bias_f32: bad argument");
+    return PS_E_INVALID;
+  }
+  hipLaunchKernelGGL(embed_bias_kernel, dim3((M + 3) / 4, N), dim3(256), 0, (hipStream_t)stream, dvec, w_embed,
+                     bias_n, E, M, normalize);
+  return check_launch("ps_embed_bias_f32");
+}

@@ -1,0 +1,68 @@
+// Shared device helpers for libpuresound_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/puresound_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace ps {
+
+constexpr int kWave = 64;
+constexpr int kTileT = 128;  // padded-row granule: ldt % kTileT == 0
+
+void set_error(const char* fmt, ...);
+
+// Per-utterance scalars of a global norm, derived from the producer's partial sums.
+struct NormScalars {
+  float mean;
+  float rstd;
+};
+
+// 64-lane butterfly sum of a double (two 32-bit shuffles per step).
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// Sum (a, b) over a 256-thread workgroup; every thread receives the totals.  `red` holds 8 doubles.
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[wave * 2] = a;
+    red[wave * 2 + 1] = b;
+  }
+  __syncthreads();
+  a = red[0] + red[2] + red[4] + red[6];
+  b = red[1] + red[3] + red[5] + red[7];
+  __syncthreads();
+}
+
+// Combine the producer's partials for utterance n into mean / rstd (fp64 combine, deterministic order
+// per thread, butterfly across threads).  biased variance, var = E[x^2] - mean^2.
+__device__ __forceinline__ NormScalars load_norm_scalars(const ps_prologue& p, int n, double* red) {
+  NormScalars s{0.f, 1.f};
+  if (p.norm != PS_NORM_GLOBAL) return s;
+  double a = 0.0, b = 0.0;
+  const double* src = p.stats + (size_t)n * p.parts * 2;
+  for (int i = threadIdx.x; i < p.parts; i += blockDim.x) {
+    a += src[2 * i];
+    b += src[2 * i + 1];
+  }
+  block_sum2(a, b, red);
+  const double mean = a / p.count;
+  double var = b / p.count - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  s.mean = (float)mean;
+  s.rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+  return s;
+}
+
+__device__ __forceinline__ float prelu(float v, float slope) { return v >= 0.f ? v : slope * v; }
+
+}  // namespace ps

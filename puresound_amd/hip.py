@@ -1,0 +1,144 @@
+"""Tensor-level front of the C ABI: each function enqueues exactly one entry point of
+libpuresound_hip.so on the current HIP stream of the tensors' device.  PyTorch is used for device
+memory and streams only; all arithmetic happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _abi
+from ._abi import Prologue, TcnBlock, check, lib, padded_frames, ptr, require_device, stats_parts, stream_ptr
+
+
+def pack_wt(w: torch.Tensor) -> torch.Tensor:
+    """[M,K] (or [M,K,1]) conv weight -> transposed, zero padded [ceil16(K)][ceil256(M)] (see ps_conv1x1_f32)."""
+    if w.dim() == 3:
+        w = w[:, :, 0]
+    m, k = w.shape
+    kp, mp = (k + 15) // 16 * 16, (m + 255) // 256 * 256
+    out = torch.zeros(kp, mp, dtype=torch.float32, device=w.device)
+    out[:k, :m] = w.detach().to(torch.float32).t()
+    return out
+
+
+def pad_rows(x: torch.Tensor) -> torch.Tensor:
+    """compact [..., T] -> padded [..., ldt] (zeros in the pad)."""
+    require_device(x, "pad_rows")
+    x = x.contiguous()
+    t = x.shape[-1]
+    ldt = padded_frames(t)
+    out = torch.empty(*x.shape[:-1], ldt, dtype=torch.float32, device=x.device)
+    rows = x.numel() // t
+    check(lib().ps_pad_rows_f32(ptr(x), ptr(out), rows, t, ldt, stream_ptr(x.device)), "ps_pad_rows_f32")
+    return out
+
+
+def unpad_rows(x: torch.Tensor, t: int) -> torch.Tensor:
+    require_device(x, "unpad_rows")
+    ldt = x.shape[-1]
+    out = torch.empty(*x.shape[:-1], t, dtype=torch.float32, device=x.device)
+    rows = x.numel() // ldt
+    check(lib().ps_unpad_rows_f32(ptr(x), ptr(out), rows, t, ldt, stream_ptr(x.device)), "ps_unpad_rows_f32")
+    return out
+
+
+def free_encode(wav: torch.Tensor, w: torch.Tensor, hop: int, relu: bool = False) -> tuple[torch.Tensor, int]:
+    """wav [N,L], w [C,1,win] -> (feats padded [N,C,ldt], T)."""
+    require_device(wav, "free_encode")
+    wav = wav.contiguous()
+    n, length = wav.shape
+    c, _, win = w.shape
+    if length < win:
+        raise RuntimeError(f"free_encode: input length {length} is shorter than the window {win}")
+    t = (length - win) // hop + 1
+    ldt = padded_frames(t)
+    feats = torch.zeros(n, c, ldt, dtype=torch.float32, device=wav.device)
+    check(lib().ps_free_encode_f32(ptr(wav), ptr(w), ptr(feats), n, length, c, win, hop, t, ldt, int(relu),
+                                   stream_ptr(wav.device)), "ps_free_encode_f32")
+    return feats, t
+
+
+def free_decode(feats: torch.Tensor, t: int, w: torch.Tensor, hop: int, mask: Optional[torch.Tensor] = None,
+                mask_act: str = "linear", out_mode: str = "none") -> torch.Tensor:
+    """feats/mask padded [N,C,ldt] -> waveform [N,(T-1)*hop+win]."""
+    require_device(feats, "free_decode")
+    n, c, ldt = feats.shape
+    win = w.shape[-1]
+    out = torch.empty(n, (t - 1) * hop + win, dtype=torch.float32, device=feats.device)
+    check(lib().ps_free_decode_f32(ptr(feats), ptr(mask), _abi.PS_ACT[mask_act], ptr(w), ptr(out), n, c, t, ldt,
+                                   win, hop, _abi.PS_OUT[out_mode], stream_ptr(feats.device)), "ps_free_decode_f32")
+    return out
+
+
+def make_prologue(norm: int = 0, prelu: bool = False, stats: Optional[torch.Tensor] = None, count: float = 0.0,
+                  eps: float = 1e-8, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
+                  slope: Optional[torch.Tensor] = None) -> Prologue:
+    p = Prologue()
+    p.norm, p.prelu = norm, int(prelu)
+    p.stats = ptr(stats)
+    p.parts = 0 if stats is None else stats.shape[1]
+    p.count, p.eps = float(count), float(eps)
+    p.gamma, p.beta, p.slope = ptr(gamma), ptr(beta), ptr(slope)
+    return p
+
+
+def conv1x1(x: torch.Tensor, t: int, wt: torch.Tensor, m: int, pro: Optional[Prologue] = None,
+            bias: Optional[torch.Tensor] = None, bias_n: Optional[torch.Tensor] = None,
+            res: Optional[torch.Tensor] = None, want_stats: bool = False,
+            out: Optional[torch.Tensor] = None) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """x padded [N,K,ldt], wt packed (pack_wt) -> y padded [N,M,ldt] (+ partial stats [N,parts,2] fp64)."""
+    require_device(x, "conv1x1")
+    n, k, ldt = x.shape
+    y = out if out is not None else torch.zeros(n, m, ldt, dtype=torch.float32, device=x.device)
+    stats = None
+    if want_stats:
+        parts = ((t + 127) // 128) * ((m + 255) // 256)
+        stats = torch.zeros(n, parts, 2, dtype=torch.float64, device=x.device)
+    check(lib().ps_conv1x1_f32(ptr(x), ptr(wt), ptr(y), n, k, m, t, ldt, C.byref(pro) if pro is not None else None,
+                               ptr(bias), ptr(bias_n), ptr(res), ptr(stats), stream_ptr(x.device)), "ps_conv1x1_f32")
+    return y, stats
+
+
+def dwconv(x: torch.Tensor, t: int, w: torch.Tensor, b: Optional[torch.Tensor], dilation: int, left: int,
+           pro: Optional[Prologue] = None, want_stats: bool = False) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """x padded [N,H,ldt], w [H,1,P] -> y padded [N,H,ldt] (+ partial stats)."""
+    require_device(x, "dwconv")
+    n, h, ldt = x.shape
+    p = w.shape[-1]
+    y = torch.zeros_like(x)
+    stats = None
+    if want_stats:
+        parts = ((t + 1023) // 1024) * ((h + 15) // 16)
+        stats = torch.zeros(n, parts, 2, dtype=torch.float64, device=x.device)
+    check(lib().ps_dwconv_f32(ptr(x), ptr(w), ptr(b), ptr(y), n, h, t, ldt, p, dilation, left,
+                              C.byref(pro) if pro is not None else None, ptr(stats), stream_ptr(x.device)),
+          "ps_dwconv_f32")
+    return y, stats
+
+
+def embed_bias(dvec: torch.Tensor, w_embed: torch.Tensor, normalize: bool) -> torch.Tensor:
+    require_device(dvec, "embed_bias")
+    n, e = dvec.shape
+    m = w_embed.shape[0]
+    out = torch.empty(n, m, dtype=torch.float32, device=dvec.device)
+    check(lib().ps_embed_bias_f32(ptr(dvec.contiguous()), ptr(w_embed), ptr(out), n, e, m, int(normalize),
+                                  stream_ptr(dvec.device)), "ps_embed_bias_f32")
+    return out
+
+
+def conv_tasnet(blocks: "C.Array[TcnBlock]", n_blocks: int, x_pad: torch.Tensor, t: int, c: int, h: int,
+                dvec: Optional[torch.Tensor], embed_norm: bool,
+                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Run the whole masker on padded input [N,C,ldt]; returns padded mask logits [N,C,ldt]."""
+    require_device(x_pad, "conv_tasnet")
+    n, _, ldt = x_pad.shape
+    need = lib().ps_conv_tasnet_workspace_bytes(n, c, h, t)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.zeros(need, dtype=torch.uint8, device=x_pad.device)
+    out = torch.zeros_like(x_pad)
+    check(lib().ps_conv_tasnet_f32(blocks, n_blocks, ptr(x_pad), ptr(out), ptr(dvec), int(embed_norm), n, t, ldt,
+                                   ptr(workspace), workspace.numel(), stream_ptr(x_pad.device)), "ps_conv_tasnet_f32")
+    return out

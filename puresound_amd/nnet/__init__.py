@@ -1,0 +1,12 @@
+"""Mirror of the inference side of `puresound.nnet` (see the module docstrings for file:line parity)."""
+from types import SimpleNamespace
+
+from .base_nn import SoTaskWrapModule
+from .conv_tasnet import TCN, ConvTasNet, GatedTCN
+from .lobe.encoder import ConvEncDec, FreeEncDec
+from .lobe.pooling import AttentiveStatisticsPooling
+
+# the class namespace the parity tests hand to tests/golden/cases.build()
+NS = SimpleNamespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
+                     ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
+                     AttentiveStatisticsPooling=AttentiveStatisticsPooling)

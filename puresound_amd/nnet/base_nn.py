@@ -1,0 +1,170 @@
+"""Task wrapper on the HIP path (mirror of the inference side of puresound/nnet/base_nn.py:11-777).
+
+`SoTaskWrapModule.inference` is the hot path: encoder -> [speaker_net] -> masker -> get_mask ->
+apply_tf_masks -> encoder.inverse -> output constraint.  Here the whole chain stays in the padded
+device layout: the encoder kernel writes [N,C,ldt], the masker updates it in place and the decoder
+kernel fuses mask activation, mask application, overlap-add and the clamp.  The training-loss
+forwards (`_forward*`, base_nn.py:426-672) are out of scope and raise.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import hip
+from .conv_tasnet import ConvTasNet
+from .lobe.encoder import ConvEncDec, FreeEncDec
+
+_MASK_ACTS = ("linear", "relu", "sigmoid")
+
+
+class BaseModel(nn.Module):
+    """base_nn.py:11-32."""
+
+    def __init__(self) -> None:
+        super().__init__()
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError
+
+    @property
+    def overall_parameters(self) -> int:
+        return sum(p.numel() for p in self.parameters())
+
+    @property
+    def overall_trainable_parameters(self) -> int:
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def get_state_dict(self):
+        return self.state_dict()
+
+
+class EncDecMaskerBaseModel(BaseModel):
+    """Argument checking of get_mask / apply_tf_masks with the reference's exception types
+    (base_nn.py:41-95); the arithmetic itself is fused into the decoder kernel."""
+
+    def check_mask_constraint(self, mask_constraint: str) -> str:
+        c = mask_constraint.lower()
+        if c not in _MASK_ACTS:
+            raise NotImplementedError  # base_nn.py:94-95
+        return c
+
+    def check_mask_pairing(self, mask_type: str, f_type: str) -> str:
+        mt, ft = mask_type.lower(), f_type.lower()
+        if (mt, ft) == ("real", "real"):
+            return "real"
+        if (mt, ft) == ("complex", "complex"):
+            return "complex"
+        if (mt, ft) == ("polar", "polar"):
+            return "polar"
+        if (mt, ft) == ("real", "complex"):
+            # the reference reads `mask` before assignment here (base_nn.py:127)
+            raise UnboundLocalError("local variable 'mask' referenced before assignment")
+        raise NameError  # base_nn.py:78-79
+
+
+class SoTaskWrapModule(EncDecMaskerBaseModel):
+    """Single-output task wrapper (speech enhancement / target speech extraction), base_nn.py:193-777."""
+
+    def __init__(self, encoder: nn.Module, masker: nn.Module, embedding_free_tse: bool = False,
+                 encoder_spk: Optional[nn.Module] = None, speaker_net: Optional[nn.Module] = None,
+                 loss_func_wav: Optional[nn.Module] = None, loss_func_spk: Optional[nn.Module] = None,
+                 loss_func_others: Optional[nn.Module] = None, f_type: str = "real", mask_type: str = "real",
+                 mask_constraint: str = "linear", output_constraint: str = "linear", drop_first_bin: bool = False,
+                 verbose: bool = True) -> None:
+        super().__init__()
+        self.f_type = f_type
+        self.mask_type = mask_type
+        self.encoder = encoder
+        self.masker = masker
+        self.embedding_free_tse = embedding_free_tse
+        self.encoder_spk = encoder_spk
+        self.speaker_net = speaker_net
+        self.loss_func_wav = loss_func_wav
+        self.loss_func_spk = loss_func_spk
+        self.loss_func_others = loss_func_others
+        self.mask_constraint = mask_constraint
+        self.output_constraint = output_constraint
+        self.drop_first_bin = drop_first_bin
+        self.task = self.check_task()
+        print(f"Current task label: {self.task}")
+        if verbose:
+            self._verbose()
+
+    def check_task(self):
+        """Task label, same decision table as base_nn.py:263-317."""
+        if self.speaker_net is None:
+            if not self.embedding_free_tse:
+                label = 0
+                print("Initialized a SE or BSS model, ignored the Encoder-spk." if self.encoder_spk is not None
+                      else "Initialized a SE or BSS model.")
+            else:
+                label = 4
+                print("Initialized a TSE model which dont need speaker net.")
+            return label
+        label = 1
+        print("Initialized a multi-task model, including two separate speech encoder." if self.encoder_spk is not None
+              else "Initialized a multi-task model, sharing a same speech encoder.")
+        if self.loss_func_spk is not None:
+            if self.loss_func_wav is None:
+                label = 2
+                print("Contrastive learning via speaker loss function.")
+            elif self.loss_func_others is None:
+                label = 1
+                print("Multi-task training has two loss function.")
+            else:
+                label = 3
+                print("Multi-task training has three loss function.")
+        elif self.loss_func_wav is None:
+            label = None
+            print("Inference mode.")
+        else:
+            label = 1
+            print("Multi-task training has only one loss function.")
+        return label
+
+    def forward(self, **kwargs):
+        raise NotImplementedError(
+            "SoTaskWrapModule.forward computes training losses (base_nn.py:426-688); puresound_amd covers the "
+            "inference path only -- use .inference()")
+
+    # -- the hot path -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def inference(self, noisy: torch.Tensor, enroll: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """noisy [N,L] (+ enroll [N,L']) -> enhanced waveform [N,L_out] (base_nn.py:690-722)."""
+        hip.require_device(noisy, "SoTaskWrapModule.inference")
+        mask_act = self.check_mask_constraint(self.mask_constraint)
+        pairing = self.check_mask_pairing(self.mask_type, self.f_type)
+        out_mode = self.output_constraint.lower()
+        if out_mode not in ("linear", "sigmoid"):
+            raise NameError("Non support type.")  # base_nn.py:421-422
+        if isinstance(self.encoder, ConvEncDec):
+            raise NotImplementedError("STFT encoder (ConvEncDec): HIP kernels are the next hot-path row")
+        if not isinstance(self.encoder, FreeEncDec) or pairing != "real":
+            raise NotImplementedError("HIP inference path: FreeEncDec encoder with (real, real) masks")
+        if not isinstance(self.masker, ConvTasNet):
+            raise NotImplementedError(f"HIP inference path: ConvTasNet masker (got {type(self.masker).__name__})")
+        if enroll is not None or self.speaker_net is not None or self.embedding_free_tse:
+            raise NotImplementedError("speaker branch (BASELINE config 3) is not on the HIP path yet")
+
+        feats, t = self.encoder.encode_padded(noisy)                 # _get_feature, base_nn.py:319-345
+        mask = self.masker.forward_padded(feats, t)                  # base_nn.py:709-714
+        # get_mask + apply_tf_masks + _get_waveform + _wav_output_constrain, base_nn.py:716-721
+        return self.encoder.decode_padded(feats, t, mask, mask_act, out_mode)
+
+    @torch.no_grad()
+    def inference_tse_embedding(self, enroll: Optional[torch.Tensor] = None) -> torch.Tensor:
+        raise NotImplementedError("speaker branch (BASELINE config 3) is not on the HIP path yet")
+
+    def _verbose(self):
+        """The reference probes look-ahead / receptive field with two 10-s CPU inferences and leaves the
+        module in train() mode (base_nn.py:740-777).  There is no CPU path here, so only the parameter
+        count is printed; the train() quirk is kept."""
+        print("---------------Verbose logging---------------")
+        self.eval()
+        print(f"Current training mode is: {self.training}")
+        print(f"Total params: {self.overall_parameters}")
+        print("Lookahead / receptive-field probe skipped: needs a ROCm device (no CPU fallback)")
+        self.train()
+        print(f"Current training mode is: {self.training}")
+        print("---------------Verbose logging---------------")

@@ -1,0 +1,257 @@
+"""Conv-TasNet masker on the HIP path (mirror of puresound/nnet/conv_tasnet.py:11-377).
+
+The modules keep the reference's parameter tree (so its checkpoints load with identical keys) but
+`forward` packs the weights once into the kernel-side layout ("plan") and enqueues the fused HIP
+kernels through the C ABI: per normal TCN block one exact-fp32 MFMA GEMM for in_conv, one depthwise
+streaming kernel, one GEMM for the pointwise conv and one GEMM for out_conv + residual, each applying
+the previous stage's gLN/gGN/bN1d + PReLU while it loads its input and emitting the partial
+statistics the next global norm needs.
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import hip
+from .._abi import TcnBlock, ptr
+from .lobe.cnn import DepthwiseSeparableConv1d
+from .lobe.norm import get_norm, norm_plan
+
+
+_PLAN_SERIAL = [0]
+
+
+class _PlanCache:
+    """Packed-weight caches hold raw device pointers (ctypes) -- never pickle / deepcopy them."""
+
+    _CACHE_ATTRS = ("_plan", "_plan_sig", "_blocks", "_blocks_sig", "_workspace")
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in self._CACHE_ATTRS:
+            if k in state:
+                state[k] = None
+        return state
+
+
+def _param_signature(module: nn.Module):
+    """Cheap fingerprint of every parameter/buffer: a changed value (in-place edit, load_state_dict,
+    .to(device)) changes the version counter or the data pointer, which invalidates the packed plan."""
+    sig = []
+    for t in list(module.parameters()) + list(module.buffers()):
+        sig.append((t.data_ptr(), t._version))
+    sig.append(module.training)
+    return tuple(sig)
+
+
+class TCN(_PlanCache, nn.Module):
+    """Input 1x1 conv -> norm -> PReLU -> depthwise-separable conv -> output 1x1 conv -> + residual
+    (conv_tasnet.py:11-90)."""
+
+    def __init__(self, in_channels: int, hid_channels: int, kernel: int, dilation: int, dropout: float = 0.0,
+                 emb_dim: int = 0, causal: bool = False, tcn_norm: str = "gLN", dconv_norm: str = "gGN") -> None:
+        super().__init__()
+        self.in_channels, self.hid_channels = in_channels, hid_channels
+        self.kernel, self.dilation, self.emb_dim, self.causal = kernel, dilation, emb_dim, causal
+        norm = get_norm(tcn_norm)
+        self.in_conv = nn.Sequential(
+            nn.Conv1d(in_channels + emb_dim, hid_channels, kernel_size=1, bias=False, groups=1),
+            norm(hid_channels), nn.PReLU())
+        self.dconv = nn.Sequential(
+            DepthwiseSeparableConv1d(in_channels=hid_channels, out_channels=hid_channels, hid_channels=None,
+                                     kernel=kernel, dilation=dilation, skip=False, causal=causal,
+                                     norm_cls=dconv_norm),
+            nn.Dropout(p=dropout))
+        self.out_conv = nn.Conv1d(hid_channels, in_channels, kernel_size=1, stride=1)
+        self._plan = None
+        self._plan_sig = None
+
+    # -- kernel-side weight layout ----------------------------------------------------------------
+    def plan(self, device: torch.device) -> dict:
+        sig = (_param_signature(self), str(device))
+        if self._plan is not None and self._plan_sig == sig:
+            return self._plan
+        if self.training and self.dconv[1].p > 0:
+            raise RuntimeError("TCN: dropout is active; the HIP path is inference only -- call .eval()")
+        if not self.causal and self.kernel % 2 == 0:
+            raise RuntimeError("TCN: an even kernel with symmetric padding changes the length (the reference "
+                               "fails at the residual add)")
+        c, h = self.in_channels, self.hid_channels
+        dsc = self.dconv[0]
+        f32 = dict(dtype=torch.float32, device=device)
+        w_in = self.in_conv[0].weight.detach().to(**f32)
+        t = {}
+        t["in_wt"] = hip.pack_wt(w_in[:, :c, 0])
+        t["in_embed_w"] = w_in[:, c:, 0].contiguous() if self.emb_dim > 0 else None
+        kinds = {}
+        for name, mod in (("in", self.in_conv[1]), ("dw", dsc.depthwise[1]), ("pw", dsc.pointwise[1])):
+            kinds[name], g, b = norm_plan(mod)
+            t[name + "_gamma"], t[name + "_beta"] = g.to(**f32).contiguous(), b.to(**f32).contiguous()
+        t["in_slope"] = self.in_conv[2].weight.detach().to(**f32).contiguous()
+        t["dw_slope"] = dsc.depthwise[2].weight.detach().to(**f32).contiguous()
+        t["pw_slope"] = dsc.pointwise[2].weight.detach().to(**f32).contiguous()
+        for k, mod in (("in_slope", self.in_conv[2]), ("dw_slope", dsc.depthwise[2]), ("pw_slope", dsc.pointwise[2])):
+            if mod.weight.numel() != 1:
+                raise NotImplementedError("PReLU with per-channel slopes is not on the HIP path")
+        t["dw_w"] = dsc.depthwise[0].weight.detach().to(**f32).contiguous()
+        t["dw_b"] = dsc.depthwise[0].bias.detach().to(**f32).contiguous()
+        t["pw_wt"] = hip.pack_wt(dsc.pointwise[0].weight.detach().to(**f32))
+        t["pw_b"] = dsc.pointwise[0].bias.detach().to(**f32).contiguous()
+        t["out_wt"] = hip.pack_wt(self.out_conv.weight.detach().to(**f32))
+        t["out_b"] = self.out_conv.bias.detach().to(**f32).contiguous()
+        b = TcnBlock()
+        b.C, b.H, b.P, b.dilation, b.causal = c, h, self.kernel, self.dilation, int(self.causal)
+        b.in_norm, b.dw_norm, b.pw_norm = kinds["in"], kinds["dw"], kinds["pw"]
+        b.E = self.emb_dim
+        for k, v in t.items():
+            setattr(b, k, ptr(v))
+        _PLAN_SERIAL[0] += 1
+        # tensors kept alive alongside the raw pointers
+        self._plan = {"block": b, "tensors": t, "serial": _PLAN_SERIAL[0]}
+        self._plan_sig = sig
+        return self._plan
+
+    def forward(self, x: torch.Tensor, embed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [N,C,T], embed [N,E] -> [N,C,T] (conv_tasnet.py:67-90)."""
+        hip.require_device(x, "TCN.forward")
+        if (embed is not None) != (self.emb_dim > 0):
+            raise RuntimeError(f"TCN.forward: block built with emb_dim={self.emb_dim} but embed is "
+                               f"{'given' if embed is not None else 'missing'} (the reference fails in in_conv)")
+        p = self.plan(x.device)
+        blocks = (TcnBlock * 1)(p["block"])
+        t = x.shape[-1]
+        out = hip.conv_tasnet(blocks, 1, hip.pad_rows(x), t, self.in_channels, self.hid_channels,
+                              None if embed is None else embed.contiguous(), False)
+        return hip.unpad_rows(out, t)
+
+
+class GatedTCN(nn.Module):
+    """Gated TCN block (conv_tasnet.py:93-215).  Parameter tree only: its dense 3-tap convolutions are a
+    later row of the hot-path table (used by the UnetTcn presets, not by the Conv-TasNet configs)."""
+
+    def __init__(self, in_channels: int, hid_channels: int, kernel: int, dilation: int, dropout: float = 0.0,
+                 emb_dim: int = 0, causal: bool = False, tcn_norm: str = "gLN", use_film: bool = False):
+        super().__init__()
+        self.causal = causal
+        self.padd = (kernel - 1) * dilation // 2 if not causal else (kernel - 1) * dilation
+        self.tcn_norm = tcn_norm
+        norm_cls = get_norm(tcn_norm)
+        self.use_film = use_film
+        self.in_conv = nn.Conv1d(in_channels, hid_channels, kernel_size=1, bias=False, groups=1)
+        self.left_conv = nn.Sequential(
+            nn.Conv1d(hid_channels, hid_channels, kernel_size=kernel, dilation=dilation, bias=False,
+                      padding=self.padd, groups=1),
+            norm_cls(hid_channels), nn.PReLU(), nn.Dropout(p=dropout))
+        if not self.use_film:
+            right_in_dim = hid_channels + emb_dim
+        else:
+            self.cond_scale = nn.Conv1d(emb_dim, hid_channels, kernel_size=1, bias=False)
+            self.cond_bias = nn.Conv1d(emb_dim, hid_channels, kernel_size=1, bias=False)
+            right_in_dim = hid_channels
+        self.right_conv = nn.Sequential(
+            nn.Conv1d(right_in_dim, hid_channels, kernel_size=kernel, dilation=dilation, bias=False,
+                      padding=self.padd, groups=1),
+            norm_cls(hid_channels), nn.PReLU(), nn.Dropout(p=dropout), nn.Sigmoid())
+        self.out_conv = nn.Conv1d(hid_channels, in_channels, kernel_size=1, bias=False, groups=1)
+
+    def forward(self, x: torch.Tensor, embed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        raise NotImplementedError("GatedTCN has no HIP kernel yet (dense dilated 3-tap convs; UnetTcn presets)")
+
+
+class ConvTasNet(_PlanCache, nn.Module):
+    """R repeats of X dilated TCN blocks with optional speaker-embedding injection
+    (conv_tasnet.py:218-377).  Encoder/decoder live outside, as in the reference."""
+
+    def __init__(self, input_dim: int = 512, embed_dim: int = 256, embed_norm: bool = False,
+                 tcn_layer: str = "normal", tcn_kernel: int = 3, tcn_dim: int = 256, tcn_dilated_basic: int = 2,
+                 per_tcn_stack: int = 5, repeat_tcn: int = 4, tcn_with_embed: List = [1, 0, 0, 0, 0],
+                 tcn_norm: str = "gLN", dconv_norm: str = "gGN", causal: bool = False):
+        super().__init__()
+        self.input_dim = input_dim
+        self.embed_dim = embed_dim
+        self.embed_norm = embed_norm
+        self.tcn_layer = tcn_layer
+        self.tcn_dim = tcn_dim
+        self.tcn_kernel = tcn_kernel
+        self.per_tcn_stack = per_tcn_stack
+        self.repeat_tcn = repeat_tcn
+        self.tcn_dilated_basic = tcn_dilated_basic
+        self.tcn_with_embed = tcn_with_embed
+        self.tcn_norm = tcn_norm
+        self.dconv_norm = dconv_norm
+        self.causal = causal
+
+        if self.tcn_layer.lower() == "normal":
+            tcn_cls = TCN
+        elif self.tcn_layer.lower() == "gated":
+            tcn_cls = GatedTCN
+        else:
+            raise NameError
+        assert per_tcn_stack == len(tcn_with_embed)
+        self.tcn_list = nn.ModuleList()
+        for _ in range(repeat_tcn):
+            stack = []
+            for i in range(per_tcn_stack):
+                kw = dict(kernel=tcn_kernel, dilation=tcn_dilated_basic ** i,
+                          emb_dim=embed_dim if tcn_with_embed[i] else 0, causal=causal, tcn_norm=tcn_norm)
+                if tcn_cls is TCN:
+                    kw["dconv_norm"] = dconv_norm
+                stack.append(tcn_cls(input_dim, tcn_dim, **kw))
+            self.tcn_list.append(nn.ModuleList(stack))
+        self._blocks = None
+        self._blocks_sig = None
+        self._workspace = None
+
+    # -- plan: one ps_tcn_block per TCN, in execution order -------------------------------------------
+    def block_array(self, device: torch.device):
+        if self.tcn_layer.lower() != "normal":
+            raise NotImplementedError("tcn_layer='gated' has no HIP kernel yet")
+        mods = [m for stack in self.tcn_list for m in stack]
+        plans = [m.plan(device) for m in mods]  # each TCN re-validates its own fingerprint
+        sig = tuple(p["serial"] for p in plans)
+        if self._blocks is None or self._blocks_sig != sig:
+            self._blocks = (TcnBlock * len(plans))(*[p["block"] for p in plans])
+            self._blocks_sig = sig
+        return self._blocks, len(plans)
+
+    def forward_padded(self, x_pad: torch.Tensor, t: int, dvec: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Padded-layout entry used by the fused wrapper: [N,C,ldt] -> mask logits [N,C,ldt]."""
+        blocks, n_blocks = self.block_array(x_pad.device)
+        need_embed = any(self.tcn_with_embed)
+        if need_embed and dvec is None:
+            # the reference would call TCN(x, None) on a block whose in_conv expects C+E channels and fail there
+            raise RuntimeError("ConvTasNet.forward: tcn_with_embed is set but no dvec was given")
+        if not need_embed:
+            dvec = None  # reference ignores dvec when no block takes it (conv_tasnet.py:354-357)
+        n = x_pad.shape[0]
+        need = hip.lib().ps_conv_tasnet_workspace_bytes(n, self.input_dim, self.tcn_dim, t)
+        ws = self._workspace
+        if ws is None or ws.numel() < need or ws.device != x_pad.device:
+            ws = self._workspace = torch.zeros(need, dtype=torch.uint8, device=x_pad.device)
+        return hip.conv_tasnet(blocks, n_blocks, x_pad, t, self.input_dim, self.tcn_dim,
+                               None if dvec is None else dvec.contiguous().float(),
+                               bool(self.embed_norm), ws)
+
+    def forward(self, x: torch.Tensor, dvec: Optional[torch.Tensor] = None):
+        """x [N,C,T], dvec [N,E] -> mask logits [N,C,T] (conv_tasnet.py:338-359)."""
+        hip.require_device(x, "ConvTasNet.forward")
+        t = x.shape[-1]
+        return hip.unpad_rows(self.forward_padded(hip.pad_rows(x), t, dvec), t)
+
+    @property
+    def get_args(self) -> Dict:
+        return {
+            "input_dim": self.input_dim,
+            "embed_dim": self.embed_dim,
+            "embed_norm": self.embed_norm,
+            "tcn_norm": self.tcn_norm,
+            "dconv_norm": self.dconv_norm,
+            "tcn_layer": self.tcn_layer,
+            "tcn_dim": self.tcn_dim,
+            "tcn_kernel": self.tcn_kernel,
+            "tcn_dilated_basic": self.tcn_dilated_basic,
+            "repeat_tcn": self.repeat_tcn,
+            "per_tcn_stack": self.per_tcn_stack,
+            "tcn_with_embed": self.tcn_with_embed,
+            "causal": self.causal,
+        }
