@@ -49,6 +49,14 @@ extern "C" {
 int ps_abi_version(void);
 const char* ps_last_error(void);
 
+/* Optional launch timing (bench.py's roofline leg): while enabled every kernel launch made by this
+ * library is bracketed by hipEvents on the launch stream.  ps_profile_enable(1) clears old records.
+ * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
+ * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
+ * "unpad_rows").  Not for use under stream capture. */
+int ps_profile_enable(int on);
+int ps_profile_read(const char* kernel, double* total_ms, int* launches);
+
 /* Number of doubles a stats buffer needs: partial (sum, sum-of-squares) slabs per utterance.
  * Stats are handed from the producing kernel to the consuming kernel as per-workgroup partials
  * (deterministic; no atomics).  ps_stats_parts() is an upper bound for any kernel here. */

@@ -42,6 +42,8 @@ class TcnBlock(C.Structure):
 SIGNATURES = {
     "ps_abi_version": (C.c_int, []),
     "ps_last_error": (C.c_char_p, []),
+    "ps_profile_enable": (C.c_int, [C.c_int]),
+    "ps_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "ps_stats_parts": (C.c_int, [C.c_int, C.c_int]),
     "ps_padded_frames": (C.c_int, [C.c_int]),
     "ps_pad_rows_f32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),

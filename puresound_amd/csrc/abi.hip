@@ -2,6 +2,10 @@
 // (conv_tasnet.py:67-90 of mcw519/PureSound) and the whole Conv-TasNet masker (conv_tasnet.py:338-359).
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
 
 #include "ps_common.h"
 
@@ -16,6 +20,30 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+struct ProfRecord {
+  const char* kernel;
+  hipEvent_t start, stop;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRecord> g_prof;
+
+LaunchTimer::LaunchTimer(const char* kernel, hipStream_t stream) : slot_(-1), stream_(stream) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRecord r{kernel, nullptr, nullptr};
+  if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+  (void)hipEventRecord(r.start, stream);
+  g_prof.push_back(r);
+  slot_ = (int)g_prof.size() - 1;
+}
+
+LaunchTimer::~LaunchTimer() {
+  if (slot_ < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  (void)hipEventRecord(g_prof[slot_].stop, stream_);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -25,6 +53,44 @@ using namespace ps;
 
 extern "C" int ps_abi_version(void) { return PS_ABI_VERSION; }
 extern "C" const char* ps_last_error(void) { return g_err; }
+
+extern "C" int ps_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (on) {
+    for (auto& r : g_prof) {
+      (void)hipEventDestroy(r.start);
+      (void)hipEventDestroy(r.stop);
+    }
+    g_prof.clear();
+  }
+  g_prof_on = on != 0;
+  return 0;
+}
+
+extern "C" int ps_profile_read(const char* kernel, double* total_ms, int* launches) {
+  if (!kernel || !total_ms || !launches) {
+    set_error("ps_profile_read: null argument");
+    return PS_E_INVALID;
+  }
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double tot = 0.0;
+  int cnt = 0;
+  for (auto& r : g_prof) {
+    if (strcmp(r.kernel, kernel) != 0) continue;
+    hipError_t e = hipEventSynchronize(r.stop);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.start, r.stop);
+    if (e != hipSuccess) {
+      set_error("ps_profile_read: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    tot += ms;
+    ++cnt;
+  }
+  *total_ms = tot;
+  *launches = cnt;
+  return 0;
+}
 
 extern "C" int ps_padded_frames(int frames) { return frames <= 0 ? 0 : ceil_div(frames, kTileT) * kTileT; }
 

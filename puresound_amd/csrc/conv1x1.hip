@@ -236,7 +236,10 @@ extern "C" int ps_conv1x1_f32(const float* x, const float* wt, float* y, int N, 
   a.ldt = ldt;
   a.Mp = (M + BM - 1) / BM * BM;
   dim3 grid((T + BT - 1) / BT, (M + BM - 1) / BM, N);
-  hipLaunchKernelGGL(conv1x1_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  {
+    LaunchTimer timer("conv1x1", (hipStream_t)stream);
+    hipLaunchKernelGGL(conv1x1_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("ps_conv1x1_f32: launch failed: %s", hipGetErrorString(e));

@@ -131,7 +131,10 @@ extern "C" int ps_dwconv_f32(const float* x, const float* w, const float* b, flo
   a.dilation = dilation;
   a.left = left;
   dim3 grid((T + DW_FRAMES - 1) / DW_FRAMES, (H + DW_ROWS - 1) / DW_ROWS, N);
-  hipLaunchKernelGGL(dwconv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  {
+    LaunchTimer timer("dwconv", (hipStream_t)stream);
+    hipLaunchKernelGGL(dwconv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("ps_dwconv_f32: launch failed: %s", hipGetErrorString(e));

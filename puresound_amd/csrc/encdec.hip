@@ -209,6 +209,7 @@ extern "C" int ps_pad_rows_f32(const float* src, float* dst, int64_t rows, int T
   }
   // grid.y is limited to 65535: fold rows
   const int64_t chunk = 65535;
+  LaunchTimer timer("pad_rows", (hipStream_t)stream);
   for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
     const int64_t nr = rows - r0 < chunk ? rows - r0 : chunk;
     hipLaunchKernelGGL(pad_rows_kernel, dim3((ldt + 255) / 256, (unsigned)nr), dim3(256), 0, (hipStream_t)stream,
@@ -223,6 +224,7 @@ extern "C" int ps_unpad_rows_f32(const float* src, float* dst, int64_t rows, int
     return PS_E_INVALID;
   }
   const int64_t chunk = 65535;
+  LaunchTimer timer("unpad_rows", (hipStream_t)stream);
   for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
     const int64_t nr = rows - r0 < chunk ? rows - r0 : chunk;
     hipLaunchKernelGGL(unpad_rows_kernel, dim3((T + 255) / 256, (unsigned)nr), dim3(256), 0, (hipStream_t)stream,
@@ -244,6 +246,7 @@ extern "C" int ps_free_encode_f32(const float* wav, const float* w, float* feats
   }
   dim3 grid((T + 255) / 256, (C + ENC_CCHUNK - 1) / ENC_CCHUNK, N);
   hipStream_t s = (hipStream_t)stream;
+  LaunchTimer timer("free_encode", s);
   if (win == 32)
     hipLaunchKernelGGL(free_encode_kernel<32>, grid, dim3(256), 0, s, wav, w, feats, L, C, win, hop, T, ldt, relu);
   else if (win == 16)
@@ -264,6 +267,7 @@ extern "C" int ps_free_decode_f32(const float* feats, const float* mask, int mas
     return PS_E_INVALID;
   }
   hipStream_t s = (hipStream_t)stream;
+  LaunchTimer timer("free_decode", s);
   if (win == 32 && hop == 16) {
     constexpr int BTF = 255;
     hipLaunchKernelGGL((free_decode_kernel<32, 16>), dim3((T + BTF - 1) / BTF, N), dim3(256), 0, s, feats, mask,
@@ -286,6 +290,7 @@ extern "C" int ps_embed_bias_f32(const float* dvec, const float* w_embed, float*
     set_error("ps_embed_bias_f32: bad argument");
     return PS_E_INVALID;
   }
+  LaunchTimer timer("embed_bias", (hipStream_t)stream);
   hipLaunchKernelGGL(embed_bias_kernel, dim3((M + 3) / 4, N), dim3(256), 0, (hipStream_t)stream, dvec, w_embed,
                      bias_n, E, M, normalize);
   return check_launch("ps_embed_bias_f32");

@@ -15,6 +15,14 @@ constexpr int kTileT = 128;  // padded-row granule: ldt % kTileT == 0
 
 void set_error(const char* fmt, ...);
 
+// Brackets one kernel launch with hipEvents when ps_profile_enable(1) is active (no-op otherwise).
+struct LaunchTimer {
+  LaunchTimer(const char* kernel, hipStream_t stream);
+  ~LaunchTimer();
+  int slot_;
+  hipStream_t stream_;
+};
+
 // Per-utterance scalars of a global norm, derived from the producer's partial sums.
 struct NormScalars {
   float mean;

@@ -1,0 +1,263 @@
+"""GPU parity tests: every call goes through the C ABI (libpuresound_hip.so) and is compared with the
+CPU oracle on the same seeded inputs and with the committed golden vectors of the imported reference.
+
+Tolerance (north star): max|a-b| / max|b| <= 1e-4 in fp32.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import rel_max
+from detweights import det_state_dict, det_wave
+from oracle import separator_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def H():
+    from puresound_amd import hip
+    hip.lib()  # fail loudly if the extension is missing
+    return hip
+
+
+@pytest.fixture(scope="module")
+def PA():
+    import puresound_amd.nnet as PA
+    return PA
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + ".npz")))
+
+
+def _rand(shape, seed, lo=-1.0, hi=1.0):
+    g = np.random.Generator(np.random.Philox(key=seed))
+    return torch.tensor(g.uniform(lo, hi, shape), dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# single kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,length,c,win,hop,relu", [
+    (2, 1000, 40, 32, 16, False), (3, 4111, 70, 32, 16, True), (2, 600, 24, 16, 8, False),
+    (2, 211, 9, 20, 6, True), (1, 32, 5, 32, 16, False), (1, 64000, 512, 32, 16, False)])
+def test_free_encode(H, dev, n, length, c, win, hop, relu):
+    wav = _rand((n, length), 1, -0.5, 0.5)
+    w = _rand((c, 1, win), 2, -0.2, 0.2)
+    ref = O.free_encode(wav, w, hop, relu)
+    feats, t = H.free_encode(wav.to(dev), w.to(dev), hop, relu)
+    assert t == ref.shape[-1] == (length - win) // hop + 1
+    assert rel_max(feats[..., :t].cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("n,c,t,win,hop,mask_act,out_mode", [
+    (2, 40, 61, 32, 16, "relu", "linear"), (2, 70, 700, 32, 16, "linear", "none"),
+    (3, 24, 300, 16, 8, "sigmoid", "sigmoid"), (2, 9, 33, 20, 6, "relu", "linear"),
+    (1, 8, 1, 32, 16, "linear", "none"), (1, 16, 255, 32, 16, "linear", "none"),
+    (1, 16, 256, 32, 16, "linear", "none"), (1, 512, 3999, 32, 16, "relu", "linear")])
+def test_free_decode(H, dev, n, c, t, win, hop, mask_act, out_mode):
+    feats = _rand((n, c, t), 3)
+    mask = _rand((n, c, t), 4)
+    w = _rand((c, 1, win), 5, -0.3, 0.3)
+    enh = feats * O.get_mask(mask, mask_act)
+    ref = O.free_decode(enh, w, hop)
+    if out_mode != "none":
+        ref = O.output_constrain(ref, out_mode)
+    out = H.free_decode(H.pad_rows(feats.to(dev)), t, w.to(dev), hop, H.pad_rows(mask.to(dev)), mask_act, out_mode)
+    assert out.shape == ref.shape
+    assert rel_max(out.cpu().numpy(), ref.numpy()) < 2e-5
+    # no-mask variant == module-level FreeEncDec.inverse
+    out2 = H.free_decode(H.pad_rows(feats.to(dev)), t, w.to(dev), hop)
+    assert rel_max(out2.cpu().numpy(), O.free_decode(feats, w, hop).numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("n,k,m,t", [(2, 16, 8, 50), (1, 512, 256, 300), (2, 256, 512, 129), (2, 20, 300, 128),
+                                     (1, 33, 70, 1), (3, 256, 256, 1000)])
+def test_conv1x1_plain_and_stats(H, dev, n, k, m, t):
+    x = _rand((n, k, t), 6)
+    w = _rand((m, k), 7, -0.2, 0.2)
+    b = _rand((m,), 8)
+    bn = _rand((n, m), 9)
+    res = _rand((n, m, t), 10)
+    ref = torch.matmul(w, x) + b.reshape(1, -1, 1) + bn.reshape(n, m, 1)
+    y, st = H.conv1x1(H.pad_rows(x.to(dev)), t, H.pack_wt(w.to(dev)), m, None, b.to(dev), bn.to(dev),
+                      H.pad_rows(res.to(dev)), want_stats=True)
+    assert rel_max(y[..., :t].cpu().numpy(), (ref + res).numpy()) < 1e-5
+    s = st.sum(1).cpu().numpy()
+    ref64 = ref.double()
+    np.testing.assert_allclose(s[:, 0], ref64.sum((1, 2)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1], (ref64 ** 2).sum((1, 2)).numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("norm", ["global", "affine", "none"])
+@pytest.mark.parametrize("n,k,m,t", [(2, 24, 12, 77), (2, 256, 256, 500)])
+def test_conv1x1_prologue(H, dev, norm, n, k, m, t):
+    from puresound_amd import _abi
+    x = _rand((n, k, t), 11) + 0.3
+    w = _rand((m, k), 12, -0.2, 0.2)
+    gamma, beta, slope = _rand((k,), 13, 0.5, 1.5), _rand((k,), 14, -0.2, 0.2), torch.tensor([0.2])
+    if norm == "global":
+        a = O.glob_ln(x, gamma, beta)
+    elif norm == "affine":
+        a = gamma.reshape(1, -1, 1) * x + beta.reshape(1, -1, 1)
+    else:
+        a = x
+    a = O.prelu(a, slope)
+    ref = torch.matmul(w, a)
+    xd = H.pad_rows(x.to(dev))
+    stats = None
+    if norm == "global":
+        # producer statistics: one part per utterance, exact fp64 sums
+        stats = torch.stack([x.double().sum((1, 2)), (x.double() ** 2).sum((1, 2))], -1).reshape(n, 1, 2).to(dev)
+    kind = {"global": _abi.PS_NORM_GLOBAL, "affine": _abi.PS_NORM_AFFINE, "none": _abi.PS_NORM_NONE}[norm]
+    # device copies stay referenced: the prologue carries raw pointers
+    g_d, b_d, s_d = gamma.to(dev), beta.to(dev), slope.to(dev)
+    pro = H.make_prologue(kind, True, stats, k * t, 1e-8, g_d, b_d, s_d)
+    y, _ = H.conv1x1(xd, t, H.pack_wt(w.to(dev)), m, pro)
+    torch.cuda.synchronize()
+    assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("p,dil,causal", [(3, 1, False), (3, 2, False), (3, 4, False), (3, 8, False), (3, 128, False),
+                                          (3, 3, False), (5, 9, False), (3, 1, True), (3, 2, True), (3, 16, True)])
+@pytest.mark.parametrize("n,h,t", [(2, 12, 77), (1, 40, 1500)])
+def test_dwconv(H, dev, p, dil, causal, n, h, t):
+    from puresound_amd import _abi
+    x = _rand((n, h, t), 15) + 0.1
+    w = _rand((h, 1, p), 16)
+    b = _rand((h,), 17)
+    gamma, beta, slope = _rand((h,), 18, 0.5, 1.5), _rand((h,), 19, -0.2, 0.2), torch.tensor([0.3])
+    a = O.prelu(O.glob_ln(x, gamma, beta), slope)
+    left = (p - 1) * dil if causal else ((p - 1) // 2) * dil
+    ref = O.dilated_conv(a, w, b, dil, left)
+    ref = ref[..., :t] if causal else ref
+    stats = torch.stack([x.double().sum((1, 2)), (x.double() ** 2).sum((1, 2))], -1).reshape(n, 1, 2).to(dev)
+    g_d, b_d, s_d = gamma.to(dev), beta.to(dev), slope.to(dev)
+    pro = H.make_prologue(_abi.PS_NORM_GLOBAL, True, stats, h * t, 1e-8, g_d, b_d, s_d)
+    y, st = H.dwconv(H.pad_rows(x.to(dev)), t, w.to(dev), b.to(dev), dil, left, pro, want_stats=True)
+    assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 1e-5
+    s = st.sum(1).cpu().numpy()
+    np.testing.assert_allclose(s[:, 0], ref.double().sum((1, 2)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1], (ref.double() ** 2).sum((1, 2)).numpy(), rtol=1e-5)
+
+
+def test_embed_bias(H, dev):
+    dvec, w = _rand((3, 19), 20), _rand((11, 19), 21)
+    for normalize in (False, True):
+        d = dvec / dvec.norm(dim=1, keepdim=True) if normalize else dvec
+        out = H.embed_bias(dvec.to(dev), w.to(dev), normalize)
+        assert rel_max(out.cpu().numpy(), (d @ w.t()).numpy()) < 1e-5
+
+
+def test_pad_unpad_roundtrip(H, dev):
+    x = _rand((3, 7, 131), 22).to(dev)
+    p = H.pad_rows(x)
+    assert p.shape[-1] == 256 and torch.equal(p[..., :131], x) and float(p[..., 131:].abs().max()) == 0.0
+    assert torch.equal(H.unpad_rows(p, 131), x)
+
+
+def test_abi_rejects_bad_arguments(H, dev):
+    x = torch.zeros(1, 16, 100, device=dev)  # ldt = 100 is not a multiple of 128
+    with pytest.raises(RuntimeError, match="ldt"):
+        H.conv1x1(x, 100, H.pack_wt(torch.zeros(8, 16, device=dev)), 8)
+    with pytest.raises(RuntimeError, match="ROCm device only"):
+        H.pad_rows(torch.zeros(2, 3, 5))
+
+
+# ------------------------------------------------------------------------------------------------
+# masker and wrapper against the reference's golden vectors
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["ctn_embed", "ctn_dil3_k5"])
+def test_masker_matches_reference_golden(PA, dev, golden_dir, name):
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    dvec = torch.tensor(g["dvec"]).to(dev) if "dvec" in g else None
+    y = model(torch.tensor(g["x"]).to(dev), dvec)
+    assert y.shape == g["y"].shape
+    assert rel_max(y.cpu().numpy(), g["y"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["tiny_free", "tiny_free_relu_causal", "cfg2_short", "cfg2_full"])
+def test_wrapper_inference_matches_reference_golden(PA, dev, golden_dir, name):
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name).eval()
+    sd = det_state_dict(model)
+    model.load_state_dict(sd)
+    model.to(dev)
+    noisy = det_wave(c["seed"], c["B"], c["L"])
+    wav = model.inference(noisy.to(dev))
+    assert wav.shape == g["wav"].shape
+    assert rel_max(wav.cpu().numpy(), g["wav"]) < TOL
+    # and against the oracle on the same inputs (pre-clamp, so the clamp cannot hide an error)
+    taps = {}
+    O.inference(noisy, sd, cases.oracle_cfg(name), None, taps)
+    feats, t = model.encoder.encode_padded(noisy.to(dev))
+    mask = model.masker.forward_padded(feats, t)
+    assert rel_max(feats[..., :t].cpu().numpy(), taps["feats"].numpy()) < 1e-5
+    mact = model.mask_constraint.lower()
+    assert rel_max(O.get_mask(mask[..., :t].cpu(), mact).numpy(), taps["mask"].numpy()) < TOL
+    pre = model.encoder.decode_padded(feats, t, mask, mact, "none")
+    assert rel_max(pre.cpu().numpy(), g["wav_preclamp"]) < TOL
+
+
+def test_input_is_not_modified_and_result_is_deterministic(PA, dev):
+    model = cases.build(PA.NS, "tiny_free").eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    noisy = det_wave(3, 4, 2000).to(dev)
+    keep = noisy.clone()
+    a = model.inference(noisy)
+    b = model.inference(noisy)
+    assert torch.equal(noisy, keep)
+    assert torch.equal(a, b)  # slab-reduced statistics: bitwise reproducible
+
+
+def test_plan_follows_weight_updates(PA, dev):
+    model = cases.build(PA.NS, "tiny_free").eval().to(dev)
+    noisy = det_wave(3, 2, 1500).to(dev)
+    a = model.inference(noisy)
+    sd = det_state_dict(model)
+    model.load_state_dict(sd)
+    b = model.inference(noisy)
+    assert not torch.equal(a, b)
+    ref = O.inference(noisy.cpu(), sd, cases.oracle_cfg("tiny_free"))
+    assert rel_max(b.cpu().numpy(), ref.numpy()) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE size (32 x 4 s): size-independent properties
+# ------------------------------------------------------------------------------------------------
+def test_full_batch_properties(PA, dev, golden_dir):
+    """At B=32 x 64000 the oracle is too slow to run per test; use properties instead:
+    (1) utterances are independent: row i of the batched run equals the B=1 run of that utterance bit for bit;
+    (2) row 0 is the reference's golden utterance (cfg2_full);  (3) length law 64000 -> 64000; (4) |y| <= 1."""
+    name = "cfg2_full"
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    first = det_wave(cases.CASES[name]["seed"], 1, 64000)
+    rest = det_wave(99, 31, 64000)
+    batch = torch.cat([first, rest]).to(dev)
+    out = model.inference(batch)
+    assert out.shape == (32, 64000)
+    assert float(out.abs().max()) <= 1.0
+    assert rel_max(out[0:1].cpu().numpy(), g["wav"]) < TOL
+    for i in (0, 7, 31):
+        single = model.inference(batch[i:i + 1])
+        assert torch.equal(single[0], out[i])
+    assert torch.isfinite(out).all()
