@@ -146,31 +146,49 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
   }
 
   // ---- epilogue: bias, residual, store, partial statistics -------------------------------------
+  // Pad columns (t >= T, always inside the padded row) are stored too: nothing reads them as data, and
+  // keeping the stores unconditional lets the compiler batch the residual loads instead of serialising
+  // 128 load->add->store round trips behind per-element branches.  Statistics mask them out.
   double ssum = 0.0, ssq = 0.0;
   if (wave_active) {
-    float* yg = a.y + (size_t)n * a.M * a.ldt;
-    const float* rg = a.res ? a.res + (size_t)n * a.M * a.ldt : nullptr;
+    float* yg = a.y + (size_t)n * a.M * a.ldt + t0 + lr;
+    const float* rg = a.res ? a.res + (size_t)n * a.M * a.ldt + t0 + lr : nullptr;
     const float* bn = a.bias_n ? a.bias_n + (size_t)n * a.M : nullptr;
+    const int row_base = m0 + wave * 64 + 4 * lk;
+    const bool full_rows = (m0 + wave * 64 + 64) <= a.M;  // wave-uniform
+    float cmask[4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) cmask[ti] = (t0 + ti * 32 + lr) < a.T ? 1.f : 0.f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       float fsum = 0.f, fsq = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wave * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row < a.M) {
-          float bsum = a.bias ? a.bias[row] : 0.f;
-          if (bn) bsum += bn[row];
+      for (int rq = 0; rq < 4; ++rq) {
+        float rv[4][4];
+        float bs[4];
+        int rows[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = row_base + mi * 32 + rr + 8 * rq;
+          rows[rr] = full_rows ? row : (row < a.M ? row : a.M - 1);  // clamp: loads stay in bounds
+          bs[rr] = (a.bias ? a.bias[rows[rr]] : 0.f) + (bn ? bn[rows[rr]] : 0.f);
+          if (rg) {
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) rv[rr][ti] = rg[(size_t)rows[rr] * a.ldt + ti * 32];
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = row_base + mi * 32 + rr + 8 * rq;
+          const bool row_ok = full_rows || row < a.M;
 #pragma unroll
           for (int ti = 0; ti < 4; ++ti) {
-            const int col = t0 + ti * 32 + lr;
-            if (col < a.T) {
-              float v = acc[mi][ti][r] + bsum;
-              fsum += v;
-              fsq += v * v;
-              const size_t off = (size_t)row * a.ldt + col;
-              if (rg) v += rg[off];
-              yg[off] = v;
-            }
+            float v = acc[mi][ti][rq * 4 + rr] + bs[rr];
+            const float vm = row_ok ? v * cmask[ti] : 0.f;
+            fsum += vm;
+            fsq += vm * vm;
+            if (rg) v += rv[rr][ti];
+            if (row_ok) yg[(size_t)row * a.ldt + ti * 32] = v;
           }
         }
       }
