@@ -42,6 +42,18 @@ def conv_flops_per_forward(model, n, t):
     return blocks * per_block, blocks * 3
 
 
+def host_cores():
+    """CPU threads this process may actually use (affinity mask and cgroup quota, not the host's total)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The CPU oracle (a restatement of the reference's PyTorch CPU path, pinned to it by tests/golden)
     timed on this host's cores on a bounded sample of the same workload."""
@@ -53,6 +65,7 @@ def cpu_baseline(seconds_budget=25.0):
     sd = {k: v.float() for k, v in det_state_dict(model).items()}
     cfg = cases.oracle_cfg("cfg2_full")
     nb = 4
+    torch.set_num_threads(host_cores())
     x = det_wave(1234, nb, L)
     with torch.no_grad():
         O.inference(x[:1], sd, cfg)  # warm-up (thread pools, allocator)

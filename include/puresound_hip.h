@@ -54,6 +54,8 @@ const char* ps_last_error(void);
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
  * "unpad_rows").  Not for use under stream capture. */
+int ps_debug_flags(int flags); /* ablation switches for kernel profiling (tools/); <0 reads; returns old */
+int ps_debug_buffer(void* device_buffer); /* 6 x u64 per conv1x1 workgroup: s_memtime stamps + HW ids */
 int ps_profile_enable(int on);
 int ps_profile_read(const char* kernel, double* total_ms, int* launches);
 

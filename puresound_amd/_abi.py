@@ -42,6 +42,8 @@ class TcnBlock(C.Structure):
 SIGNATURES = {
     "ps_abi_version": (C.c_int, []),
     "ps_last_error": (C.c_char_p, []),
+    "ps_debug_flags": (C.c_int, [C.c_int]),
+    "ps_debug_buffer": (C.c_int, [_vp]),
     "ps_profile_enable": (C.c_int, [C.c_int]),
     "ps_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "ps_stats_parts": (C.c_int, [C.c_int, C.c_int]),
@@ -104,7 +106,11 @@ def require_device(t: torch.Tensor, what: str) -> None:
 
 
 def padded_frames(t: int) -> int:
-    return (t + 127) // 128 * 128
+    """Same law as ps_padded_frames: an odd multiple of 128 frames >= t (no power-of-two row stride)."""
+    tiles = (t + 127) // 128
+    if tiles % 2 == 0:
+        tiles += 1
+    return tiles * 128
 
 
 def stats_parts(channels: int, frames: int) -> int:

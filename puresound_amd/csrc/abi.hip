@@ -12,6 +12,8 @@
 namespace ps {
 
 static thread_local char g_err[512] = "";
+int g_debug_flags = 0;
+void* g_debug_buffer = nullptr;
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -54,6 +56,17 @@ using namespace ps;
 extern "C" int ps_abi_version(void) { return PS_ABI_VERSION; }
 extern "C" const char* ps_last_error(void) { return g_err; }
 
+extern "C" int ps_debug_flags(int flags) {
+  const int old = g_debug_flags;
+  if (flags >= 0) g_debug_flags = flags;
+  return old;
+}
+
+extern "C" int ps_debug_buffer(void* device_buffer) {
+  g_debug_buffer = device_buffer;
+  return 0;
+}
+
 extern "C" int ps_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (on) {
@@ -92,7 +105,14 @@ extern "C" int ps_profile_read(const char* kernel, double* total_ms, int* launch
   return 0;
 }
 
-extern "C" int ps_padded_frames(int frames) { return frames <= 0 ? 0 : ceil_div(frames, kTileT) * kTileT; }
+// Rows are padded to an ODD multiple of 128 frames (512 B): a power-of-two row stride (T=3999 -> 16 KiB)
+// would put the same column of every channel row on the same HBM channels ("channel camping").
+extern "C" int ps_padded_frames(int frames) {
+  if (frames <= 0) return 0;
+  int tiles = ceil_div(frames, kTileT);
+  if ((tiles & 1) == 0) ++tiles;
+  return tiles * kTileT;
+}
 
 extern "C" int ps_stats_parts(int channels, int frames) {
   if (channels <= 0 || frames <= 0) return 0;

@@ -31,6 +31,8 @@ struct Conv1x1Args {
   double* ostats;
   ps_prologue pro;
   int K, M, T, ldt, Mp;
+  unsigned long long* stamps;  // ps_debug_buffer(): per-workgroup s_memtime stamps (diagnostic builds/runs only)
+  int dbg;  // ablation switches (ps_debug_flags): 1 no stores, 2 no MFMA, 4 no in-loop global loads, 8 no stats
 };
 
 __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
@@ -45,6 +47,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
   const int m0 = blockIdx.y * BM;
   const int t0 = blockIdx.x * BT;
 
+  unsigned long long t_begin = 0, t_pro = 0, t_loop = 0;
+  if (a.stamps) t_begin = __builtin_amdgcn_s_memtime();
   const NormScalars ns = load_norm_scalars(a.pro, n, red);
   const bool transform = a.pro.norm != PS_NORM_NONE || a.pro.prelu;
   const float slope = a.pro.prelu ? a.pro.slope[0] : 1.f;
@@ -59,8 +63,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
   const int b_col = (tid & 31) * 4;   // 0..124
 
   f32x4 ra[4], rb[2];
-  float sc[2], sh[2], mu[2];
+  float gm[2], bt[2];
+  bool valid[2];
+  const bool has_norm = a.pro.norm != PS_NORM_NONE;  // kernel-uniform
 
+  // Issue the global loads of one K-step.  Nothing here consumes a loaded value, so the compiler places
+  // no s_waitcnt between these loads and the MFMAs that follow: the tile lands while the matrix pipe works.
+  // Rows k >= K are clamped to a valid address and zeroed in store_step (branch-free issue).
   auto load_step = [&](int k0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -68,21 +77,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int k = k0 + b_row + 8 * j;
-      if (k < a.K) {
-        rb[j] = *reinterpret_cast<const f32x4*>(xg + (size_t)k * a.ldt + b_col);
-        if (a.pro.norm != PS_NORM_NONE) {
-          sc[j] = a.pro.gamma[k] * ns.rstd;
-          sh[j] = a.pro.beta[k];
-        } else {
-          sc[j] = 1.f;
-          sh[j] = 0.f;
-        }
-        mu[j] = 1.f;  // marks "row valid"
-      } else {
-        rb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        sc[j] = 0.f;
-        sh[j] = 0.f;
-        mu[j] = 0.f;
+      valid[j] = k < a.K;
+      const int kc = valid[j] ? k : a.K - 1;
+      rb[j] = *reinterpret_cast<const f32x4*>(xg + (size_t)kc * a.ldt + b_col);
+      if (has_norm) {
+        gm[j] = a.pro.gamma[kc];
+        bt[j] = a.pro.beta[kc];
       }
     }
   };
@@ -94,13 +94,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
     for (int j = 0; j < 2; ++j) {
       f32x4 v = rb[j];
       if (transform) {
+        const float sc = has_norm ? gm[j] * ns.rstd : 1.f;
+        const float sh = has_norm ? bt[j] : 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float u = (v[e] - ns.mean) * sc[j] + sh[j];
-          u = prelu(u, slope);
-          v[e] = mu[j] != 0.f ? u : 0.f;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = prelu((v[e] - ns.mean) * sc + sh, slope);
       }
+      if (!valid[j]) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(&Bs[buf][b_row + 8 * j][b_col]) = v;
     }
   };
@@ -121,30 +120,43 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
   load_step(0);
   store_step(0);
   __syncthreads();
+  if (a.stamps) t_pro = __builtin_amdgcn_s_memtime();
 
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nsteps) load_step((s + 1) * BK);
-    if (wave_active) {
+    if (s + 1 < nsteps && !(a.dbg & 4)) load_step((s + 1) * BK);
+    if (wave_active && !(a.dbg & 2)) {
+      // fragment registers are double-buffered: the LDS reads of k-pair kk+1 are in flight while the
+      // eight MFMAs of k-pair kk issue, so no MFMA waits on an LDS round trip inside a K-step.
+      float av[2][2], bv[2][4];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) av[0][mi] = As[buf][lk][wave * 64 + mi * 32 + lr];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) bv[0][ti] = Bs[buf][lk][ti * 32 + lr];
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
-        const int k = 2 * kk + lk;
-        float av[2], bv[4];
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 2) {
+          const int k = 2 * (kk + 1) + lk;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) av[mi] = As[buf][k][wave * 64 + mi * 32 + lr];
+          for (int mi = 0; mi < 2; ++mi) av[nxt][mi] = As[buf][k][wave * 64 + mi * 32 + lr];
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) bv[ti] = Bs[buf][k][ti * 32 + lr];
+          for (int ti = 0; ti < 4; ++ti) bv[nxt][ti] = Bs[buf][k][ti * 32 + lr];
+        }
+        // keep the prefetch reads ahead of this k-pair's MFMAs (hipcc otherwise sinks them to their use)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ti = 0; ti < 4; ++ti)
-            acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ti], acc[mi][ti], 0, 0, 0);
+            acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mi], bv[cur][ti], acc[mi][ti], 0, 0, 0);
       }
     }
     if (s + 1 < nsteps) store_step(buf ^ 1);
     __syncthreads();
   }
 
+  if (a.stamps) t_loop = __builtin_amdgcn_s_memtime();
   // ---- epilogue: bias, residual, store, partial statistics -------------------------------------
   // Pad columns (t >= T, always inside the padded row) are stored too: nothing reads them as data, and
   // keeping the stores unconditional lets the compiler batch the residual loads instead of serialising
@@ -188,7 +200,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
             fsum += vm;
             fsq += vm * vm;
             if (rg) v += rv[rr][ti];
-            if (row_ok) yg[(size_t)row * a.ldt + ti * 32] = v;
+            if (a.dbg & 1) {
+              asm volatile("" ::"v"(v));
+            } else if (row_ok) {
+              yg[(size_t)row * a.ldt + ti * 32] = v;
+            }
           }
         }
       }
@@ -196,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
       ssq += (double)fsq;
     }
   }
-  if (a.ostats) {
+  if (a.ostats && !(a.dbg & 8)) {
     block_sum2(ssum, ssq, red);
     if (tid == 0) {
       const int parts = gridDim.x * gridDim.y;
@@ -204,6 +220,21 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
       dst[0] = ssum;
       dst[1] = ssq;
     }
+  }
+  if (a.stamps && tid == 0) {
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const size_t wgid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    unsigned long long* d = a.stamps + wgid * 6;
+    d[0] = t_begin;
+    d[1] = t_pro;
+    d[2] = t_loop;
+    d[3] = t_end;
+    d[4] = hwid;
+    d[5] = xcc;
   }
 }
 
@@ -253,6 +284,8 @@ extern "C" int ps_conv1x1_f32(const float* x, const float* wt, float* y, int N, 
   a.T = T;
   a.ldt = ldt;
   a.Mp = (M + BM - 1) / BM * BM;
+  a.dbg = g_debug_flags;
+  a.stamps = (unsigned long long*)g_debug_buffer;
   dim3 grid((T + BT - 1) / BT, (M + BM - 1) / BM, N);
   {
     LaunchTimer timer("conv1x1", (hipStream_t)stream);

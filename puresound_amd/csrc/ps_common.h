@@ -14,6 +14,8 @@ constexpr int kWave = 64;
 constexpr int kTileT = 128;  // padded-row granule: ldt % kTileT == 0
 
 void set_error(const char* fmt, ...);
+extern void* g_debug_buffer;  // ps_debug_buffer(): where diagnostic stamps go (NULL in production)
+extern int g_debug_flags;  // ps_debug_flags(): kernel ablation switches for profiling builds, 0 in production
 
 // Brackets one kernel launch with hipEvents when ps_profile_enable(1) is active (no-op otherwise).
 struct LaunchTimer {

@@ -163,7 +163,7 @@ def test_embed_bias(H, dev):
 def test_pad_unpad_roundtrip(H, dev):
     x = _rand((3, 7, 131), 22).to(dev)
     p = H.pad_rows(x)
-    assert p.shape[-1] == 256 and torch.equal(p[..., :131], x) and float(p[..., 131:].abs().max()) == 0.0
+    assert p.shape[-1] == 384 and torch.equal(p[..., :131], x) and float(p[..., 131:].abs().max()) == 0.0
     assert torch.equal(H.unpad_rows(p, 131), x)
 
 

@@ -1,0 +1,45 @@
+"""Ablation timing of ps_conv1x1_f32 on the three Conv-TasNet GEMM shapes (run on the GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from puresound_amd import hip, _abi
+
+dev = torch.device("cuda:0")
+lib = _abi.lib()
+N, T = 32, 3999
+ldt = _abi.padded_frames(T)
+shapes = {"in  K512 M256": (512, 256, False, False), "pw  K256 M256": (256, 256, True, False),
+          "out K256 M512": (256, 512, True, True)}
+flags = {"full": 0, "no-store": 1, "no-mfma": 2, "no-gload": 4, "no-stats": 8, "no-store+no-mfma": 3,
+         "no-mfma+no-gload": 6, "only-loop-mfma(1|4|8)": 13}
+torch.manual_seed(0)
+for name, (K, M, pro, res) in shapes.items():
+    x = torch.randn(N, K, ldt, device=dev)
+    wt = hip.pack_wt(torch.randn(M, K, device=dev) * 0.05)
+    y = torch.empty(N, M, ldt, device=dev)
+    r = torch.randn(N, M, ldt, device=dev) if res else None
+    bias = torch.randn(M, device=dev)
+    g, b, sl = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1, torch.tensor([0.25], device=dev)
+    parts = 64
+    st = torch.zeros(N, parts, 2, dtype=torch.float64, device=dev)
+    st[:, 0, 0] = 0.0
+    st[:, 0, 1] = float(K * T)
+    p = hip.make_prologue(_abi.PS_NORM_GLOBAL, True, st, K * T, 1e-8, g, b, sl) if pro else None
+    flop = 2.0 * N * T * K * M
+    res_line = []
+    for fname, f in flags.items():
+        lib.ps_debug_flags(f)
+        for _ in range(3):
+            hip.conv1x1(x, T, wt, M, p, bias, None, r, want_stats=not res, out=y)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            hip.conv1x1(x, T, wt, M, p, bias, None, r, want_stats=not res, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        res_line.append(f"{fname}={us:.0f}us")
+    lib.ps_debug_flags(0)
+    print(name, f"(peak {flop / 157.3e12 * 1e6:.0f}us)", "  ".join(res_line), flush=True)
