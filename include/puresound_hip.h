@@ -63,6 +63,9 @@ int ps_profile_read(const char* kernel, double* total_ms, int* launches);
  * Stats are handed from the producing kernel to the consuming kernel as per-workgroup partials
  * (deterministic; no atomics).  ps_stats_parts() is an upper bound for any kernel here. */
 int ps_stats_parts(int channels, int frames);
+/* exact number of partial slabs per utterance each producer writes ([N][parts][2] doubles) */
+int ps_conv1x1_stats_parts(int M, int T);
+int ps_dwconv_stats_parts(int H, int T);
 
 /* round up T to the padded row length the kernels require */
 int ps_padded_frames(int frames);

@@ -47,6 +47,8 @@ SIGNATURES = {
     "ps_profile_enable": (C.c_int, [C.c_int]),
     "ps_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "ps_stats_parts": (C.c_int, [C.c_int, C.c_int]),
+    "ps_conv1x1_stats_parts": (C.c_int, [C.c_int, C.c_int]),
+    "ps_dwconv_stats_parts": (C.c_int, [C.c_int, C.c_int]),
     "ps_padded_frames": (C.c_int, [C.c_int]),
     "ps_pad_rows_f32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "ps_unpad_rows_f32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
@@ -111,9 +113,3 @@ def padded_frames(t: int) -> int:
     if tiles % 2 == 0:
         tiles += 1
     return tiles * 128
-
-
-def stats_parts(channels: int, frames: int) -> int:
-    gemm = ((frames + 127) // 128) * ((channels + 255) // 256)
-    dw = ((frames + 1023) // 1024) * ((channels + 15) // 16)
-    return max(gemm, dw)

@@ -116,8 +116,8 @@ extern "C" int ps_padded_frames(int frames) {
 
 extern "C" int ps_stats_parts(int channels, int frames) {
   if (channels <= 0 || frames <= 0) return 0;
-  const int gemm = ceil_div(frames, 128) * ceil_div(channels, 256);
-  const int dw = ceil_div(frames, 1024) * ceil_div(channels, 16);
+  const int gemm = ps_conv1x1_stats_parts(channels, frames);
+  const int dw = ps_dwconv_stats_parts(channels, frames);
   return gemm > dw ? gemm : dw;
 }
 
@@ -163,8 +163,8 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
   int rc;
   const float eps = 1e-8f;  // GlobLN.eps and gGN's eps (lobe/norm.py:10,96); folded BN carries its own
   const double count = (double)b.H * (double)T;
-  const int gemm_parts_h = ceil_div(T, 128) * ceil_div(b.H, 256);
-  const int dw_parts = ceil_div(T, 1024) * ceil_div(b.H, 16);
+  const int gemm_parts_h = ps_conv1x1_stats_parts(b.H, T);
+  const int dw_parts = ps_dwconv_stats_parts(b.H, T);
 
   // 1) in_conv (no bias) [+ per-utterance embedding bias]; stats of y1
   const float* bias_n = nullptr;

@@ -89,6 +89,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
 
 }  // namespace ps
 
+extern "C" int ps_dwconv_stats_parts(int H, int T) {
+  if (H <= 0 || T <= 0) return 0;
+  return ((T + ps::DW_FRAMES - 1) / ps::DW_FRAMES) * ((H + ps::DW_ROWS - 1) / ps::DW_ROWS);
+}
+
 extern "C" int ps_dwconv_f32(const float* x, const float* w, const float* b, float* y, int N, int H, int T,
                              int ldt, int P, int dilation, int left, const ps_prologue* pro, double* ostats,
                              void* stream) {

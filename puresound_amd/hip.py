@@ -10,7 +10,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _abi
-from ._abi import Prologue, TcnBlock, check, lib, padded_frames, ptr, require_device, stats_parts, stream_ptr
+from ._abi import Prologue, TcnBlock, check, lib, padded_frames, ptr, require_device, stream_ptr
 
 
 def pack_wt(w: torch.Tensor) -> torch.Tensor:
@@ -95,7 +95,7 @@ def conv1x1(x: torch.Tensor, t: int, wt: torch.Tensor, m: int, pro: Optional[Pro
     y = out if out is not None else torch.zeros(n, m, ldt, dtype=torch.float32, device=x.device)
     stats = None
     if want_stats:
-        parts = ((t + 127) // 128) * ((m + 255) // 256)
+        parts = lib().ps_conv1x1_stats_parts(m, t)
         stats = torch.zeros(n, parts, 2, dtype=torch.float64, device=x.device)
     check(lib().ps_conv1x1_f32(ptr(x), ptr(wt), ptr(y), n, k, m, t, ldt, C.byref(pro) if pro is not None else None,
                                ptr(bias), ptr(bias_n), ptr(res), ptr(stats), stream_ptr(x.device)), "ps_conv1x1_f32")
@@ -111,7 +111,7 @@ def dwconv(x: torch.Tensor, t: int, w: torch.Tensor, b: Optional[torch.Tensor], 
     y = torch.zeros_like(x)
     stats = None
     if want_stats:
-        parts = ((t + 1023) // 1024) * ((h + 15) // 16)
+        parts = lib().ps_dwconv_stats_parts(h, t)
         stats = torch.zeros(n, parts, 2, dtype=torch.float64, device=x.device)
     check(lib().ps_dwconv_f32(ptr(x), ptr(w), ptr(b), ptr(y), n, h, t, ldt, p, dilation, left,
                               C.byref(pro) if pro is not None else None, ptr(stats), stream_ptr(x.device)),

@@ -91,9 +91,13 @@ def test_conv1x1_plain_and_stats(H, dev, n, k, m, t):
     bn = _rand((n, m), 9)
     res = _rand((n, m, t), 10)
     ref = torch.matmul(w, x) + b.reshape(1, -1, 1) + bn.reshape(n, m, 1)
-    y, st = H.conv1x1(H.pad_rows(x.to(dev)), t, H.pack_wt(w.to(dev)), m, None, b.to(dev), bn.to(dev),
-                      H.pad_rows(res.to(dev)), want_stats=True)
+    xd, wd = H.pad_rows(x.to(dev)), H.pack_wt(w.to(dev))
+    y, _ = H.conv1x1(xd, t, wd, m, None, b.to(dev), bn.to(dev), H.pad_rows(res.to(dev)))
     assert rel_max(y[..., :t].cpu().numpy(), (ref + res).numpy()) < 1e-5
+    y, st = H.conv1x1(xd, t, wd, m, None, b.to(dev), bn.to(dev), None, want_stats=True)
+    assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 1e-5
+    with pytest.raises(RuntimeError, match="cannot be combined"):
+        H.conv1x1(xd, t, wd, m, None, b.to(dev), bn.to(dev), H.pad_rows(res.to(dev)), want_stats=True)
     s = st.sum(1).cpu().numpy()
     ref64 = ref.double()
     np.testing.assert_allclose(s[:, 0], ref64.sum((1, 2)).numpy(), rtol=1e-5, atol=1e-3)

@@ -10,8 +10,7 @@ N, T = 32, 3999
 ldt = _abi.padded_frames(T)
 shapes = {"in  K512 M256": (512, 256, False, False), "pw  K256 M256": (256, 256, True, False),
           "out K256 M512": (256, 512, True, True)}
-flags = {"full": 0, "no-store": 1, "no-mfma": 2, "no-gload": 4, "no-stats": 8, "no-store+no-mfma": 3,
-         "no-mfma+no-gload": 6, "only-loop-mfma(1|4|8)": 13}
+flags = {"full": 0}
 torch.manual_seed(0)
 for name, (K, M, pro, res) in shapes.items():
     x = torch.randn(N, K, ldt, device=dev)
@@ -20,7 +19,7 @@ for name, (K, M, pro, res) in shapes.items():
     r = torch.randn(N, M, ldt, device=dev) if res else None
     bias = torch.randn(M, device=dev)
     g, b, sl = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1, torch.tensor([0.25], device=dev)
-    parts = 64
+    parts = lib.ps_dwconv_stats_parts(K, T)
     st = torch.zeros(N, parts, 2, dtype=torch.float64, device=dev)
     st[:, 0, 0] = 0.0
     st[:, 0, 1] = float(K * T)

@@ -1,4 +1,4 @@
-"""Per-workgroup timeline of ps_conv1x1_f32 (s_memtime stamps): phases and co-residency (GPU box)."""
+"""Per-workgroup timeline of ps_conv1x1_f32 (s_memtime stamps) -- persistent-kernel layout (GPU box)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,9 +11,10 @@ for name, (K, M, pro, res) in shapes.items():
     y = torch.empty(N, M, ldt, device=dev); r = torch.randn(N, M, ldt, device=dev) if res else None
     bias = torch.randn(M, device=dev)
     g, b, sl = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1, torch.tensor([0.25], device=dev)
-    st = torch.zeros(N, 64, 2, dtype=torch.float64, device=dev); st[:, 0, 1] = float(K * T)
+    parts = lib.ps_dwconv_stats_parts(K, T)
+    st = torch.zeros(N, parts, 2, dtype=torch.float64, device=dev); st[:, 0, 1] = float(K * T)
     p = hip.make_prologue(_abi.PS_NORM_GLOBAL, True, st, K * T, 1e-8, g, b, sl) if pro else None
-    nwg = 32 * ((M + 255) // 256) * N
+    nwg = 512
     buf = torch.zeros(nwg * 6, dtype=torch.int64, device=dev)
     for _ in range(3):
         hip.conv1x1(x, T, wt, M, p, bias, None, r, want_stats=not res, out=y)
@@ -21,18 +22,11 @@ for name, (K, M, pro, res) in shapes.items():
     hip.conv1x1(x, T, wt, M, p, bias, None, r, want_stats=not res, out=y)
     torch.cuda.synchronize(); lib.ps_debug_buffer(None)
     s = buf.cpu().numpy().reshape(nwg, 6).astype(np.int64)
+    s = s[s[:, 0] > 0]
     t0 = s[:, 0].min()
-    # s_memtime ticks at 100 MHz? report in ticks and as fractions
-    dur = s[:, 3] - s[:, 0]; pro_t = s[:, 1] - s[:, 0]; loop_t = s[:, 2] - s[:, 1]; epi_t = s[:, 3] - s[:, 2]
-    print(f"{name}: WGs={nwg} span={s[:,3].max()-t0} ticks; per-WG total med={np.median(dur):.0f} "
-          f"prologue med={np.median(pro_t):.0f} loop med={np.median(loop_t):.0f} epilogue med={np.median(epi_t):.0f}")
-    start = s[:, 0] - t0
-    first = np.sort(start)[:512]; print("   start of first 512 WGs: max", first.max(), " later WGs start min", np.sort(start)[512:].min() if nwg > 512 else -1)
-    # per-CU grouping: hw_id bits: cu_id [11:8], sh [12], se [15:13]; plus xcc
-    cu = (s[:, 4] >> 8) & 0xff; key = s[:, 5] * 1000 + cu
-    uniq, cnt = np.unique(key, return_counts=True)
-    print("   distinct (xcc,cu-ish) keys:", len(uniq), " WGs per key min/max:", cnt.min(), cnt.max())
-    # show timeline for one key
-    k0 = uniq[0]; rows = s[key == k0]; rows = rows[np.argsort(rows[:, 0])]
-    for rrow in rows[:8]:
-        print("     ", [int(v - t0) for v in rrow[:4]])
+    tiles = s[:, 3]; dur = s[:, 2] - s[:, 0]; fill = s[:, 1] - s[:, 0]
+    nsteps = max(2, (K + 15) // 16)
+    ideal = tiles * nsteps * 32 * 64 * 2  # two co-resident waves per SIMD share the MFMA pipe
+    print(f"{name}: WGs={len(s)} span={s[:,2].max()-t0} cyc; tiles/WG {tiles.min()}..{tiles.max()}; per-WG total med={np.median(dur):.0f} "
+          f"fill med={np.median(fill):.0f}; per tile med={np.median(dur/tiles):.0f} (MFMA-only 2-wave ideal {nsteps*32*64*2}); "
+          f"start spread={np.ptp(s[:,0])}")
