@@ -54,7 +54,8 @@ const char* ps_last_error(void);
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
  * "unpad_rows").  Not for use under stream capture. */
-int ps_debug_flags(int flags); /* ablation switches for kernel profiling (tools/); <0 reads; returns old */
+int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
+                                  <0 reads; returns the old value */
 int ps_debug_buffer(void* device_buffer); /* 6 x u64 per conv1x1 workgroup: s_memtime stamps + HW ids */
 int ps_profile_enable(int on);
 int ps_profile_read(const char* kernel, double* total_ms, int* launches);
@@ -103,7 +104,8 @@ int ps_free_decode_f32(const float* feats, const float* mask, int mask_act, cons
  * (lobe/cnn.py:75-79), TCN.out_conv + residual (conv_tasnet.py:65,87-88), together with the
  * GlobLN / GroupNorm(1) / BatchNorm1d(eval) + PReLU that precede them (lobe/norm.py:20-34,94,96).
  *
- * wt is the weight TRANSPOSED and zero padded to [Kp][Mp], Kp = ceil16(K), Mp = ceil256(M).
+ * wt is the weight in kernel layout [ceil(M/256)][Kp][256], Kp = ceil16(K): transposed (k-major), zero
+ * padded, one 256-channel output tile after the other.
  * ------------------------------------------------------------------------------------------- */
 typedef struct ps_prologue {
   int norm;              /* PS_NORM_* */
@@ -148,13 +150,13 @@ int ps_embed_bias_f32(const float* dvec, const float* w_embed, float* bias_n, in
 typedef struct ps_tcn_block {
   int C, H, P, dilation, causal;
   int in_norm, dw_norm, pw_norm; /* PS_NORM_GLOBAL or PS_NORM_AFFINE */
-  const float* in_wt;            /* [ceil16(C)][ceil256(H)] */
+  const float* in_wt;            /* kernel layout of in_conv.0.weight[:, :C] (see ps_conv1x1_f32) */
   const float* in_embed_w;       /* [H][E] or NULL */
   int E;
   const float *in_gamma, *in_beta, *in_slope;
   const float *dw_w, *dw_b, *dw_gamma, *dw_beta, *dw_slope;
-  const float *pw_wt, *pw_b, *pw_gamma, *pw_beta, *pw_slope; /* pw_wt [ceil16(H)][ceil256(H)] */
-  const float *out_wt, *out_b;                                /* out_wt [ceil16(H)][ceil256(C)] */
+  const float *pw_wt, *pw_b, *pw_gamma, *pw_beta, *pw_slope; /* pw_wt: kernel layout */
+  const float *out_wt, *out_b;                                /* out_wt: kernel layout */
 } ps_tcn_block;
 
 /* bytes of scratch ps_conv_tasnet_f32 needs for a batch (3 hidden maps + stats + embed bias) */

@@ -14,13 +14,17 @@ from ._abi import Prologue, TcnBlock, check, lib, padded_frames, ptr, require_de
 
 
 def pack_wt(w: torch.Tensor) -> torch.Tensor:
-    """[M,K] (or [M,K,1]) conv weight -> transposed, zero padded [ceil16(K)][ceil256(M)] (see ps_conv1x1_f32)."""
+    """[M,K] (or [M,K,1]) conv weight -> kernel layout [ceil(M/256)][ceil16(K)][256]: transposed (k-major),
+    zero padded, one 256-channel output tile after the other (see ps_conv1x1_f32)."""
     if w.dim() == 3:
         w = w[:, :, 0]
     m, k = w.shape
-    kp, mp = (k + 15) // 16 * 16, (m + 255) // 256 * 256
-    out = torch.zeros(kp, mp, dtype=torch.float32, device=w.device)
-    out[:k, :m] = w.detach().to(torch.float32).t()
+    kp, mt = (k + 15) // 16 * 16, (m + 255) // 256
+    out = torch.zeros(mt, kp, 256, dtype=torch.float32, device=w.device)
+    wt = w.detach().to(torch.float32).t()  # [K, M]
+    for i in range(mt):
+        cols = min(256, m - i * 256)
+        out[i, :k, :cols] = wt[:, i * 256:i * 256 + cols]
     return out
 
 

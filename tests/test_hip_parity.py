@@ -156,6 +156,39 @@ def test_dwconv(H, dev, p, dil, causal, n, h, t):
     np.testing.assert_allclose(s[:, 1], (ref.double() ** 2).sum((1, 2)).numpy(), rtol=1e-5)
 
 
+@pytest.mark.parametrize("grid_cap", [1, 2, 3])
+def test_conv1x1_long_runs_across_utterances(H, dev, grid_cap):
+    """A persistent workgroup's run of tiles crosses utterance and m-tile boundaries (grid capped by the
+    test hook): per-utterance norm tables, bias rows and the residual window must all follow."""
+    from puresound_amd import _abi
+    n, k, m, t = 5, 40, 300, 300
+    x = _rand((n, k, t), 31) + 0.2
+    w = _rand((m, k), 32, -0.2, 0.2)
+    b, bn, res = _rand((m,), 33), _rand((n, m), 34), _rand((n, m, t), 35)
+    gamma, beta, slope = _rand((k,), 36, 0.5, 1.5), _rand((k,), 37, -0.2, 0.2), torch.tensor([0.15])
+    a = O.prelu(O.glob_ln(x, gamma, beta), slope)
+    ref = torch.matmul(w, a) + b.reshape(1, -1, 1) + bn.reshape(n, m, 1)
+    stats = torch.stack([x.double().sum((1, 2)), (x.double() ** 2).sum((1, 2))], -1).reshape(n, 1, 2).to(dev)
+    g_d, b_d, s_d = gamma.to(dev), beta.to(dev), slope.to(dev)
+    pro = H.make_prologue(_abi.PS_NORM_GLOBAL, True, stats, k * t, 1e-8, g_d, b_d, s_d)
+    xd, wd, bd, bnd, rd = H.pad_rows(x.to(dev)), H.pack_wt(w.to(dev)), b.to(dev), bn.to(dev), H.pad_rows(res.to(dev))
+    old = H.lib().ps_debug_flags(grid_cap << 8)
+    try:
+        y, st = H.conv1x1(xd, t, wd, m, pro, bd, bnd, None, want_stats=True)
+        y2, _ = H.conv1x1(xd, t, wd, m, pro, bd, bnd, rd)
+        y3, _ = H.conv1x1(xd, t, wd, m, None, bd, bnd, rd)
+        torch.cuda.synchronize()
+    finally:
+        H.lib().ps_debug_flags(old)
+    assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 2e-5
+    assert rel_max(y2[..., :t].cpu().numpy(), (ref + res).numpy()) < 2e-5
+    ref3 = torch.matmul(w, x) + b.reshape(1, -1, 1) + bn.reshape(n, m, 1) + res
+    assert rel_max(y3[..., :t].cpu().numpy(), ref3.numpy()) < 2e-5
+    s = st.sum(1).cpu().numpy()
+    np.testing.assert_allclose(s[:, 0], ref.double().sum((1, 2)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1], (ref.double() ** 2).sum((1, 2)).numpy(), rtol=1e-5)
+
+
 def test_embed_bias(H, dev):
     dvec, w = _rand((3, 19), 20), _rand((11, 19), 21)
     for normalize in (False, True):
