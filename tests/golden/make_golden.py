@@ -112,9 +112,22 @@ def run_encdec(name, c):
     return {"feats": feats.numpy(), "rec": rec.numpy()}
 
 
+def dump_state_dict_keys():
+    """Key -> shape of every reference state_dict the mirror modules must reproduce (drop-in checkpoints)."""
+    import json
+    out = {}
+    for name in cases.CASES:
+        model = cases.build(REF, name)
+        out[name] = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("state_dict_keys.json:", sum(len(v) for v in out.values()), "keys")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    dump_state_dict_keys()
     for name, c in cases.CASES.items():
         fn = {"wrap": run_wrap, "masker": run_masker, "encdec": run_encdec}[c["kind"]]
         out = fn(name, c)

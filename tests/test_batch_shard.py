@@ -1,0 +1,74 @@
+"""Utterance-batch data parallelism (puresound_amd/batch_shard.py) on CPU: world_size-2 gloo processes.
+The compute inside each rank is the CPU oracle here (tests may use it); on GPUs it is the HIP path and the
+collective is RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+from detweights import det_state_dict, det_wave
+from oracle import separator_oracle as O
+from puresound_amd.batch_shard import gather_utterances, shard_bounds, sharded_inference
+import puresound_amd.nnet as PA
+
+
+def test_shard_bounds_cover_the_batch_exactly():
+    for batch in (1, 2, 7, 32, 33, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(batch, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == batch
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b and c <= d
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, batch, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        name = "tiny_free"
+        sd = det_state_dict(cases.build(PA.NS, name))
+        cfg = cases.oracle_cfg(name)
+        noisy = det_wave(21, batch, 900)
+
+        def infer(x):
+            return O.inference(x, sd, cfg)
+
+        out = sharded_inference(infer, noisy)
+        lo, hi = shard_bounds(batch, world, rank)
+        # ragged explicit gather as well
+        again = gather_utterances(infer(noisy[lo:hi]), batch)
+        full = infer(noisy)
+        results[rank] = (bool(torch.allclose(out, full, atol=1e-6)), bool(torch.equal(out, again)), tuple(out.shape))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [4, 5])
+def test_sharded_inference_two_ranks_gloo(batch):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, port, batch, results), nprocs=world, join=True)
+    assert len(results) == world
+    for r in range(world):
+        same_as_unsharded, deterministic, shape = results[r]
+        assert same_as_unsharded and deterministic and shape[0] == batch
