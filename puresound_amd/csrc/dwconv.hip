@@ -3,10 +3,14 @@
 //   y[n][h][t] = b[h] + sum_j w[h][j] * a[n][h][t + j*dilation - left]      (a == 0 outside [0,T))
 // plus per-workgroup partial (sum, sumsq) of y for the next global norm.
 //
-// HBM-bound streaming kernel: one thread owns 4 consecutive frames (16-byte loads/stores), a workgroup
-// owns DW_ROWS channels x 1024 frames.  Taps whose offset is a multiple of 4 frames are aligned 16-byte
-// loads of the neighbouring vectors (they hit L1/L2: the same rows were just streamed); other offsets
-// (dilation 1, 2 or odd bases) fall back to dword loads.
+// HBM-bound streaming kernel with LDS-staged input tiles.  A workgroup owns DW_ROWS channels x 1024 frames
+// and walks them DW_RB rows at a time: each row segment [t0 - left, t0 + 1024 + right) is loaded ONCE with
+// coalesced 16-byte loads (the halo by the first threads), normalised + activated ONCE per element, zeroed
+// outside [0, T) and written to LDS; the taps are then plain LDS reads (16-byte when the tap offset is a
+// multiple of 4 frames, dword otherwise), so neither the tap loop nor the zero padding costs masks or repeated
+// transforms.  (A register-only version re-loaded and re-transformed every element once per tap: 26 VALU per
+// output frame and 0.43-0.6 of the achievable bandwidth.)  DW_RB rows are in flight per thread to cover the
+// HBM latency at the per-CU bandwidth share.
 #include "ps_common.h"
 
 namespace ps {
@@ -14,6 +18,9 @@ namespace ps {
 constexpr int DW_ROWS = 16;
 constexpr int DW_FRAMES = 1024;  // 256 threads x 4
 constexpr int DW_MAXP = 8;
+constexpr int DW_RB = 4;          // rows staged together
+constexpr int DW_MAXHALO = 1024;  // (P-1)*dilation frames of halo the LDS image can hold
+constexpr int DW_SEG = DW_FRAMES + DW_MAXHALO;
 
 struct DwArgs {
   const float* x;
@@ -25,55 +32,109 @@ struct DwArgs {
   int H, T, ldt, P, dilation, left;
 };
 
+// P > 0: compile-time tap count; P == 0: run-time taps.  ALIGNED: every tap offset is a multiple of 4 frames.
+template <int P, bool ALIGNED>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
+  __shared__ __attribute__((aligned(16))) float seg[DW_RB][DW_SEG];
   __shared__ double red[8];
   const int tid = threadIdx.x;
   const int n = blockIdx.z;
   const int h0 = blockIdx.y * DW_ROWS;
-  const int t = blockIdx.x * DW_FRAMES + tid * 4;
+  const int t0 = blockIdx.x * DW_FRAMES;
+  const int np = P > 0 ? P : a.P;
+  const int halo = (np - 1) * a.dilation;  // left + right
+  const int halo4 = (halo + 3) / 4;        // halo vectors, loaded by the first threads
+  // segment origin in frames, rounded down to a multiple of 4 so that every staging load is 16-byte aligned
+  const int lpad = (a.left + 3) / 4 * 4;
+  const int org = t0 - lpad;               // frame of seg[.][0]
+  const int shift = lpad - a.left;         // tap j of output frame f reads seg[f - t0 + j*dilation + shift]
+  const int nvec = DW_FRAMES / 4 + (lpad + halo - a.left + 3) / 4 + 0;  // vectors that can be touched
+  (void)halo4;
 
   const NormScalars ns = load_norm_scalars(a.pro, n, red);
   const bool has_norm = a.pro.norm != PS_NORM_NONE;
-  const float slope = a.pro.prelu ? a.pro.slope[0] : 1.f;
-  const bool aligned = (a.dilation % 4 == 0) && (a.left % 4 == 0);
+  const bool has_prelu = a.pro.prelu != 0;
+  const float slope = has_prelu ? a.pro.slope[0] : 1.f;
 
   float fsum = 0.f, fsq = 0.f;
-  if (t < a.T) {
-    for (int r = 0; r < DW_ROWS; ++r) {
-      const int h = h0 + r;
-      if (h >= a.H) break;
-      const float* xr = a.x + ((size_t)n * a.H + h) * a.ldt;
-      const float sc = has_norm ? a.pro.gamma[h] * ns.rstd : 1.f;
-      const float sh = has_norm ? a.pro.beta[h] : 0.f;
-      const float bias = a.b ? a.b[h] : 0.f;
-      f32x4 out{bias, bias, bias, bias};
-      for (int j = 0; j < a.P; ++j) {
-        const float wj = a.w[h * a.P + j];
-        const int tt = t + j * a.dilation - a.left;
-        f32x4 v{0.f, 0.f, 0.f, 0.f};
-        if (aligned) {
-          if (tt >= 0 && tt < a.T) v = *reinterpret_cast<const f32x4*>(xr + tt);
-        } else {
+  const int t = t0 + tid * 4;
+  for (int r0 = 0; r0 < DW_ROWS; r0 += DW_RB) {
+    if (h0 + r0 >= a.H) break;  // uniform
+    // ---- stage DW_RB row segments: load, transform once, zero outside [0,T), write LDS ----------------
+    f32x4 v[DW_RB][2];
+    const int i1 = tid + 256;  // second vector index (halo part): only the first (nvec - 256) threads
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (tt + e >= 0 && tt + e < a.T) v[e] = xr[tt + e];
-        }
+    for (int r = 0; r < DW_RB; ++r) {
+      const int h = h0 + r0 + r;
+      const float* xr = a.x + ((size_t)n * a.H + (h < a.H ? h : a.H - 1)) * a.ldt;
+      const int f0 = org + tid * 4, f1 = org + i1 * 4;
+      v[r][0] = (f0 >= 0 && f0 < a.T) ? *reinterpret_cast<const f32x4*>(xr + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[r][1] = (i1 < nvec && f1 >= 0 && f1 < a.T) ? *reinterpret_cast<const f32x4*>(xr + f1)
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int r = 0; r < DW_RB; ++r) {
+      const int h = h0 + r0 + r;
+      const int hc = h < a.H ? h : a.H - 1;
+      const float sc = has_norm ? a.pro.gamma[hc] * ns.rstd : 1.f;
+      const float sh = (has_norm ? a.pro.beta[hc] : 0.f) - ns.mean * sc;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int idx = q == 0 ? tid : i1;
+        if (q == 1 && idx >= nvec) continue;
+        const int f = org + idx * 4;
+        f32x4 u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float u = (v[e] - ns.mean) * sc + sh;
-          if (a.pro.prelu) u = prelu(u, slope);
-          u = (tt + e >= 0 && tt + e < a.T) ? u : 0.f;
-          out[e] += wj * u;
+          float z = v[r][q][e] * sc + sh;
+          if (has_prelu) z = prelu(z, slope);
+          u[e] = (f + e >= 0 && f + e < a.T) ? z : 0.f;  // the conv's zero padding is applied AFTER norm+PReLU
+        }
+        *reinterpret_cast<f32x4*>(&seg[r][idx * 4]) = u;
+      }
+    }
+    __syncthreads();
+    // ---- taps from LDS, bias, statistics, store --------------------------------------------------------
+    if (t < a.T) {
+#pragma unroll
+      for (int r = 0; r < DW_RB; ++r) {
+        const int h = h0 + r0 + r;
+        if (h < a.H) {
+          const float bias = a.b ? a.b[h] : 0.f;
+          f32x4 out{bias, bias, bias, bias};
+          const float* sp = &seg[r][tid * 4 + shift];
+          if constexpr (P > 0) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+              const float wj = a.w[h * P + j];
+              f32x4 s;
+              if constexpr (ALIGNED) {
+                s = *reinterpret_cast<const f32x4*>(sp + j * a.dilation);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] = sp[j * a.dilation + e];
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) out[e] += wj * s[e];
+            }
+          } else {
+            for (int j = 0; j < np; ++j) {
+              const float wj = a.w[h * np + j];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) out[e] += wj * sp[j * a.dilation + e];
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (t + e < a.T) {
+              fsum += out[e];
+              fsq += out[e] * out[e];
+            }
+          *reinterpret_cast<f32x4*>(a.y + ((size_t)n * a.H + h) * a.ldt + t) = out;
         }
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (t + e < a.T) {
-          fsum += out[e];
-          fsq += out[e] * out[e];
-        }
-      *reinterpret_cast<f32x4*>(a.y + ((size_t)n * a.H + h) * a.ldt + t) = out;
     }
+    __syncthreads();  // the next batch overwrites the LDS image
   }
   if (a.ostats) {
     double s = fsum, q = fsq;
@@ -101,6 +162,15 @@ extern "C" int ps_dwconv_f32(const float* x, const float* w, const float* b, flo
   if (!x || !w || !y || N <= 0 || H <= 0 || T <= 0 || P <= 0 || P > DW_MAXP || dilation <= 0 || left < 0) {
     set_error("ps_dwconv_f32: bad argument (N=%d H=%d T=%d P=%d dilation=%d left=%d)", N, H, T, P, dilation, left);
     return PS_E_INVALID;
+  }
+  if (left > (P - 1) * dilation) {
+    set_error("ps_dwconv_f32: left=%d exceeds the receptive field (P-1)*dilation=%d", left, (P - 1) * dilation);
+    return PS_E_INVALID;
+  }
+  if ((P - 1) * dilation + 8 > DW_MAXHALO) {
+    set_error("ps_dwconv_f32: (P-1)*dilation=%d exceeds the %d-frame halo the LDS tile holds", (P - 1) * dilation,
+              DW_MAXHALO - 8);
+    return PS_E_UNSUPPORTED;
   }
   if (ldt < T || ldt % kTileT != 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) {
     set_error("ps_dwconv_f32: ldt=%d must be a multiple of %d >= T=%d and pointers 16-byte aligned", ldt, kTileT, T);
@@ -135,10 +205,17 @@ extern "C" int ps_dwconv_f32(const float* x, const float* w, const float* b, flo
   a.P = P;
   a.dilation = dilation;
   a.left = left;
+  const bool aligned = (dilation % 4 == 0) && (left % 4 == 0);
   dim3 grid((T + DW_FRAMES - 1) / DW_FRAMES, (H + DW_ROWS - 1) / DW_ROWS, N);
   {
     LaunchTimer timer("dwconv", (hipStream_t)stream);
-    hipLaunchKernelGGL(dwconv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (P == 3 && aligned)
+      hipLaunchKernelGGL((dwconv_kernel<3, true>), grid, dim3(256), 0, st, a);
+    else if (P == 3)
+      hipLaunchKernelGGL((dwconv_kernel<3, false>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((dwconv_kernel<0, false>), grid, dim3(256), 0, st, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
