@@ -66,12 +66,15 @@ def free_encode(wav: torch.Tensor, w: torch.Tensor, hop: int, relu: bool = False
 
 
 def free_decode(feats: torch.Tensor, t: int, w: torch.Tensor, hop: int, mask: Optional[torch.Tensor] = None,
-                mask_act: str = "linear", out_mode: str = "none") -> torch.Tensor:
-    """feats/mask padded [N,C,ldt] -> waveform [N,(T-1)*hop+win]."""
+                mask_act: str = "linear", out_mode: str = "none", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """feats/mask padded [N,C,ldt] -> waveform [N,(T-1)*hop+win] (into `out` if given: contiguous rows)."""
     require_device(feats, "free_decode")
     n, c, ldt = feats.shape
     win = w.shape[-1]
-    out = torch.empty(n, (t - 1) * hop + win, dtype=torch.float32, device=feats.device)
+    if out is None:
+        out = torch.empty(n, (t - 1) * hop + win, dtype=torch.float32, device=feats.device)
+    elif tuple(out.shape) != (n, (t - 1) * hop + win) or not out.is_contiguous():
+        raise RuntimeError("free_decode: `out` must be a contiguous [N, (T-1)*hop+win] tensor")
     check(lib().ps_free_decode_f32(ptr(feats), ptr(mask), _abi.PS_ACT[mask_act], ptr(w), ptr(out), n, c, t, ldt,
                                    win, hop, _abi.PS_OUT[out_mode], stream_ptr(feats.device)), "ps_free_decode_f32")
     return out

@@ -214,8 +214,10 @@ class ConvTasNet(_PlanCache, nn.Module):
             self._blocks_sig = sig
         return self._blocks, len(plans)
 
-    def forward_padded(self, x_pad: torch.Tensor, t: int, dvec: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Padded-layout entry used by the fused wrapper: [N,C,ldt] -> mask logits [N,C,ldt]."""
+    def forward_padded(self, x_pad: torch.Tensor, t: int, dvec: Optional[torch.Tensor] = None,
+                       lane: int = 0) -> torch.Tensor:
+        """Padded-layout entry used by the fused wrapper: [N,C,ldt] -> mask logits [N,C,ldt].
+        `lane` selects the cached scratch buffer (one per concurrent HIP stream of the caller)."""
         blocks, n_blocks = self.block_array(x_pad.device)
         need_embed = any(self.tcn_with_embed)
         if need_embed and dvec is None:
@@ -225,9 +227,11 @@ class ConvTasNet(_PlanCache, nn.Module):
             dvec = None  # reference ignores dvec when no block takes it (conv_tasnet.py:354-357)
         n = x_pad.shape[0]
         need = hip.lib().ps_conv_tasnet_workspace_bytes(n, self.input_dim, self.tcn_dim, t)
-        ws = self._workspace
+        if self._workspace is None:
+            self._workspace = {}
+        ws = self._workspace.get(lane)
         if ws is None or ws.numel() < need or ws.device != x_pad.device:
-            ws = self._workspace = torch.zeros(need, dtype=torch.uint8, device=x_pad.device)
+            ws = self._workspace[lane] = torch.zeros(need, dtype=torch.uint8, device=x_pad.device)
         return hip.conv_tasnet(blocks, n_blocks, x_pad, t, self.input_dim, self.tcn_dim,
                                None if dvec is None else dvec.contiguous().float(),
                                bool(self.embed_norm), ws)

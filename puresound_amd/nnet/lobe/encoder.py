@@ -32,9 +32,10 @@ class FreeEncDec(nn.Module):
         return hip.free_encode(x, self.encoder.weight.detach(), self.hop_length, self.output_active)
 
     def decode_padded(self, feats_pad: torch.Tensor, t: int, mask_pad: Optional[torch.Tensor] = None,
-                      mask_act: str = "linear", out_mode: str = "none") -> torch.Tensor:
+                      mask_act: str = "linear", out_mode: str = "none",
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
         return hip.free_decode(feats_pad, t, self.decoder.weight.detach(), self.hop_length, mask_pad, mask_act,
-                               out_mode)
+                               out_mode, out)
 
     # -- reference API -------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:

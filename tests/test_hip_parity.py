@@ -263,6 +263,24 @@ def test_input_is_not_modified_and_result_is_deterministic(PA, dev):
     assert torch.equal(a, b)  # slab-reduced statistics: bitwise reproducible
 
 
+def test_stream_split_is_bit_identical(PA, dev):
+    model = cases.build(PA.NS, "tiny_free").eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    noisy = det_wave(4, 7, 2500).to(dev)
+    model.hip_streams = 1
+    one = model.inference(noisy)
+    for lanes in (2, 3):
+        model.hip_streams = lanes
+        assert torch.equal(model.inference(noisy), one)
+    side = torch.cuda.Stream(dev)  # and from a caller-chosen stream
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        other = model.inference(noisy)
+    side.synchronize()
+    assert torch.equal(other, one)
+
+
 def test_plan_follows_weight_updates(PA, dev):
     model = cases.build(PA.NS, "tiny_free").eval().to(dev)
     noisy = det_wave(3, 2, 1500).to(dev)
