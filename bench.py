@@ -24,6 +24,11 @@ import torch  # noqa: E402
 
 B_PER_GPU, L, SR = 32, 64000, 16000
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# HBM bytes per ps_conv1x1_f32 launch at 32 utterances, averaged over the three GEMM shapes, from the PMC
+# passes committed as profiles/r01_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+# runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): (207.4 + 149.4 + 388.4) / 3 MB per
+# 16-utterance launch.  Algorithmic bytes of the same launches: (207.6 + 138.4 + 346.0) / 3 MB.
+PMC_CONV1X1_BYTES_PER_LAUNCH = 2 * (207.4e6 + 149.4e6 + 388.4e6) / 3
 
 
 def build_model(dev):
@@ -177,7 +182,9 @@ def main():
         avg_ms = conv_ms / conv_cnt
         achieved = (flops / launches) / (avg_ms * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                              "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": PMC_CONV1X1_BYTES_PER_LAUNCH,
+                              "traffic_note": "bytes per launch from the committed PMC passes "
+                                              "(profiles/r01_pmc_hbm_traffic.txt), not re-measured in this run",
                               "kernel": "ps::conv1x1_* (ps_conv1x1_f32)", "avg_launch_ms": avg_ms,
                               "note": "kernel durations from a single-stream pass; value/ms_per_step from the "
                                       "product path (2 sub-batch streams)",
