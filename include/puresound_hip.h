@@ -53,7 +53,7 @@ const char* ps_last_error(void);
  * library is bracketed by hipEvents on the launch stream.  ps_profile_enable(1) clears old records.
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
- * "unpad_rows").  Not for use under stream capture. */
+ * "unpad_rows", "frame", "complex_mask", "istft_ola").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
 int ps_debug_buffer(void* device_buffer); /* 6 x u64 per conv1x1 workgroup: s_memtime stamps + HW ids */
@@ -94,6 +94,21 @@ int ps_free_encode_f32(const float* wav, const float* w, float* feats, int N, in
  * ------------------------------------------------------------------------------------------- */
 int ps_free_decode_f32(const float* feats, const float* mask, int mask_act, const float* w, float* out,
                        int N, int C, int T, int ldt, int win, int hop, int out_mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conv-STFT encoder / iSTFT decoder (ConvSTFT.forward / .inverse, lobe/encoder.py:358-456; extend_fbins,
+ * overlap_add, torch_window_sumsquare, lobe/stft.py:103-125).  wsin/wcos are trainable in every recipe, so both
+ * transforms are dense products on ps_conv1x1_f32 (analysis: K = n_fft window samples; synthesis: K = 2*bins
+ * with the Hermitian extension folded into the weight); these entry points are the steps around them:
+ *   ps_frame_f32        frames[n][k][t] = wav[n][t*hop + k]                     (conv1d's stride)
+ *   ps_complex_mask_f32 complex product of [re;im] channel halves with act(mask) (base_nn.py:56-61,97-112)
+ *   ps_istft_ola_f32    out = constrain( OLA-sum(frames * window / n_fft) / OLA-sum(window^2) where > 1e-10 )
+ * ------------------------------------------------------------------------------------------- */
+int ps_frame_f32(const float* wav, float* frames, int N, int L, int win, int hop, int T, int ldt, void* stream);
+int ps_complex_mask_f32(const float* feats, const float* mask, float* out, int N, int half, int ldt,
+                        int mask_act, void* stream);
+int ps_istft_ola_f32(const float* frames, const float* window, float* out, int N, int n_fft, int hop, int T,
+                     int ldt, int out_mode, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused 1x1 convolution (the Conv-TasNet channel-mixing GEMM; exact-fp32 MFMA):

@@ -54,6 +54,9 @@ SIGNATURES = {
     "ps_unpad_rows_f32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "ps_free_encode_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
     "ps_free_decode_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp] + [C.c_int] * 7 + [_vp]),
+    "ps_frame_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 6 + [_vp]),
+    "ps_complex_mask_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
+    "ps_istft_ola_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_conv1x1_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 5 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
     "ps_dwconv_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp]),
     "ps_embed_bias_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

@@ -581,8 +581,9 @@ extern "C" int ps_conv1x1_f32(const float* x, const float* wt, float* y, int N, 
     set_error("ps_conv1x1_f32: bias pointers must be 4-byte aligned");
     return PS_E_ALIGN;
   }
-  if (K > KMAX) {
-    set_error("ps_conv1x1_f32: K=%d exceeds the %d input channels this kernel keeps norm tables for", K, KMAX);
+  if (K > KMAX && pro && (pro->norm != PS_NORM_NONE || pro->prelu)) {
+    set_error("ps_conv1x1_f32: K=%d exceeds the %d input channels the prologue keeps scale/shift tables for", K,
+              KMAX);
     return PS_E_UNSUPPORTED;
   }
   if ((long long)K * ldt * 4 > 0x7fffffffLL || (long long)M * ldt * 4 > 0x7fffffffLL) {

@@ -1,0 +1,131 @@
+// Conv-STFT encoder / iSTFT decoder helpers (ConvSTFT, lobe/encoder.py:358-456 and lobe/stft.py:103-125 of
+// mcw519/PureSound).  The analysis kernels wsin/wcos are TRAINABLE parameters in every recipe, so the
+// transform is a dense product against learned filters, not an FFT: the two dense products (analysis,
+// synthesis with the Hermitian extension folded into the weight) run on ps_conv1x1_f32; this file holds the
+// byte-moving steps around them.
+#include "ps_common.h"
+
+namespace ps {
+
+// frames[n][k][t] = wav[n][t*hop + k]  (k < win, t < T): the strided framing the reference gets from conv1d's
+// stride.  One thread per (k, 4 frames): 16-byte coalesced stores, gathered dword loads (L1/L2 resident).
+__global__ __launch_bounds__(256) void frame_kernel(const float* __restrict__ wav, float* __restrict__ frames,
+                                                    int L, int win, int hop, int T, int ldt) {
+  const int n = blockIdx.z, k = blockIdx.y;
+  const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t >= ldt) return;
+  const float* x = wav + (size_t)n * L + k;
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (t + e < T) ? x[(size_t)(t + e) * hop] : 0.f;
+  *reinterpret_cast<f32x4*>(frames + ((size_t)n * win + k) * ldt + t) = v;
+}
+
+__device__ __forceinline__ float act(float m, int a) {
+  if (a == PS_ACT_RELU) return fmaxf(m, 0.f);
+  if (a == PS_ACT_SIGMOID) return 1.f / (1.f + expf(-m));
+  return m;
+}
+
+// Complex mask on a complex representation stored as channel halves [re ; im] (apply_tf_masks complex/complex,
+// base_nn.py:56-61, _mul_c :97-112):  y_re = x_re*m_re - x_im*m_im,  y_im = x_re*m_im + x_im*m_re.
+__global__ __launch_bounds__(256) void complex_mask_kernel(const float* __restrict__ feats,
+                                                           const float* __restrict__ mask, float* __restrict__ out,
+                                                           int half, int ldt, int mask_act) {
+  const int n = blockIdx.z, c = blockIdx.y;
+  const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t >= ldt) return;
+  const size_t re = ((size_t)n * 2 * half + c) * ldt + t, im = re + (size_t)half * ldt;
+  const f32x4 xr = *reinterpret_cast<const f32x4*>(feats + re), xi = *reinterpret_cast<const f32x4*>(feats + im);
+  f32x4 mr = *reinterpret_cast<const f32x4*>(mask + re), mi = *reinterpret_cast<const f32x4*>(mask + im);
+  f32x4 yr, yi;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float a = act(mr[e], mask_act), b = act(mi[e], mask_act);
+    yr[e] = xr[e] * a - xi[e] * b;
+    yi[e] = xr[e] * b + xi[e] * a;
+  }
+  *reinterpret_cast<f32x4*>(out + re) = yr;
+  *reinterpret_cast<f32x4*>(out + im) = yi;
+}
+
+// Overlap-add of synthesis frames (ConvSTFT.inverse, lobe/encoder.py:432-454): every frame is multiplied by the
+// window and divided by n_fft, overlapping samples are summed, then divided by the overlap-added squared window
+// wherever that exceeds 1e-10 (the reference does this with a boolean-mask index, i.e. a host sync; here the
+// window sum is recomputed per sample in the same loop).  One thread per output sample.
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames,
+                                                        const float* __restrict__ window, float* __restrict__ out,
+                                                        int n_fft, int hop, int T, int ldt, int out_mode) {
+  const int n = blockIdx.y;
+  const int Lout = (T - 1) * hop + n_fft;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= Lout) return;
+  int t_hi = g / hop;
+  if (t_hi > T - 1) t_hi = T - 1;
+  const int t_lo = (g - n_fft + 1 <= 0) ? 0 : (g - n_fft + 1 + hop - 1) / hop;
+  const float inv = (float)n_fft;
+  float acc = 0.f, wsum = 0.f;
+  for (int t = t_lo; t <= t_hi; ++t) {
+    const int s = g - t * hop;
+    const float w = window[s];
+    acc += frames[((size_t)n * n_fft + s) * ldt + t] * w / inv;
+    wsum += w * w;
+  }
+  if (wsum > 1e-10f) acc = acc / wsum;
+  if (out_mode == PS_OUT_CLAMP) acc = fminf(fmaxf(acc, -1.f), 1.f);
+  if (out_mode == PS_OUT_SIGMOID) acc = 1.f / (1.f + expf(-acc));
+  out[(size_t)n * Lout + g] = acc;
+}
+
+static int launched(const char* who) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", who, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+}  // namespace ps
+
+using namespace ps;
+
+extern "C" int ps_frame_f32(const float* wav, float* frames, int N, int L, int win, int hop, int T, int ldt,
+                            void* stream) {
+  if (!wav || !frames || N <= 0 || win <= 0 || hop <= 0 || L < win || T != (L - win) / hop + 1 || ldt < T ||
+      ldt % kTileT != 0 || win > 65535) {
+    set_error("ps_frame_f32: bad argument (N=%d L=%d win=%d hop=%d T=%d ldt=%d)", N, L, win, hop, T, ldt);
+    return PS_E_INVALID;
+  }
+  LaunchTimer timer("frame", (hipStream_t)stream);
+  hipLaunchKernelGGL(frame_kernel, dim3((ldt / 4 + 255) / 256, win, N), dim3(256), 0, (hipStream_t)stream, wav,
+                     frames, L, win, hop, T, ldt);
+  return launched("ps_frame_f32");
+}
+
+extern "C" int ps_complex_mask_f32(const float* feats, const float* mask, float* out, int N, int half, int ldt,
+                                   int mask_act, void* stream) {
+  if (!feats || !mask || !out || N <= 0 || half <= 0 || half > 65535 || ldt <= 0 || ldt % kTileT != 0 ||
+      mask_act < PS_ACT_LINEAR || mask_act > PS_ACT_SIGMOID) {
+    set_error("ps_complex_mask_f32: bad argument (N=%d half=%d ldt=%d act=%d)", N, half, ldt, mask_act);
+    return PS_E_INVALID;
+  }
+  LaunchTimer timer("complex_mask", (hipStream_t)stream);
+  hipLaunchKernelGGL(complex_mask_kernel, dim3((ldt / 4 + 255) / 256, half, N), dim3(256), 0, (hipStream_t)stream,
+                     feats, mask, out, half, ldt, mask_act);
+  return launched("ps_complex_mask_f32");
+}
+
+extern "C" int ps_istft_ola_f32(const float* frames, const float* window, float* out, int N, int n_fft, int hop,
+                                int T, int ldt, int out_mode, void* stream) {
+  if (!frames || !window || !out || N <= 0 || n_fft <= 0 || hop <= 0 || T <= 0 || ldt < T ||
+      out_mode < PS_OUT_CLAMP || out_mode > PS_OUT_NONE) {
+    set_error("ps_istft_ola_f32: bad argument (N=%d n_fft=%d hop=%d T=%d)", N, n_fft, hop, T);
+    return PS_E_INVALID;
+  }
+  const int Lout = (T - 1) * hop + n_fft;
+  LaunchTimer timer("istft_ola", (hipStream_t)stream);
+  hipLaunchKernelGGL(istft_ola_kernel, dim3((Lout + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, frames,
+                     window, out, n_fft, hop, T, ldt, out_mode);
+  return launched("ps_istft_ola_f32");
+}

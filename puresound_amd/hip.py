@@ -80,6 +80,42 @@ def free_decode(feats: torch.Tensor, t: int, w: torch.Tensor, hop: int, mask: Op
     return out
 
 
+def frame(wav: torch.Tensor, win: int, hop: int) -> tuple[torch.Tensor, int]:
+    """wav [N,L] -> (frames padded [N,win,ldt], T): frames[n][k][t] = wav[n][t*hop+k]."""
+    require_device(wav, "frame")
+    wav = wav.contiguous()
+    n, length = wav.shape
+    if length < win:
+        raise RuntimeError(f"frame: input length {length} is shorter than the window {win}")
+    t = (length - win) // hop + 1
+    ldt = padded_frames(t)
+    out = torch.empty(n, win, ldt, dtype=torch.float32, device=wav.device)
+    check(lib().ps_frame_f32(ptr(wav), ptr(out), n, length, win, hop, t, ldt, stream_ptr(wav.device)), "ps_frame_f32")
+    return out, t
+
+
+def complex_mask(feats: torch.Tensor, mask: torch.Tensor, mask_act: str = "linear") -> torch.Tensor:
+    """[re;im] channel halves, padded [N,2H,ldt] x mask [N,2H,ldt] -> complex product, same layout."""
+    require_device(feats, "complex_mask")
+    n, c2, ldt = feats.shape
+    if c2 % 2 or mask.shape != feats.shape:
+        raise RuntimeError("complex_mask: feats and mask must be [N, 2*half, ldt] with equal shapes")
+    out = torch.empty_like(feats)
+    check(lib().ps_complex_mask_f32(ptr(feats), ptr(mask), ptr(out), n, c2 // 2, ldt, _abi.PS_ACT[mask_act],
+                                    stream_ptr(feats.device)), "ps_complex_mask_f32")
+    return out
+
+
+def istft_ola(frames: torch.Tensor, t: int, window: torch.Tensor, hop: int, out_mode: str = "none") -> torch.Tensor:
+    """synthesis frames padded [N,n_fft,ldt] -> waveform [N,(T-1)*hop+n_fft] (window, /n_fft, OLA, /window-sum)."""
+    require_device(frames, "istft_ola")
+    n, n_fft, ldt = frames.shape
+    out = torch.empty(n, (t - 1) * hop + n_fft, dtype=torch.float32, device=frames.device)
+    check(lib().ps_istft_ola_f32(ptr(frames), ptr(window), ptr(out), n, n_fft, hop, t, ldt, _abi.PS_OUT[out_mode],
+                                 stream_ptr(frames.device)), "ps_istft_ola_f32")
+    return out
+
+
 def make_prologue(norm: int = 0, prelu: bool = False, stats: Optional[torch.Tensor] = None, count: float = 0.0,
                   eps: float = 1e-8, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
                   slope: Optional[torch.Tensor] = None) -> Prologue:

@@ -147,14 +147,26 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         out_mode = self.output_constraint.lower()
         if out_mode not in ("linear", "sigmoid"):
             raise NameError("Non support type.")  # base_nn.py:421-422
-        if isinstance(self.encoder, ConvEncDec):
-            raise NotImplementedError("STFT encoder (ConvEncDec): HIP kernels are the next hot-path row")
-        if not isinstance(self.encoder, FreeEncDec) or pairing != "real":
+        stft = isinstance(self.encoder, ConvEncDec)
+        if stft:
+            if pairing != "complex":
+                raise NotImplementedError("HIP inference path with an STFT encoder: (complex, complex) masks")
+        elif not isinstance(self.encoder, FreeEncDec) or pairing != "real":
             raise NotImplementedError("HIP inference path: FreeEncDec encoder with (real, real) masks")
         if not isinstance(self.masker, ConvTasNet):
             raise NotImplementedError(f"HIP inference path: ConvTasNet masker (got {type(self.masker).__name__})")
         if enroll is not None or self.speaker_net is not None or self.embedding_free_tse:
             raise NotImplementedError("speaker branch (BASELINE config 3) is not on the HIP path yet")
+
+        if stft:
+            # _get_feature (STFT branch, base_nn.py:337-345) -> masker -> get_mask + complex apply_tf_masks
+            # (:56-61) -> _get_waveform (:380-395, zero DC re-inserted = DC columns left out of the synthesis
+            # weight) -> ConvSTFT.inverse -> output constraint
+            enc = self.encoder.encoder
+            feats, t = enc.encode_padded(noisy.contiguous(), self.drop_first_bin)
+            mask = self.masker.forward_padded(feats, t)
+            enh = hip.complex_mask(feats, mask, mask_act)
+            return enc.decode_padded(enh, t, self.drop_first_bin, out_mode)
 
         def run(part: torch.Tensor, lane: int, out: Optional[torch.Tensor]) -> torch.Tensor:
             feats, t = self.encoder.encode_padded(part)                # _get_feature, base_nn.py:319-345

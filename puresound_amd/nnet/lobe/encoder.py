@@ -1,8 +1,9 @@
 """Encoder / decoder filterbanks (mirror of puresound/nnet/lobe/encoder.py:16-183, 275-456).
 
-FreeEncDec runs on ps_free_encode_f32 / ps_free_decode_f32.  ConvEncDec / ConvSTFT carry the
-reference's parameters and buffers (wsin, wcos, kernel_{sin,cos}_inv, window_mask) under the same
-state_dict keys; their kernels are the next row of the hot-path table.
+FreeEncDec runs on ps_free_encode_f32 / ps_free_decode_f32.  ConvEncDec / ConvSTFT carry the reference's
+parameters and buffers (wsin, wcos, kernel_{sin,cos}_inv, window_mask) under the same state_dict keys; both
+transforms are dense products against those (trainable) tables on ps_conv1x1_f32, framed by ps_frame_f32 and
+finished by ps_istft_ola_f32.
 """
 import math
 from typing import Optional
@@ -97,14 +98,86 @@ class ConvSTFT(nn.Module):
             self.register_buffer("wcos", wcos)
         self.register_buffer("window_mask", window_mask.unsqueeze(0).unsqueeze(-1))
 
+    # -- kernel-side plans (rebuilt when a table changes) -----------------------------------------------
+    def _sig(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def _analysis_plan(self, drop_first_bin: bool):
+        """Packed weight of the analysis product in the wrapper's channel order [re bins ; im bins]:
+        re = conv(x, wcos), im = -conv(x, wsin) (encoder.py:370-382), optionally without the DC bin
+        (base_nn.py:341-345)."""
+        key = ("a", drop_first_bin, self._sig())
+        if getattr(self, "_plan_a", None) is None or self._plan_a[0] != key:
+            lo = 1 if drop_first_bin else 0
+            bins = self.freq_bins if self.freq_bins is not None else self.wcos.shape[0]
+            w = torch.cat([self.wcos.detach()[lo:bins, 0, :], -self.wsin.detach()[lo:bins, 0, :]], dim=0).float()
+            self._plan_a = (key, hip.pack_wt(w), w.shape[0])
+        return self._plan_a[1], self._plan_a[2]
+
+    def _synthesis_plan(self, drop_first_bin: bool):
+        """Packed weight of the synthesis product with the Hermitian extension (extend_fbins, stft.py:118-125)
+        folded in: out[s] = sum_f re[f]*(Kc[s][f] + Kc[s][N-f]) - im[f]*(Ks[s][f] - Ks[s][N-f]), the mirrored
+        terms only for 0 < f < N/2 (encoder.py:419-433); input channels [re bins ; im bins]."""
+        key = ("s", drop_first_bin, self._sig())
+        if getattr(self, "_plan_s", None) is None or self._plan_s[0] != key:
+            kc = self.kernel_cos_inv.detach()[:, 0, :, 0].float()  # [out sample s][bin h], h = 0..N-1
+            ks = self.kernel_sin_inv.detach()[:, 0, :, 0].float()
+            n = self.n_fft
+            f = torch.arange(n // 2 + 1, device=kc.device)
+            mirror = ((f > 0) & (f < n // 2)).float().unsqueeze(0)
+            mf = (n - f) % n
+            wre = kc[:, f] + mirror * kc[:, mf]
+            wim = -(ks[:, f] - mirror * ks[:, mf])
+            lo = 1 if drop_first_bin else 0
+            w = torch.cat([wre[:, lo:], wim[:, lo:]], dim=1).contiguous()  # [n_fft, 2*bins]
+            self._plan_s = (key, hip.pack_wt(w), self.window_mask.detach().flatten().float().contiguous())
+        return self._plan_s[1], self._plan_s[2]
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_plan_a", None)
+        state.pop("_plan_s", None)
+        return state
+
+    # -- padded-layout entry points used by the fused wrapper ------------------------------------------
+    def encode_padded(self, x: torch.Tensor, drop_first_bin: bool):
+        """[N,L] -> ([re;im] channel layout, padded [N,2*bins,ldt], T)."""
+        hip.require_device(x, "ConvSTFT.forward")
+        frames, t = hip.frame(x, self.n_fft, self.stride)
+        wt, m = self._analysis_plan(drop_first_bin)
+        y, _ = hip.conv1x1(frames, t, wt, m, out=torch.empty(x.shape[0], m, frames.shape[-1], device=x.device))
+        return y, t
+
+    def decode_padded(self, spec_pad: torch.Tensor, t: int, drop_first_bin: bool, out_mode: str = "none"):
+        """[re;im] channel layout padded [N,2*bins,ldt] -> waveform [N,(T-1)*hop+n_fft]."""
+        if not hasattr(self, "kernel_sin_inv") or not hasattr(self, "kernel_cos_inv"):
+            raise NameError("Please activate the iSTFT module by setting `iSTFT=True` if you want to use `inverse`")
+        wt, window = self._synthesis_plan(drop_first_bin)
+        frames, _ = hip.conv1x1(spec_pad, t, wt, self.n_fft,
+                                out=torch.empty(spec_pad.shape[0], self.n_fft, spec_pad.shape[-1],
+                                                device=spec_pad.device))
+        return hip.istft_ola(frames, t, window, self.stride, out_mode)
+
+    # -- reference API ----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("ConvSTFT.forward: the conv-STFT HIP kernel is the next hot-path row")
+        """[N,1,L] -> [N,F,T,2] = stack(real, -imag) (encoder.py:358-391)."""
+        if self.output_format != "Complex":
+            raise NotImplementedError("only output_format='Complex' is on the HIP path")
+        y, t = self.encode_padded(x[:, 0, :] if x.dim() == 3 else x, False)
+        bins = y.shape[1] // 2
+        y = hip.unpad_rows(y, t)
+        return torch.stack((y[:, :bins], y[:, bins:]), dim=-1)
 
     def inverse(self, X: torch.Tensor, refresh_win: bool = True) -> torch.Tensor:
+        """[N,F,T,2] -> [N,L] (encoder.py:393-456)."""
         if not hasattr(self, "kernel_sin_inv") or not hasattr(self, "kernel_cos_inv"):
             raise NameError("Please activate the iSTFT module by setting `iSTFT=True` if you want to use `inverse`")
         assert X.dim() == 4, "Inverse iSTFT only works for complex number (batch, freq_bins, timesteps, 2)."
-        raise NotImplementedError("ConvSTFT.inverse: the iSTFT HIP kernel is the next hot-path row")
+        if self.output_format != "Complex":
+            raise NotImplementedError("Inverse only support complex input")
+        hip.require_device(X, "ConvSTFT.inverse")
+        spec = torch.cat((X[..., 0], X[..., 1]), dim=1).contiguous()
+        return self.decode_padded(hip.pad_rows(spec), X.shape[2], False)
 
 
 class ConvEncDec(nn.Module):

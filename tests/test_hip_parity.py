@@ -251,6 +251,67 @@ def test_wrapper_inference_matches_reference_golden(PA, dev, golden_dir, name):
     assert rel_max(pre.cpu().numpy(), g["wav_preclamp"]) < TOL
 
 
+def edge_ok(a, b, rtol=1e-3):
+    return bool(np.all(np.abs(a - b) <= rtol * np.maximum(np.abs(b), 1.0)))
+
+
+@pytest.mark.parametrize("name", ["tiny_stft", "tiny_stft_keepdc", "cfg1_short", "cfg1_full"])
+def test_stft_wrapper_matches_reference_golden(PA, dev, golden_dir, name):
+    """STFT encoder + complex masks + iSTFT decoder (BASELINE config 1 family).  The first/last 16 samples are
+    divided by a window sum as small as 1.4e-9 and are compared element-relative."""
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    noisy = det_wave(c["seed"], c["B"], c["L"])
+    wav = model.inference(noisy.to(dev)).cpu().numpy()
+    assert wav.shape == g["wav"].shape
+    assert rel_max(wav[:, 16:-16], g["wav"][:, 16:-16]) < TOL
+    assert np.all(wav[:, 0] == 0)  # window sum 0 at sample 0: never divided
+    enc = model.encoder.encoder
+    feats, t = enc.encode_padded(noisy.to(dev), model.drop_first_bin)
+    mask = model.masker.forward_padded(feats, t)
+    pre = enc.decode_padded(H_complex(feats, mask), t, model.drop_first_bin, "none").cpu().numpy()
+    assert rel_max(pre[:, 16:-16], g["wav_preclamp"][:, 16:-16]) < TOL
+    assert edge_ok(pre, g["wav_preclamp"])
+    if "feats_sub" in g:
+        assert rel_max(feats[..., :t][:, ::7, ::5].cpu().numpy(), g["feats_sub"]) < 1e-5
+        assert rel_max(mask[..., :t][:, ::7, ::5].cpu().numpy(), g["mask_sub"]) < TOL
+
+
+def H_complex(feats, mask):
+    from puresound_amd import hip
+    return hip.complex_mask(feats, mask, "linear")
+
+
+def test_stft_module_level_matches_reference_golden(PA, dev, golden_dir):
+    name = "enc_stft"
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    wav = det_wave(c["seed"], c["B"], c["L"]).to(dev)
+    feats = model(wav)
+    assert feats.shape == g["feats"].shape
+    assert rel_max(feats.cpu().numpy(), g["feats"]) < 1e-5
+    rec = model.inverse(torch.tensor(g["feats"]).to(dev)).cpu().numpy()
+    assert rec.shape == g["rec"].shape
+    assert rel_max(rec[:, 16:-16], g["rec"][:, 16:-16]) < TOL and edge_ok(rec, g["rec"])
+
+
+def test_complex_mask_and_frame_kernels(H, dev):
+    x, m = _rand((2, 12, 70), 41), _rand((2, 12, 70), 42)
+    out = H.complex_mask(H.pad_rows(x.to(dev)), H.pad_rows(m.to(dev)), "relu")[..., :70].cpu()
+    ref = O.apply_tf_masks(x, O.get_mask(m, "relu"), "complex", "complex")
+    assert rel_max(out[:, :6].numpy(), ref[..., 0].numpy()) < 1e-6
+    assert rel_max(out[:, 6:].numpy(), ref[..., 1].numpy()) < 1e-6
+    wav = _rand((2, 333), 43)
+    fr, t = H.frame(wav.to(dev), 20, 6)
+    assert torch.equal(fr[..., :t].cpu(), O.frame(wav, 20, 6).transpose(1, 2))
+
+
 def test_input_is_not_modified_and_result_is_deterministic(PA, dev):
     model = cases.build(PA.NS, "tiny_free").eval()
     model.load_state_dict(det_state_dict(model))
