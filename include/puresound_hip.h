@@ -53,7 +53,7 @@ const char* ps_last_error(void);
  * library is bracketed by hipEvents on the launch stream.  ps_profile_enable(1) clears old records.
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
- * "unpad_rows", "frame", "complex_mask", "istft_ola").  Not for use under stream capture. */
+ * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
 int ps_debug_buffer(void* device_buffer); /* 6 x u64 per conv1x1 workgroup: s_memtime stamps + HW ids */
@@ -132,6 +132,8 @@ typedef struct ps_prologue {
   const float* gamma;    /* [K] gain  (PS_NORM_GLOBAL) or folded scale (PS_NORM_AFFINE) */
   const float* beta;     /* [K] bias  (PS_NORM_GLOBAL) or folded shift (PS_NORM_AFFINE) */
   const float* slope;    /* [1] PReLU slope */
+  int pre_relu;          /* 1: ReLU BEFORE the norm (AttentiveStatisticsPooling.tdnn: Conv -> ReLU -> BatchNorm) */
+  int post_tanh;         /* 1: tanh after the norm (pooling.py:82,108) instead of / in addition to PReLU */
 } ps_prologue;
 
 int ps_conv1x1_f32(const float* x, const float* wt, float* y, int N, int K, int M, int T, int ldt,
@@ -157,6 +159,16 @@ int ps_dwconv_f32(const float* x, const float* w, const float* b, float* y, int 
  * ------------------------------------------------------------------------------------------- */
 int ps_embed_bias_f32(const float* dvec, const float* w_embed, float* bias_n, int N, int E, int M,
                       int normalize, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attentive statistics pooling tail (AttentiveStatisticsPooling.forward with lengths=None,
+ * lobe/pooling.py:109-126): per (utterance, channel) softmax of the attention logits over frames, then the
+ * attention-weighted mean and standard deviation of x:
+ *   a = softmax_t(logits[n][c][:T]);  mean = sum a*x;  std = sqrt(max(sum a*(x-mean)^2, eps))
+ *   out[n][c] = mean, out[n][C + c] = std          (the reference's cat((mean, std), 1).unsqueeze(2))
+ * ------------------------------------------------------------------------------------------- */
+int ps_attn_stats_pool_f32(const float* logits, const float* x, float* out, int N, int C, int T, int ldt,
+                           float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One "normal" TCN block and the whole Conv-TasNet masker (conv_tasnet.py:67-90, 338-359).

@@ -25,7 +25,8 @@ _vp = C.c_void_p
 
 class Prologue(C.Structure):
     _fields_ = [("norm", C.c_int), ("prelu", C.c_int), ("stats", _vp), ("parts", C.c_int),
-                ("count", C.c_double), ("eps", C.c_float), ("gamma", _vp), ("beta", _vp), ("slope", _vp)]
+                ("count", C.c_double), ("eps", C.c_float), ("gamma", _vp), ("beta", _vp), ("slope", _vp),
+                ("pre_relu", C.c_int), ("post_tanh", C.c_int)]
 
 
 class TcnBlock(C.Structure):
@@ -59,6 +60,7 @@ SIGNATURES = {
     "ps_istft_ola_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_conv1x1_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 5 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
     "ps_dwconv_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp]),
+    "ps_attn_stats_pool_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
     "ps_embed_bias_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ps_conv_tasnet_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "ps_conv_tasnet_f32": (C.c_int, [C.POINTER(TcnBlock), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,

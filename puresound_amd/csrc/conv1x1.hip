@@ -131,6 +131,7 @@ __device__ __forceinline__ void conv1x1_body(const Conv1x1Args& a, float* lds) {
   const bool has_norm = a.pro.norm != PS_NORM_NONE;  // kernel-uniform
   constexpr bool has_res = W > 0;
   const float slope = (TR && a.pro.prelu) ? a.pro.slope[0] : 1.f;
+  const bool pre_relu = TR && a.pro.pre_relu, post_tanh = TR && a.pro.post_tanh;  // kernel-uniform
   const int m_end = a.tiles_m * BM, t_end = a.tiles_t * BT;
 
   // ---- descriptors: every global access is SGPR-base + 32-bit offsets; out-of-range reads return 0.0f and
@@ -216,11 +217,25 @@ __device__ __forceinline__ void conv1x1_body(const Conv1x1Args& a, float* lds) {
     if (bl_left <= 0) return;  // uniform
     --bl_left;
     f32x4 v0 = __builtin_bit_cast(f32x4, rb0), v1 = __builtin_bit_cast(f32x4, rb1);
+    if (pre_relu) {  // kernel-uniform
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v0[e] = fmaxf(v0[e], 0.f);
+        v1[e] = fmaxf(v1[e], 0.f);
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float u0 = v0[e] * b_sc + b_sh, u1 = v1[e] * b_sc + b_sh;
       v0[e] = u0 >= 0.f ? u0 : slope * u0;
       v1[e] = u1 >= 0.f ? u1 : slope * u1;
+    }
+    if (post_tanh) {  // kernel-uniform; channels >= K have sc = sh = 0 -> tanh(0) = 0
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v0[e] = tanhf(v0[e]);
+        v1[e] = tanhf(v1[e]);
+      }
     }
     float* dst = lds + slot_next * SLOT + SLOT_A + b_row * BT + b_col;
     *reinterpret_cast<f32x4*>(dst) = v0;
@@ -581,7 +596,7 @@ extern "C" int ps_conv1x1_f32(const float* x, const float* wt, float* y, int N, 
     set_error("ps_conv1x1_f32: bias pointers must be 4-byte aligned");
     return PS_E_ALIGN;
   }
-  if (K > KMAX && pro && (pro->norm != PS_NORM_NONE || pro->prelu)) {
+  if (K > KMAX && pro && (pro->norm != PS_NORM_NONE || pro->prelu || pro->pre_relu || pro->post_tanh)) {
     set_error("ps_conv1x1_f32: K=%d exceeds the %d input channels the prologue keeps scale/shift tables for", K,
               KMAX);
     return PS_E_UNSUPPORTED;
@@ -640,7 +655,7 @@ extern "C" int ps_conv1x1_f32(const float* x, const float* wt, float* y, int N, 
   // test hook (ps_debug_flags bits 8..23): cap the persistent grid so that a workgroup's run spans many
   // tiles / utterances even on small problems
   if ((g_debug_flags >> 8) & 0xffff) grid = grid < ((g_debug_flags >> 8) & 0xffff) ? grid : ((g_debug_flags >> 8) & 0xffff);
-  const bool tr = a.pro.norm != PS_NORM_NONE || a.pro.prelu;
+  const bool tr = a.pro.norm != PS_NORM_NONE || a.pro.prelu || a.pro.pre_relu || a.pro.post_tanh;
   {
     LaunchTimer timer("conv1x1", (hipStream_t)stream);
     const dim3 gr(grid), bl(256);

@@ -1,0 +1,84 @@
+// Attentive statistics pooling tail (AttentiveStatisticsPooling, lobe/pooling.py:109-126 of mcw519/PureSound):
+// softmax over frames of the attention logits, attention-weighted mean and standard deviation of x.
+// One workgroup per (utterance, channel) row; the row (<= 16 KiB at T = 3999) is streamed three times
+// (max, normaliser + mean, variance) and stays in L1/L2 after the first pass.  Two-pass variance as in the
+// reference (sum a*(x-mean)^2), not E[x^2]-mean^2.
+#include "ps_common.h"
+
+namespace ps {
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  v = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  return v;
+}
+
+__global__ __launch_bounds__(256) void attn_stats_pool_kernel(const float* __restrict__ logits,
+                                                              const float* __restrict__ x, float* __restrict__ out,
+                                                              int C, int T, int ldt, float eps) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, n = blockIdx.y;
+  const float* lr = logits + ((size_t)n * C + c) * ldt;
+  const float* xr = x + ((size_t)n * C + c) * ldt;
+  float m = -INFINITY;
+  for (int t = threadIdx.x; t < T; t += 256) m = fmaxf(m, lr[t]);
+  m = block_max(m, red);
+  float s = 0.f, s1 = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float e = expf(lr[t] - m);
+    s += e;
+    s1 += e * xr[t];
+  }
+  s = block_sum(s, red);
+  s1 = block_sum(s1, red);
+  const float mean = s1 / s;
+  float s2 = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float e = expf(lr[t] - m);
+    const float d = xr[t] - mean;
+    s2 += e * d * d;
+  }
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    out[(size_t)n * 2 * C + c] = mean;
+    out[(size_t)n * 2 * C + C + c] = sqrtf(fmaxf(s2 / s, eps));
+  }
+}
+
+}  // namespace ps
+
+extern "C" int ps_attn_stats_pool_f32(const float* logits, const float* x, float* out, int N, int C, int T, int ldt,
+                                      float eps, void* stream) {
+  using namespace ps;
+  if (!logits || !x || !out || N <= 0 || C <= 0 || T <= 0 || ldt < T || N > 65535) {
+    set_error("ps_attn_stats_pool_f32: bad argument (N=%d C=%d T=%d ldt=%d)", N, C, T, ldt);
+    return PS_E_INVALID;
+  }
+  {
+    LaunchTimer timer("attn_stats_pool", (hipStream_t)stream);
+    hipLaunchKernelGGL(attn_stats_pool_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, logits, x, out, C, T,
+                       ldt, eps);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("ps_attn_stats_pool_f32: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}

@@ -118,8 +118,9 @@ def istft_ola(frames: torch.Tensor, t: int, window: torch.Tensor, hop: int, out_
 
 def make_prologue(norm: int = 0, prelu: bool = False, stats: Optional[torch.Tensor] = None, count: float = 0.0,
                   eps: float = 1e-8, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
-                  slope: Optional[torch.Tensor] = None) -> Prologue:
+                  slope: Optional[torch.Tensor] = None, pre_relu: bool = False, post_tanh: bool = False) -> Prologue:
     p = Prologue()
+    p.pre_relu, p.post_tanh = int(pre_relu), int(post_tanh)
     p.norm, p.prelu = norm, int(prelu)
     p.stats = ptr(stats)
     p.parts = 0 if stats is None else stats.shape[1]
@@ -160,6 +161,16 @@ def dwconv(x: torch.Tensor, t: int, w: torch.Tensor, b: Optional[torch.Tensor], 
                               C.byref(pro) if pro is not None else None, ptr(stats), stream_ptr(x.device)),
           "ps_dwconv_f32")
     return y, stats
+
+
+def attn_stats_pool(logits: torch.Tensor, x: torch.Tensor, t: int, eps: float = 1e-12) -> torch.Tensor:
+    """attention logits / features padded [N,C,ldt] -> [N,2C] = cat(weighted mean, weighted std)."""
+    require_device(x, "attn_stats_pool")
+    n, c, ldt = x.shape
+    out = torch.empty(n, 2 * c, dtype=torch.float32, device=x.device)
+    check(lib().ps_attn_stats_pool_f32(ptr(logits), ptr(x), ptr(out), n, c, t, ldt, float(eps),
+                                       stream_ptr(x.device)), "ps_attn_stats_pool_f32")
+    return out
 
 
 def embed_bias(dvec: torch.Tensor, w_embed: torch.Tensor, normalize: bool) -> torch.Tensor:

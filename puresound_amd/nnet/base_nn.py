@@ -12,8 +12,10 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from .conv_tasnet import ConvTasNet
+from .._abi import TcnBlock
+from .conv_tasnet import TCN, ConvTasNet
 from .lobe.encoder import ConvEncDec, FreeEncDec
+from .lobe.pooling import AttentiveStatisticsPooling
 
 _MASK_ACTS = ("linear", "relu", "sigmoid")
 _STREAMS = {}
@@ -155,8 +157,12 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             raise NotImplementedError("HIP inference path: FreeEncDec encoder with (real, real) masks")
         if not isinstance(self.masker, ConvTasNet):
             raise NotImplementedError(f"HIP inference path: ConvTasNet masker (got {type(self.masker).__name__})")
-        if enroll is not None or self.speaker_net is not None or self.embedding_free_tse:
-            raise NotImplementedError("speaker branch (BASELINE config 3) is not on the HIP path yet")
+        if self.embedding_free_tse:
+            raise NotImplementedError("embedding_free_tse (DPRNN init-state mode) is not on the HIP path yet")
+        if enroll is not None:
+            hip.require_device(enroll, "SoTaskWrapModule.inference")
+            if stft or self.encoder_spk is not None or self.speaker_net is None:
+                raise NotImplementedError("HIP speaker branch: shared FreeEncDec encoder + speaker_net")
 
         if stft:
             # _get_feature (STFT branch, base_nn.py:337-345) -> masker -> get_mask + complex apply_tf_masks
@@ -168,9 +174,13 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             enh = hip.complex_mask(feats, mask, mask_act)
             return enc.decode_padded(enh, t, self.drop_first_bin, out_mode)
 
-        def run(part: torch.Tensor, lane: int, out: Optional[torch.Tensor]) -> torch.Tensor:
+        def run(part: torch.Tensor, lane: int, out: Optional[torch.Tensor],
+                part_enroll: Optional[torch.Tensor] = None) -> torch.Tensor:
+            dvec = None
+            if part_enroll is not None:                                # base_nn.py:347-350, 697-705
+                dvec = self._speaker_embedding(part_enroll, lane)
             feats, t = self.encoder.encode_padded(part)                # _get_feature, base_nn.py:319-345
-            mask = self.masker.forward_padded(feats, t, lane=lane)     # base_nn.py:709-714
+            mask = self.masker.forward_padded(feats, t, dvec, lane=lane)  # base_nn.py:709-714
             # get_mask + apply_tf_masks + _get_waveform + _wav_output_constrain, base_nn.py:716-721
             return self.encoder.decode_padded(feats, t, mask, mask_act, out_mode, out)
 
@@ -179,9 +189,12 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         # MFMA-bound GEMMs.  Results are bit-identical to the single-stream run.
         n = noisy.shape[0]
         lanes = min(int(getattr(self, "hip_streams", 2)), n // 2) if n >= 4 else 1
+        if enroll is not None and enroll.shape[0] != n:
+            raise RuntimeError("inference: noisy and enroll must have the same batch size")
         if lanes <= 1:
-            return run(noisy.contiguous(), 0, None)
+            return run(noisy.contiguous(), 0, None, None if enroll is None else enroll.contiguous())
         noisy = noisy.contiguous()
+        enroll = None if enroll is None else enroll.contiguous()
         dev = noisy.device
         win, hop = self.encoder.win_length, self.encoder.hop_length
         t_frames = (noisy.shape[1] - win) // hop + 1
@@ -192,14 +205,48 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         for i, s in enumerate(pool):
             s.wait_stream(cur)
             with torch.cuda.stream(s):
-                run(noisy[bounds[i]:bounds[i + 1]], i, out[bounds[i]:bounds[i + 1]])
+                run(noisy[bounds[i]:bounds[i + 1]], i, out[bounds[i]:bounds[i + 1]],
+                    None if enroll is None else enroll[bounds[i]:bounds[i + 1]])
         for s in pool:
             cur.wait_stream(s)
         return out
 
+    # -- speaker branch (base_nn.py:697-705, 724-738) ---------------------------------------------------
+    def _speaker_layers(self):
+        """Split speaker_net into (leading plain TCN blocks, pooling, trailing 1x1 conv) -- the layout of every
+        Conv-TasNet TSE preset (egs/tse/model.py:118-135).  Anything else has no HIP path yet."""
+        layers = list(self.speaker_net) if isinstance(self.speaker_net, (nn.ModuleList, nn.Sequential)) else None
+        if layers is None:
+            raise NotImplementedError("HIP speaker branch: speaker_net must be a ModuleList / Sequential")
+        tcns = []
+        while layers and isinstance(layers[0], TCN):
+            if layers[0].emb_dim != 0:
+                raise NotImplementedError("HIP speaker branch: TCN blocks with their own embedding input")
+            tcns.append(layers.pop(0))
+        if len(layers) != 2 or not isinstance(layers[0], AttentiveStatisticsPooling) or \
+                not isinstance(layers[1], nn.Conv1d) or layers[1].kernel_size != (1,) or layers[1].bias is not None:
+            raise NotImplementedError("HIP speaker branch: TCN* -> AttentiveStatisticsPooling -> Conv1d(k=1, no bias)")
+        return tcns, layers[0], layers[1]
+
+    def _speaker_embedding(self, enroll: torch.Tensor, lane: int = 0) -> torch.Tensor:
+        """enroll [N,L'] -> dvec [N,E]."""
+        tcns, pool, proj = self._speaker_layers()
+        x, t = self.encoder.encode_padded(enroll)
+        if tcns:
+            plans = [m.plan(x.device) for m in tcns]
+            blocks = (TcnBlock * len(plans))(*[p["block"] for p in plans])
+            x = hip.conv_tasnet(blocks, len(plans), x, t, tcns[0].in_channels, tcns[0].hid_channels, None, False)
+        pooled = pool.forward_padded(x, t)                                       # [N, 2C]
+        w = proj.weight.detach()[:, :, 0].float().contiguous()                   # [E, 2C]
+        return hip.embed_bias(pooled, w, False)                                  # Conv1d(2C -> E, 1, bias=False)
+
     @torch.no_grad()
     def inference_tse_embedding(self, enroll: Optional[torch.Tensor] = None) -> torch.Tensor:
-        raise NotImplementedError("speaker branch (BASELINE config 3) is not on the HIP path yet")
+        """enroll [N,L'] -> [N,E,1], as the reference returns it (base_nn.py:724-738: not squeezed)."""
+        hip.require_device(enroll, "SoTaskWrapModule.inference_tse_embedding")
+        if self.encoder_spk is not None or not isinstance(self.encoder, FreeEncDec):
+            raise NotImplementedError("HIP speaker branch: shared FreeEncDec encoder")
+        return self._speaker_embedding(enroll.contiguous()).unsqueeze(2)
 
     def _verbose(self):
         """The reference probes look-ahead / receptive field with two 10-s CPU inferences and leaves the

@@ -1,18 +1,65 @@
-"""Attentive statistics pooling (mirror of puresound/nnet/lobe/pooling.py:58-126): parameters only for
-now -- the speaker branch (BASELINE config 3) is a later row of the hot-path table."""
+"""Attentive statistics pooling on the HIP path (mirror of puresound/nnet/lobe/pooling.py:58-126).
+
+tdnn (1x1 conv -> ReLU -> BatchNorm1d) and the attention conv run on ps_conv1x1_f32 -- the ReLU, the folded
+eval BatchNorm and the tanh are the second GEMM's prologue -- and ps_attn_stats_pool_f32 does the softmax over
+frames and the weighted mean / std.  `lengths` (ragged batches) and `return_weight` are not on the HIP path.
+"""
 import torch
 import torch.nn as nn
+
+from ... import hip
+from ..._abi import PS_NORM_AFFINE
 
 
 class AttentiveStatisticsPooling(nn.Module):
     def __init__(self, channels, attention_channels=128):
         super().__init__()
         self.eps = 1e-12
+        self.channels, self.attention_channels = channels, attention_channels
         self.tdnn = nn.Sequential(
             nn.Conv1d(in_channels=channels, out_channels=attention_channels, kernel_size=1, dilation=1),
             nn.ReLU(), nn.BatchNorm1d(attention_channels))
         self.tanh = nn.Tanh()
         self.conv = nn.Conv1d(in_channels=attention_channels, out_channels=channels, kernel_size=1)
+        self._plan = None
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_plan"] = None
+        return state
+
+    def _get_plan(self, device):
+        sig = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers())) + \
+            (self.training, str(device))
+        if self._plan is None or self._plan["sig"] != sig:
+            bn = self.tdnn[2]
+            if bn.training:
+                raise RuntimeError("AttentiveStatisticsPooling: BatchNorm1d must be in eval() mode on the HIP path")
+            f32 = dict(dtype=torch.float32, device=device)
+            scale = (bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)).to(**f32).contiguous()
+            shift = (bn.bias.detach().to(**f32) - bn.running_mean.detach().to(**f32) * scale).contiguous()
+            self._plan = dict(sig=sig,
+                              w1=hip.pack_wt(self.tdnn[0].weight.detach().to(**f32)),
+                              b1=self.tdnn[0].bias.detach().to(**f32).contiguous(),
+                              w2=hip.pack_wt(self.conv.weight.detach().to(**f32)),
+                              b2=self.conv.bias.detach().to(**f32).contiguous(), scale=scale, shift=shift)
+        return self._plan
+
+    def forward_padded(self, x_pad: torch.Tensor, t: int) -> torch.Tensor:
+        """padded [N,C,ldt] -> [N,2C] (mean ; std)."""
+        p = self._get_plan(x_pad.device)
+        n, _, ldt = x_pad.shape
+        h, _ = hip.conv1x1(x_pad, t, p["w1"], self.attention_channels, None, p["b1"],
+                           out=torch.empty(n, self.attention_channels, ldt, device=x_pad.device))
+        pro = hip.make_prologue(PS_NORM_AFFINE, False, None, 0.0, 0.0, p["scale"], p["shift"], None,
+                                pre_relu=True, post_tanh=True)
+        logits, _ = hip.conv1x1(h, t, p["w2"], self.channels, pro, p["b2"],
+                                out=torch.empty(n, self.channels, ldt, device=x_pad.device))
+        return hip.attn_stats_pool(logits, x_pad, t, self.eps)
 
     def forward(self, x: torch.Tensor, lengths=None, return_weight: bool = False):
-        raise NotImplementedError("AttentiveStatisticsPooling has no HIP kernel yet (speaker branch, config 3)")
+        """x [N,C,L] -> [N,2C,1] (pooling.py:87-126, lengths=None)."""
+        hip.require_device(x, "AttentiveStatisticsPooling.forward")
+        if lengths is not None or return_weight:
+            raise NotImplementedError("AttentiveStatisticsPooling on HIP: lengths / return_weight are not supported")
+        return self.forward_padded(hip.pad_rows(x), x.shape[-1]).unsqueeze(2)

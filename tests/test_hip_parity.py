@@ -251,6 +251,95 @@ def test_wrapper_inference_matches_reference_golden(PA, dev, golden_dir, name):
     assert rel_max(pre.cpu().numpy(), g["wav_preclamp"]) < TOL
 
 
+# ------------------------------------------------------------------------------------------------
+# speaker branch (BASELINE config 3): TCN x5 -> attentive statistics pooling -> 1x1 projection -> dvec
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,c,t", [(2, 24, 77), (3, 512, 249), (1, 40, 1500)])
+def test_attn_stats_pool_kernel(H, dev, n, c, t):
+    logits = _rand((n, c, t), 31, -3.0, 3.0)
+    x = _rand((n, c, t), 32)
+    a = torch.softmax(logits.double(), 2)
+    mean = (a * x.double()).sum(2)
+    std = torch.sqrt((a * (x.double() - mean.unsqueeze(2)) ** 2).sum(2).clamp(1e-12))
+    ref = torch.cat((mean, std), 1).float().numpy()
+    out = H.attn_stats_pool(H.pad_rows(logits.to(dev)), H.pad_rows(x.to(dev)), t)
+    assert out.shape == (n, 2 * c)
+    assert rel_max(out.cpu().numpy(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("n,k,m,t", [(2, 24, 12, 77), (2, 128, 512, 249)])
+def test_conv1x1_relu_affine_tanh_prologue(H, dev, n, k, m, t):
+    """tanh(BN(ReLU(x))) on load: the attention branch of AttentiveStatisticsPooling (lobe/pooling.py:109-112)."""
+    from puresound_amd import _abi
+    x = _rand((n, k, t), 41, -2.0, 2.0)
+    w, b = _rand((m, k), 42, -0.2, 0.2), _rand((m,), 43)
+    scale, shift = _rand((k,), 44, 0.5, 1.5), _rand((k,), 45, -0.3, 0.3)
+    ref = torch.matmul(w, torch.tanh(torch.relu(x) * scale.reshape(1, -1, 1) + shift.reshape(1, -1, 1)))
+    ref = ref + b.reshape(1, -1, 1)
+    sc_d, sh_d = scale.to(dev), shift.to(dev)
+    pro = H.make_prologue(_abi.PS_NORM_AFFINE, False, None, 0.0, 0.0, sc_d, sh_d, None, pre_relu=True, post_tanh=True)
+    y, _ = H.conv1x1(H.pad_rows(x.to(dev)), t, H.pack_wt(w.to(dev)), m, pro, b.to(dev))
+    torch.cuda.synchronize()
+    assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 2e-5
+
+
+def test_attentive_stats_pooling_module_matches_oracle(PA, dev):
+    from puresound_amd.nnet.lobe.pooling import AttentiveStatisticsPooling
+    pool = AttentiveStatisticsPooling(48, 16).eval()
+    sd = det_state_dict(pool)
+    sd["tdnn.2.running_var"] = sd["tdnn.2.running_var"].abs() + 0.5
+    pool.load_state_dict(sd)
+    pool.to(dev)
+    x = _rand((3, 48, 333), 51)
+    ref = O.attentive_stats_pooling(x, sd, "")
+    out = pool(x.to(dev))
+    assert out.shape == ref.shape == (3, 96, 1)
+    assert rel_max(out.cpu().numpy(), ref.numpy()) < 2e-5
+    with pytest.raises(NotImplementedError):
+        pool(x.to(dev), lengths=torch.ones(3))
+    with pytest.raises(RuntimeError):
+        pool.train()(x.to(dev))
+
+
+def test_tse_wrapper_matches_reference_golden(PA, dev, golden_dir):
+    name = "cfg3_short"
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name).eval()
+    sd = det_state_dict(model)
+    model.load_state_dict(sd)
+    model.to(dev)
+    assert model.overall_parameters == cases.PARAM_COUNTS[name]
+    noisy = det_wave(c["seed"], c["B"], c["L"])
+    enroll = det_wave(c["seed"] + 1, c["B"], c["L_enroll"])
+    dvec = model.inference_tse_embedding(enroll.to(dev))
+    assert dvec.shape == (c["B"], 192, 1)
+    assert rel_max(dvec[..., 0].cpu().numpy(), g["dvec"]) < TOL
+    wav = model.inference(noisy.to(dev), enroll.to(dev))
+    assert wav.shape == g["wav"].shape
+    assert rel_max(wav.cpu().numpy(), g["wav"]) < TOL
+    # pre-clamp waveform and the oracle's intermediate taps
+    taps = {}
+    O.inference(noisy, sd, cases.oracle_cfg(name), enroll, taps)
+    assert rel_max(dvec[..., 0].cpu().numpy(), taps["dvec"].numpy()) < TOL
+    feats, t = model.encoder.encode_padded(noisy.to(dev))
+    mask = model.masker.forward_padded(feats, t, dvec[..., 0])
+    pre = model.encoder.decode_padded(feats, t, mask, "relu", "none")
+    assert rel_max(pre.cpu().numpy(), g["wav_preclamp"]) < TOL
+    # enrolment of a different length than the mixture, and a 4-utterance batch over two streams
+    n4 = det_wave(5, 4, 4000)
+    e4 = det_wave(6, 4, 2500)
+    ref4 = O.inference(n4, sd, cases.oracle_cfg(name), e4)
+    out4 = model.inference(n4.to(dev), e4.to(dev))
+    assert rel_max(out4.cpu().numpy(), ref4.numpy()) < TOL
+    model.hip_streams = 1
+    assert torch.equal(model.inference(n4.to(dev), e4.to(dev)), out4)
+    with pytest.raises(RuntimeError):
+        model.inference(n4.to(dev))               # masker takes an embedding, none given
+    with pytest.raises(RuntimeError):
+        model.inference(n4.to(dev), e4[:2].to(dev))
+
+
 def edge_ok(a, b, rtol=1e-3):
     return bool(np.all(np.abs(a - b) <= rtol * np.maximum(np.abs(b), 1.0)))
 
