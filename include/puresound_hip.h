@@ -53,7 +53,8 @@ const char* ps_last_error(void);
  * library is bracketed by hipEvents on the launch stream.  ps_profile_enable(1) clears old records.
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
- * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool").  Not for use under stream capture. */
+ * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "chan_layernorm",
+ * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
 int ps_debug_buffer(void* device_buffer); /* 6 x u64 per conv1x1 workgroup: s_memtime stamps + HW ids */
@@ -169,6 +170,47 @@ int ps_embed_bias_f32(const float* dvec, const float* w_embed, float* bias_n, in
  * ------------------------------------------------------------------------------------------- */
 int ps_attn_stats_pool_f32(const float* logits, const float* x, float* out, int N, int C, int T, int ldt,
                            float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Recurrent maskers (DPRNN dprnn.py:111-191, SkiM skim.py:198-229,45-114,410-469, StreamingSkiM
+ * streaming/skim_inference.py:41-252).  They run on the same channel-major padded layout, so their Linear layers
+ * (LSTM input projections, proj, FiLM convs, output_fc) are ps_conv1x1_f32 calls; what is left is below.
+ *
+ * ps_lstm_f32: the recurrence of nn.LSTM(num_layers=1, batch_first=True), one or two directions.
+ *   gx    [N][D*4H][ldt]  W_ih x + b_ih + b_hh for every frame (rows: direction, then gates i,f,g,o, then unit)
+ *   whh_t [D][H][4H]      weight_hh_l0(_reverse) transposed
+ *   A sequence is (n, q), q < Q; its step s reads/writes frame q*q_stride + s*step_stride (direction 1 walks the
+ *   steps backwards):  intra-segment pass Q=S, q_stride=K, steps=K, step_stride=1;  inter-segment pass Q=K,
+ *   q_stride=1, steps=S, step_stride=K;  streaming step Q=streams, q_stride=1, steps=1.
+ *   c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c');  hout [N][D*H][ldt] gets h' at the step's frame.
+ *   States use the "state layout" [N][D*H][ldq], one frame per sequence: h0/c0 initial (NULL = zeros), h_last /
+ *   c_last final (NULL = not wanted; may alias h0/c0 when state_shift == 0).  state_shift = 1 starts flat sequence
+ *   b = n*Q+q from the state stored for b-1 and sequence 0 from zeros -- MemLSTM's causal hand-over including its
+ *   cross-utterance leak (skim.py:102-109).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* gx;
+  const float* whh_t;
+  const float* h0;
+  const float* c0;
+  float* hout;
+  float* h_last;
+  float* c_last;
+  int N, H, D, Q, q_stride, steps, step_stride, ldt, ldq, state_shift;
+} ps_lstm_args;
+int ps_lstm_f32(const ps_lstm_args* args, void* stream);
+
+/* y = [res +] [mul *] act( LN_C(x) * gamma + beta ): statistics over the C channels of each frame, biased two-pass
+ * variance, 1/sqrt(var + eps).  nn.LayerNorm(C) on [.., C] rows (eps 1e-5; dprnn.py:157,171, skim.py:85-98,226,
+ * FiLM's input norm lobe/trivial.py:160) and ChanLN (eps 1e-8, lobe/norm.py:37-50).  act: PReLU when prelu_slope
+ * is given (one shared slope), then sigmoid when `sigmoid` (Gate, lobe/trivial.py:75-104). */
+int ps_chan_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, const float* prelu_slope,
+                          int sigmoid, const float* mul, const float* res, float* y, int N, int C, int T, int ldt,
+                          void* stream);
+
+/* FiLM (lobe/trivial.py:162-167): y[n][c][t] = sb[n][c][t] * x[n][c][t] + sb[n][C + c][t]; sb [N][2C][ldt] is the
+ * output of cond_scale / cond_bias stacked into one 1x1 conv. */
+int ps_film_apply_f32(const float* x, const float* scale_bias, float* y, int N, int C, int T, int ldt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One "normal" TCN block and the whole Conv-TasNet masker (conv_tasnet.py:67-90, 338-359).

@@ -397,9 +397,16 @@ def inference(noisy: torch.Tensor, sd: SD, cfg: dict, enroll: Optional[torch.Ten
     """
     feats = encode_features(noisy, sd, cfg["encoder"])
     dvec = None
+    kind = cfg.get("masker_kind", "convtasnet")
     if enroll is not None:
-        dvec = speaker_embedding(encode_features(enroll, sd, cfg["encoder"]), sd, cfg["speaker_net"])
-    mask = conv_tasnet(feats, sd, "masker.", cfg["masker"], dvec, taps)
+        dvec = encode_features(enroll, sd, cfg["encoder"])
+        if not cfg["masker"].get("embedding_free_tse", False):      # base_nn.py:697-707
+            dvec = speaker_embedding(dvec, sd, cfg["speaker_net"])
+    if kind == "convtasnet":
+        mask = conv_tasnet(feats, sd, "masker.", cfg["masker"], dvec, taps)
+    else:
+        from . import dualpath_oracle as DP                          # recurrent maskers live in their own file
+        mask = {"dprnn": DP.dprnn, "skim": DP.skim}[kind](feats, sd, "masker.", cfg["masker"], dvec)
     mask = get_mask(mask, cfg.get("mask_constraint", "linear"))
     enh = apply_tf_masks(feats, mask, cfg.get("mask_type", "real"), cfg.get("f_type", "real"))
     wav = decode_waveform(enh, sd, cfg["encoder"])

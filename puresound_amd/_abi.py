@@ -29,6 +29,12 @@ class Prologue(C.Structure):
                 ("pre_relu", C.c_int), ("post_tanh", C.c_int)]
 
 
+class LstmArgs(C.Structure):
+    _fields_ = [("gx", _vp), ("whh_t", _vp), ("h0", _vp), ("c0", _vp), ("hout", _vp), ("h_last", _vp),
+                ("c_last", _vp)] + [(k, C.c_int) for k in ("N", "H", "D", "Q", "q_stride", "steps", "step_stride",
+                                                           "ldt", "ldq", "state_shift")]
+
+
 class TcnBlock(C.Structure):
     _fields_ = [("C", C.c_int), ("H", C.c_int), ("P", C.c_int), ("dilation", C.c_int), ("causal", C.c_int),
                 ("in_norm", C.c_int), ("dw_norm", C.c_int), ("pw_norm", C.c_int),
@@ -61,6 +67,9 @@ SIGNATURES = {
     "ps_conv1x1_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 5 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
     "ps_dwconv_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp]),
     "ps_attn_stats_pool_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "ps_lstm_f32": (C.c_int, [C.POINTER(LstmArgs), _vp]),
+    "ps_chan_layernorm_f32": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
+    "ps_film_apply_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
     "ps_embed_bias_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ps_conv_tasnet_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "ps_conv_tasnet_f32": (C.c_int, [C.POINTER(TcnBlock), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,

@@ -10,7 +10,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _abi
-from ._abi import Prologue, TcnBlock, check, lib, padded_frames, ptr, require_device, stream_ptr
+from ._abi import LstmArgs, Prologue, TcnBlock, check, lib, padded_frames, ptr, require_device, stream_ptr
 
 
 def pack_wt(w: torch.Tensor) -> torch.Tensor:
@@ -28,12 +28,12 @@ def pack_wt(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def pad_rows(x: torch.Tensor) -> torch.Tensor:
-    """compact [..., T] -> padded [..., ldt] (zeros in the pad)."""
+def pad_rows(x: torch.Tensor, min_frames: int = 0) -> torch.Tensor:
+    """compact [..., T] -> padded [..., ldt] (zeros in the pad); ldt also covers `min_frames`."""
     require_device(x, "pad_rows")
     x = x.contiguous()
     t = x.shape[-1]
-    ldt = padded_frames(t)
+    ldt = padded_frames(max(t, min_frames))
     out = torch.empty(*x.shape[:-1], ldt, dtype=torch.float32, device=x.device)
     rows = x.numel() // t
     check(lib().ps_pad_rows_f32(ptr(x), ptr(out), rows, t, ldt, stream_ptr(x.device)), "ps_pad_rows_f32")
@@ -49,8 +49,10 @@ def unpad_rows(x: torch.Tensor, t: int) -> torch.Tensor:
     return out
 
 
-def free_encode(wav: torch.Tensor, w: torch.Tensor, hop: int, relu: bool = False) -> tuple[torch.Tensor, int]:
-    """wav [N,L], w [C,1,win] -> (feats padded [N,C,ldt], T)."""
+def free_encode(wav: torch.Tensor, w: torch.Tensor, hop: int, relu: bool = False,
+                min_frames=None) -> tuple[torch.Tensor, int]:
+    """wav [N,L], w [C,1,win] -> (feats padded [N,C,ldt], T).  `min_frames`: int or callable T -> frames the
+    consumer needs the (zero-filled) rows to hold (segment padding of the dual-path maskers)."""
     require_device(wav, "free_encode")
     wav = wav.contiguous()
     n, length = wav.shape
@@ -58,7 +60,8 @@ def free_encode(wav: torch.Tensor, w: torch.Tensor, hop: int, relu: bool = False
     if length < win:
         raise RuntimeError(f"free_encode: input length {length} is shorter than the window {win}")
     t = (length - win) // hop + 1
-    ldt = padded_frames(t)
+    need = min_frames(t) if callable(min_frames) else (min_frames or 0)
+    ldt = padded_frames(max(t, need))
     feats = torch.zeros(n, c, ldt, dtype=torch.float32, device=wav.device)
     check(lib().ps_free_encode_f32(ptr(wav), ptr(w), ptr(feats), n, length, c, win, hop, t, ldt, int(relu),
                                    stream_ptr(wav.device)), "ps_free_encode_f32")
@@ -171,6 +174,68 @@ def attn_stats_pool(logits: torch.Tensor, x: torch.Tensor, t: int, eps: float = 
     check(lib().ps_attn_stats_pool_f32(ptr(logits), ptr(x), ptr(out), n, c, t, ldt, float(eps),
                                        stream_ptr(x.device)), "ps_attn_stats_pool_f32")
     return out
+
+
+def lstm(gx: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int, q: int, q_stride: int, steps: int,
+         step_stride: int, h0: Optional[torch.Tensor] = None, c0: Optional[torch.Tensor] = None,
+         want_state: bool = False, state_shift: int = 0, state_out: Optional[tuple] = None):
+    """LSTM recurrence over gate pre-activations gx padded [N,D*4H,ldt] -> hout [N,D*H,ldt]
+    (+ final (h, c) in state layout [N,D*H,ldq] when want_state / state_out)."""
+    require_device(gx, "lstm")
+    n, rows, ldt = gx.shape
+    if rows != dirs * 4 * hidden or tuple(whh_t.shape) != (dirs, hidden, 4 * hidden):
+        raise RuntimeError("lstm: gx must be [N, D*4H, ldt] and whh_t [D, H, 4H]")
+    hout = torch.zeros(n, dirs * hidden, ldt, dtype=torch.float32, device=gx.device)
+    a = LstmArgs()
+    a.gx, a.whh_t, a.hout = ptr(gx), ptr(whh_t), ptr(hout)
+    ldq = padded_frames(q)
+    for name, t in (("h0", h0), ("c0", c0)):
+        if t is not None and (tuple(t.shape[:2]) != (n, dirs * hidden) or t.shape[2] < q or not t.is_contiguous()):
+            raise RuntimeError(f"lstm: {name} must be a contiguous state tensor [N, D*H, ldq >= Q]")
+    if h0 is not None:
+        ldq = h0.shape[2]
+    elif c0 is not None:
+        ldq = c0.shape[2]
+    if (h0 is not None and c0 is not None) and h0.shape[2] != c0.shape[2]:
+        raise RuntimeError("lstm: h0 and c0 must share ldq")
+    h_last = c_last = None
+    if state_out is not None:
+        h_last, c_last = state_out
+        if h_last.shape[2] != ldq and (h0 is not None or c0 is not None):
+            raise RuntimeError("lstm: state_out must share ldq with h0/c0")
+        ldq = h_last.shape[2]
+    elif want_state:
+        h_last = torch.zeros(n, dirs * hidden, ldq, dtype=torch.float32, device=gx.device)
+        c_last = torch.zeros_like(h_last)
+    a.h0, a.c0, a.h_last, a.c_last = ptr(h0), ptr(c0), ptr(h_last), ptr(c_last)
+    a.N, a.H, a.D, a.Q, a.q_stride, a.steps, a.step_stride = n, hidden, dirs, q, q_stride, steps, step_stride
+    a.ldt, a.ldq, a.state_shift = ldt, ldq, state_shift
+    check(lib().ps_lstm_f32(C.byref(a), stream_ptr(gx.device)), "ps_lstm_f32")
+    return (hout, (h_last, c_last)) if h_last is not None else (hout, None)
+
+
+def chan_layernorm(x: torch.Tensor, t: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                   res: Optional[torch.Tensor] = None, slope: Optional[torch.Tensor] = None, sigmoid: bool = False,
+                   mul: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[res +] [mul *] act(LN over channels of every frame) on padded [N,C,ldt]."""
+    require_device(x, "chan_layernorm")
+    n, c, ldt = x.shape
+    y = torch.zeros_like(x)
+    check(lib().ps_chan_layernorm_f32(ptr(x), ptr(gamma), ptr(beta), float(eps), ptr(slope), int(sigmoid), ptr(mul),
+                                      ptr(res), ptr(y), n, c, t, ldt, stream_ptr(x.device)), "ps_chan_layernorm_f32")
+    return y
+
+
+def film_apply(x: torch.Tensor, scale_bias: torch.Tensor, t: int) -> torch.Tensor:
+    """scale_bias padded [N,2C,ldt] (scale rows, then bias rows), x padded [N,C,ldt] -> scale * x + bias."""
+    require_device(x, "film_apply")
+    n, c, ldt = x.shape
+    if tuple(scale_bias.shape) != (n, 2 * c, ldt):
+        raise RuntimeError("film_apply: scale_bias must be [N, 2C, ldt]")
+    y = torch.zeros_like(x)
+    check(lib().ps_film_apply_f32(ptr(x), ptr(scale_bias), ptr(y), n, c, t, ldt, stream_ptr(x.device)),
+          "ps_film_apply_f32")
+    return y
 
 
 def embed_bias(dvec: torch.Tensor, w_embed: torch.Tensor, normalize: bool) -> torch.Tensor:

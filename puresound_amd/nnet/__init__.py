@@ -3,10 +3,15 @@ from types import SimpleNamespace
 
 from .base_nn import SoTaskWrapModule
 from .conv_tasnet import TCN, ConvTasNet, GatedTCN
+from .dprnn import DPRNN
 from .lobe.encoder import ConvEncDec, FreeEncDec
 from .lobe.pooling import AttentiveStatisticsPooling
+from .lobe.trivial import FiLM, Gate
+from .skim import MemLSTM, SegLSTM, SkiM
+from ..streaming.skim_inference import StreamingSkiM
 
 # the class namespace the parity tests hand to tests/golden/cases.build()
 NS = SimpleNamespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                      ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
-                     AttentiveStatisticsPooling=AttentiveStatisticsPooling)
+                     AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM,
+                     StreamingSkiM=StreamingSkiM, MemLSTM=MemLSTM, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate)

@@ -1,0 +1,89 @@
+"""Kernel-side parameter layouts ("plans") shared by the recurrent maskers.
+
+A plan holds the packed / transposed fp32 copies of a module's parameters that the HIP kernels consume, keyed by a
+fingerprint of the parameters so that load_state_dict / .to(device) / in-place edits invalidate it.  Plans hold
+raw device pointers through the tensors they keep alive; they are never pickled.
+"""
+import torch
+import torch.nn as nn
+
+from .. import hip
+
+
+def param_signature(module: nn.Module, device) -> tuple:
+    sig = [(t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers())]
+    sig.append(module.training)
+    sig.append(str(device))
+    return tuple(sig)
+
+
+class PlanCache:
+    """Mixin: `self._plan_get(device, builder)` caches builder(device) until a parameter changes."""
+
+    _plan = None
+    _plan_sig = None
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_plan"] = None
+        state["_plan_sig"] = None
+        return state
+
+    def _plan_get(self, device, builder):
+        sig = param_signature(self, device)
+        if self._plan is None or self._plan_sig != sig:
+            self._plan = builder(device)
+            self._plan_sig = sig
+        return self._plan
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(dtype=torch.float32, device=device).contiguous()
+
+
+def lstm_plan(lstm: nn.LSTM, device) -> dict:
+    """nn.LSTM(num_layers=1, batch_first=True): input projection rows stacked over directions (for one
+    ps_conv1x1_f32), summed biases, W_hh transposed per direction."""
+    if lstm.num_layers != 1 or not lstm.batch_first or lstm.proj_size != 0 or not lstm.bias:
+        raise NotImplementedError("HIP LSTM: num_layers=1, batch_first=True, bias=True, no projection")
+    dirs = 2 if lstm.bidirectional else 1
+    hid = lstm.hidden_size
+    wih, bias, whh = [], [], []
+    for suf in ["", "_reverse"][:dirs]:
+        wih.append(_f32(getattr(lstm, "weight_ih_l0" + suf), device))
+        bias.append(_f32(getattr(lstm, "bias_ih_l0" + suf), device) + _f32(getattr(lstm, "bias_hh_l0" + suf), device))
+        whh.append(_f32(getattr(lstm, "weight_hh_l0" + suf), device).t().contiguous())
+    return dict(wih=hip.pack_wt(torch.cat(wih, 0)), bias=torch.cat(bias).contiguous(),
+                whh_t=torch.stack(whh).contiguous(), H=hid, D=dirs, rows=dirs * 4 * hid, I=lstm.input_size)
+
+
+def linear_plan(lin: nn.Module, device) -> dict:
+    """nn.Linear or nn.Conv1d(k=1)."""
+    w = lin.weight
+    if w.dim() == 3:
+        w = w[:, :, 0]
+    return dict(wt=hip.pack_wt(_f32(w, device)), bias=None if lin.bias is None else _f32(lin.bias, device),
+                M=w.shape[0], K=w.shape[1])
+
+
+def layernorm_plan(ln: nn.Module, device) -> dict:
+    """nn.LayerNorm(C) (weight/bias, eps) or ChanLN (gamma/beta, eps 1e-8)."""
+    if isinstance(ln, nn.LayerNorm):
+        if len(ln.normalized_shape) != 1 or ln.weight is None:
+            raise NotImplementedError("HIP LayerNorm: one normalised dim with affine parameters")
+        return dict(gamma=_f32(ln.weight, device), beta=_f32(ln.bias, device), eps=float(ln.eps))
+    return dict(gamma=_f32(ln.gamma, device), beta=_f32(ln.beta, device), eps=float(ln.eps))
+
+
+def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int, q_stride: int, steps: int,
+              step_stride: int, h0=None, c0=None, want_state: bool = False, state_shift: int = 0, state_out=None):
+    """x + LN(proj(LSTM(x))) on padded [N,C,ldt] (dprnn.py:154-172, skim.py:215-227) -> (x', final states)."""
+    n, _, ldt = x.shape
+    dev = x.device
+    gx, _ = hip.conv1x1(x, t, rnn["wih"], rnn["rows"], None, rnn["bias"],
+                        out=torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev))
+    hseq, state = hip.lstm(gx, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride, h0, c0, want_state,
+                           state_shift, state_out)
+    p, _ = hip.conv1x1(hseq, t, proj["wt"], proj["M"], None, proj["bias"],
+                       out=torch.empty(n, proj["M"], ldt, dtype=torch.float32, device=dev))
+    return hip.chan_layernorm(p, t, norm["gamma"], norm["beta"], norm["eps"], res=x), state

@@ -28,9 +28,9 @@ class FreeEncDec(nn.Module):
         self.decoder = nn.ConvTranspose1d(laten_length, 1, kernel_size=win_length, stride=hop_length, bias=False)
 
     # -- padded-layout entry points used by the fused wrapper ---------------------------------
-    def encode_padded(self, x: torch.Tensor):
-        """[N,L] -> (padded feats [N,C,ldt], T)."""
-        return hip.free_encode(x, self.encoder.weight.detach(), self.hop_length, self.output_active)
+    def encode_padded(self, x: torch.Tensor, min_frames=None):
+        """[N,L] -> (padded feats [N,C,ldt], T); rows are zero beyond T and hold at least min_frames(T) frames."""
+        return hip.free_encode(x, self.encoder.weight.detach(), self.hop_length, self.output_active, min_frames)
 
     def decode_padded(self, feats_pad: torch.Tensor, t: int, mask_pad: Optional[torch.Tensor] = None,
                       mask_act: str = "linear", out_mode: str = "none",

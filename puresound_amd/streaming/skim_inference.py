@@ -1,0 +1,199 @@
+"""Streaming SkiM on the HIP path (mirror of puresound/streaming/skim_inference.py:10-252).
+
+The reference streams ONE utterance: every state tensor has a constant batch axis of 1.  Here B concurrent
+streams are the frame axis of the library's channel-major layout -- activations [1][C][ldB], LSTM states
+[1][D*H][ldB] -- so one frame step of all streams is the same handful of kernels (FiLM conv, input projection,
+ps_lstm_f32 with one step per stream, projection, LayerNorm + residual) whatever B is, and the whole step is
+captured once in a hipGraph and replayed (no allocation, no host sync inside).  With B = 1 the tensors that
+cross the API have exactly the reference's shapes.
+"""
+import time
+from typing import List, Optional, Tuple
+
+import torch
+
+from .. import hip
+from ..nnet.skim import SkiM
+
+
+def _rows_to_frames(v: torch.Tensor) -> torch.Tensor:
+    """[B, R] -> padded [1, R, ldB] (streams become frames)."""
+    return hip.pad_rows(v.t().unsqueeze(0))
+
+
+def _frames_to_rows(v: torch.Tensor, b: int) -> torch.Tensor:
+    """padded [1, R, ldB] -> [B, R]."""
+    return v[0, :, :b].t().contiguous()
+
+
+class StreamingSkiM(SkiM):
+    """Constructor as the reference (skim_inference.py:11-39)."""
+
+    def __init__(self, input_size: int, hidden_size: int, output_size: int, n_blocks: int = 2, seg_size: int = 20,
+                 seg_overlap: bool = False, causal: bool = True, embed_dim: int = 0, embed_norm: bool = False,
+                 embed_fusion: Optional[str] = None, block_with_embed: Optional[List] = None, dropout: float = 0):
+        super().__init__(input_size, hidden_size, output_size, n_blocks, seg_size, seg_overlap, causal, embed_dim,
+                         embed_norm, embed_fusion, block_with_embed, dropout)
+        self._graph = None
+
+    # -- chunk API (stateless; the caller carries the states) -------------------------------------------
+    @torch.no_grad()
+    def step_chunk(self, x: torch.Tensor, seg_lstm_h_state=None, mem_lstm_h_hidden=None, seg_lstm_c_state=None,
+                   mem_lstm_c_hidden=None, embed: Optional[torch.Tensor] = None):
+        """x [B,K,C] = one whole segment (B = 1 in the reference); states as the reference passes them: seg states
+        lists of [D,B,H] for blocks 1.., Mem-LSTM hidden lists of ((h, c)) [D,B,H] (skim_inference.py:41-139).
+        A frame-by-frame walk through the blocks equals one pass of every block's SegLSTM over the segment."""
+        hip.require_device(x, "StreamingSkiM.step_chunk")
+        b, k, c = x.shape
+        nb, hid = self.n_blocks, self.hidden_size
+        d = 1 if self.causal else 2
+        to_state = lambda v: hip.pad_rows(v.permute(1, 0, 2).reshape(b, d * hid, 1).float())  # noqa: E731
+        back = lambda v: v[..., 0].reshape(b, d, hid).permute(1, 0, 2).contiguous()  # noqa: E731
+        if seg_lstm_h_state is not None and seg_lstm_c_state is not None:
+            seg_h = [None] + [to_state(seg_lstm_h_state[i]) for i in range(nb - 1)]
+            seg_c = [None] + [to_state(seg_lstm_c_state[i]) for i in range(nb - 1)]
+        else:
+            seg_h, seg_c = [None] * nb, [None] * nb
+        if mem_lstm_h_hidden is None and mem_lstm_c_hidden is None:
+            mem_h, mem_c = [None] * (nb - 1), [None] * (nb - 1)
+        else:
+            mem_h = [None if s is None else tuple(to_state(t) for t in s) for s in mem_lstm_h_hidden]
+            mem_c = [None if s is None else tuple(to_state(t) for t in s) for s in mem_lstm_c_hidden]
+        cur = hip.pad_rows(x.transpose(1, 2).float())          # [B, C, ldK]: every stream is an utterance
+        for i in range(nb):
+            cur = self._fuse(i, cur, k, embed)
+            cur, (seg_h[i], seg_c[i]) = self.seg_lstm[i].forward_padded(cur, k, 1, k, seg_h[i], seg_c[i])
+        out = hip.unpad_rows(self._output(cur, k), k)
+        for i in range(nb - 1):
+            seg_h[i], seg_c[i], mem_h[i], mem_c[i] = self.mem_lstm[i].forward_state(
+                seg_h[i], seg_c[i], 1, mem_h[i], mem_c[i], want_states=True)
+        return (out, [back(v) for v in seg_h[:-1]], [tuple(back(t) for t in s) for s in mem_h],
+                [back(v) for v in seg_c[:-1]], [tuple(back(t) for t in s) for s in mem_c])
+
+    # -- frame API (stateful) ------------------------------------------------------------------------------
+    def init_status(self, streams: int = 1, device=None, use_graph: bool = True):
+        """Initialise the streaming state (skim_inference.py:142-167) for `streams` concurrent streams."""
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("StreamingSkiM.init_status: ROCm device only (there is no CPU fallback)")
+        d = 1 if self.causal else 2
+        self.streams = streams
+        self.frames_counter = 0
+        ldb = hip.padded_frames(streams)
+        z = lambda rows: torch.zeros(1, rows, ldb, dtype=torch.float32, device=dev)  # noqa: E731
+        rows = d * self.hidden_size
+        self._seg_h = [z(rows) for _ in range(self.n_blocks)]
+        self._seg_c = [z(rows) for _ in range(self.n_blocks)]
+        self._mem_h = [(z(rows), z(rows)) for _ in range(self.n_blocks - 1)]
+        self._mem_c = [(z(rows), z(rows)) for _ in range(self.n_blocks - 1)]
+        self._x_in = z(self.input_size)
+        self._embed_key = None
+        self._embed_static = None
+        self._graph = None
+        self._use_graph = use_graph
+        self._out = None
+        print(f"{time.asctime(time.localtime(time.time()))}, Initialized streaming SkiM model")
+
+    # reference-shaped views of the state (skim_inference.py:146-164), for B streams: [D, B, H]
+    def _view(self, v: torch.Tensor) -> torch.Tensor:
+        d = 1 if self.causal else 2
+        return _frames_to_rows(v, self.streams).reshape(self.streams, d, self.hidden_size).permute(1, 0, 2).contiguous()
+
+    @property
+    def seg_lstm_h_states(self):
+        return [self._view(v) for v in self._seg_h]
+
+    @property
+    def seg_lstm_c_states(self):
+        return [self._view(v) for v in self._seg_c]
+
+    @property
+    def mem_lstm_h_hidden(self):
+        return [tuple(self._view(t) for t in s) for s in self._mem_h]
+
+    @property
+    def mem_lstm_c_hidden(self):
+        return [tuple(self._view(t) for t in s) for s in self._mem_c]
+
+    def reset_seg_lstm_status(self):
+        self._seg_h[0].zero_()
+        self._seg_c[0].zero_()
+
+    def _frame_body(self):
+        """One frame of every stream through all blocks; reads _x_in / _embed_static, updates the seg states in
+        place, returns padded [1, C_out, ldB]."""
+        b = self.streams
+        cur = self._x_in
+        for i in range(self.n_blocks):
+            if self._embed_static is not None and self.block_with_embed[i]:
+                cur = self.seg_input_fusion[i].forward_padded(cur, b, self._embed_static, self.embed_norm,
+                                                              per_frame=True)
+            p = self.seg_lstm[i]._plan_get(cur.device, self.seg_lstm[i]._build)
+            from ..nnet._plans import lstm_path
+            cur, _ = lstm_path(cur, b, *p, q=b, q_stride=1, steps=1, step_stride=0, h0=self._seg_h[i],
+                               c0=self._seg_c[i], state_out=(self._seg_h[i], self._seg_c[i]))
+        return self._output(cur, b)
+
+    @torch.no_grad()
+    def step_frame(self, x: torch.Tensor, embed: Optional[torch.Tensor]) -> torch.Tensor:
+        """x: one frame per stream, [B,C,1] / [B,1,C] / [B,C] (the reference passes [1,C,1] or [1,1,C]);
+        embed [B,E] -> [B,C_out,1] (skim_inference.py:176-218)."""
+        hip.require_device(x, "StreamingSkiM.step_frame")
+        b = self.streams
+        if x.numel() != b * self.input_size:
+            raise RuntimeError(f"step_frame: expected {b} x {self.input_size} values, got {tuple(x.shape)}")
+        self._x_in[0, :, :b].copy_(x.reshape(b, self.input_size).t())
+        if embed is not None:
+            key = (embed.data_ptr(), embed._version, tuple(embed.shape))
+            if key != self._embed_key:
+                if self._embed_static is None:
+                    self._embed_static = embed.detach().reshape(b, -1).float().clone()
+                else:
+                    self._embed_static.copy_(embed.reshape(b, -1))
+                self._embed_key = key
+                for m in getattr(self, "seg_input_fusion", []):
+                    if m is not None:
+                        m.invalidate_per_frame()
+        elif self._embed_static is not None:
+            raise RuntimeError("step_frame: the stream was started with an embedding; keep passing it")
+        if not self._use_graph:
+            out = self._frame_body()
+        else:
+            if self._graph is None:
+                # warm up once eagerly on a side stream (fills plan caches / per-frame embedding terms), then capture
+                saved = [t.clone() for t in self._seg_h + self._seg_c]
+                s = torch.cuda.Stream(x.device)
+                s.wait_stream(torch.cuda.current_stream(x.device))
+                with torch.cuda.stream(s):
+                    self._frame_body()
+                torch.cuda.current_stream(x.device).wait_stream(s)
+                for t, v in zip(self._seg_h + self._seg_c, saved):
+                    t.copy_(v)
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._out = self._frame_body()
+                for t, v in zip(self._seg_h + self._seg_c, saved):
+                    t.copy_(v)
+            self._graph.replay()
+            out = self._out
+        res = out[0, :, :b].t().reshape(b, -1, 1).clone()
+        self.frames_counter += 1
+        if self.frames_counter % self.seg_size == 0:
+            self.update_mem_lstm()
+            self.reset_seg_lstm_status()
+            self.frames_counter = 0
+        return res
+
+    @torch.no_grad()
+    def update_mem_lstm(self):
+        """skim_inference.py:220-252: block i's segment-end state -> MemLSTM i -> block i+1's initial state."""
+        b = self.streams
+        new = []
+        for i in range(self.n_blocks - 1):
+            new.append(self.mem_lstm[i].forward_state(self._seg_h[i], self._seg_c[i], b, self._mem_h[i],
+                                                      self._mem_c[i], per_frame_sequences=True))
+        for i, (h, c, hs, cs) in enumerate(new):
+            self._seg_h[i + 1].copy_(h)
+            self._seg_c[i + 1].copy_(c)
+            for dst, src in zip(self._mem_h[i] + self._mem_c[i], hs + cs):
+                dst.copy_(src)

@@ -37,6 +37,19 @@ CASES = {
                        masker=masker_args(512, 192, True, [1, 0, 0, 0, 0, 0, 0, 0], **CTN_FULL),
                        speaker_net=dict(n_tcn=5, C=512, H=256, att=128, E=192),
                        wrap=dict(mask_constraint="ReLU"), B=2, L=4000, L_enroll=4000, seed=1234),
+    # BASELINE config 4: DPRNN hyper-parameters of veve_dprnn_v0_causal (egs/tse/model.py:614-630) as a plain
+    # separator, and the preset verbatim (embedding-free TSE: the enrolment pass seeds the inter-LSTM states)
+    "cfg4_short": dict(kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
+                       masker=dict(cls="DPRNN", args=(128, 64, 128),
+                                   kw=dict(n_blocks=6, seg_size=20, seg_overlap=False, causal=True)),
+                       wrap=dict(mask_constraint="ReLU"), B=2, L=4000, seed=1234),
+    "cfg4_tse_short": dict(kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
+                           masker=dict(cls="DPRNN", args=(128, 64, 128),
+                                       kw=dict(n_blocks=6, seg_size=20, seg_overlap=False, causal=True, embed_dim=0,
+                                               embed_norm=False, block_with_embed=(False,) * 6,
+                                               embedding_free_tse=True)),
+                           wrap=dict(mask_constraint="ReLU", embedding_free_tse=True), B=2, L=4000, L_enroll=3000,
+                           seed=1234),
     # ---- reduced wrapper cases: odd sizes, ragged tails, sigmoid/linear constraints -----------
     "tiny_free": dict(kind="wrap", enc=dict(kind="free", win=16, hop=8, C=24),
                       masker=masker_args(24, 0, False, [0, 0, 0], tcn_kernel=3, tcn_dim=12, repeat_tcn=2,
@@ -86,6 +99,49 @@ CASES = {
                                                        tcn_norm="cLN", dconv_norm="cLN", causal=True,
                                                        tcn_layer="normal"),
                     B=2, T=33, seed=15),
+    # ---- recurrent maskers, module level: T mod K in {0, 1, K-1}, causal / bidirectional, FiLM / Gate
+    # conditioning, embedding-free TSE (embed = enrolment features), overlapped segments
+    "dprnn_causal_r0": dict(kind="rnn", cls="DPRNN", args=(16, 8, 16), kw=dict(n_blocks=2, seg_size=5, causal=True),
+                            B=2, T=20, seed=21),
+    "dprnn_causal_r1": dict(kind="rnn", cls="DPRNN", args=(16, 8, 12), kw=dict(n_blocks=2, seg_size=5, causal=True),
+                            B=2, T=21, seed=22),
+    "dprnn_bi_rk1": dict(kind="rnn", cls="DPRNN", args=(16, 8, 16), kw=dict(n_blocks=2, seg_size=5, causal=False),
+                         B=3, T=24, seed=23),
+    "dprnn_film": dict(kind="rnn", cls="DPRNN", args=(16, 8, 16),
+                       kw=dict(n_blocks=2, seg_size=5, causal=True, embed_dim=6, embed_norm=True,
+                               block_with_embed=[1, 0]), B=2, T=23, seed=24, embed="vec"),
+    "dprnn_embfree": dict(kind="rnn", cls="DPRNN", args=(16, 8, 16),
+                          kw=dict(n_blocks=2, seg_size=5, causal=True, block_with_embed=[0, 0],
+                                  embedding_free_tse=True),
+                          B=2, T=22, seed=25, embed="feat", Te=17),
+    "dprnn_embfree_bi": dict(kind="rnn", cls="DPRNN", args=(16, 8, 16),
+                             kw=dict(n_blocks=2, seg_size=4, causal=False, block_with_embed=[0, 0],
+                                     embedding_free_tse=True),
+                             B=2, T=19, seed=26, embed="feat", Te=30),
+    "dprnn_overlap": dict(kind="rnn", cls="DPRNN", args=(16, 8, 16),
+                          kw=dict(n_blocks=2, seg_size=6, seg_overlap=True, causal=False), B=2, T=25, seed=27),
+    "skim_causal": dict(kind="rnn", cls="SkiM", args=(16, 12, 16), kw=dict(n_blocks=3, seg_size=7, causal=True),
+                        B=2, T=30, seed=31),
+    "skim_bi_film": dict(kind="rnn", cls="SkiM", args=(16, 12, 10),
+                         kw=dict(n_blocks=3, seg_size=7, causal=False, embed_dim=6, embed_norm=True,
+                                 embed_fusion="FiLM", block_with_embed=[1, 0, 1]), B=2, T=29, seed=32, embed="vec"),
+    "skim_gate": dict(kind="rnn", cls="SkiM", args=(16, 12, 16),
+                      kw=dict(n_blocks=2, seg_size=8, causal=True, embed_dim=6, embed_norm=False,
+                              embed_fusion="Gate", block_with_embed=[1, 1]), B=2, T=24, seed=33, embed="vec"),
+    "skim_overlap": dict(kind="rnn", cls="SkiM", args=(16, 12, 16),
+                         kw=dict(n_blocks=2, seg_size=6, seg_overlap=True, causal=True), B=2, T=25, seed=34),
+    # ---- streaming: offline forward vs step_chunk vs step_frame (the reference's own property,
+    # test/test_streaming.py:61-116) on its tiny model and on the demo preset (BASELINE config 5,
+    # egs/tse/demo/utils.py:51-66) across two Mem-LSTM updates; plus three 320-sample chunks through the demo
+    # harness (sliding window, encoder, mask, decoder, averaging overlap-add; utils.py:78-128)
+    "stream_tiny": dict(kind="stream", args=(5, 20, 5),
+                        kw=dict(seg_size=10, seg_overlap=False, causal=True, n_blocks=4, embed_dim=10,
+                                embed_norm=True, embed_fusion="FiLM", block_with_embed=[1, 1, 1, 1]),
+                        frames=47, seed=41),
+    "cfg5_demo": dict(kind="stream", args=(128, 256, 128),
+                      kw=dict(n_blocks=4, seg_size=150, seg_overlap=False, causal=True, embed_dim=192,
+                              embed_norm=True, block_with_embed=[1, 1, 1, 1], embed_fusion="FiLM"),
+                      frames=307, seed=42, harness=dict(win=32, hop=16, C=128, chunks=3, chunk=320)),
     "enc_free": dict(kind="encdec", enc=dict(kind="free", win=32, hop=16, C=20), B=3, L=500, seed=16),
     "enc_free_relu_ragged": dict(kind="encdec", enc=dict(kind="free", win=20, hop=6, C=9, relu=True),
                                  B=2, L=211, seed=17),
@@ -94,7 +150,7 @@ CASES = {
 }
 
 # parameter counts the reference documents / the survey measured (known answers)
-PARAM_COUNTS = {"cfg2_short": 7977032, "cfg1_short": 8207432, "cfg3_short": 10108119}
+PARAM_COUNTS = {"cfg2_short": 7977032, "cfg1_short": 8207432, "cfg3_short": 10108119, "cfg4_tse_short": 723585}
 
 
 def build_encoder(ns, enc):
@@ -106,6 +162,8 @@ def build_encoder(ns, enc):
 
 
 def build_masker(ns, m):
+    if "cls" in m:
+        return getattr(ns, m["cls"])(*m["args"], **m["kw"])
     kw = {k: v for k, v in m.items() if k not in ("input_dim", "embed_dim", "embed_norm")}
     return ns.ConvTasNet(m["input_dim"], m["embed_dim"], m["embed_norm"], **kw)
 
@@ -131,15 +189,31 @@ def build(ns, name):
         return build_masker(ns, c["masker"])
     if c["kind"] == "encdec":
         return build_encoder(ns, c["enc"])
+    if c["kind"] == "rnn":
+        return getattr(ns, c["cls"])(*c["args"], **c["kw"])
+    if c["kind"] == "stream":
+        return ns.StreamingSkiM(*c["args"], **c["kw"])
     raise KeyError(c["kind"])
+
+
+def rnn_args(spec):
+    """The oracle's description of a DPRNN / SkiM constructor call (defaults of dprnn.py:27-40, skim.py:280-294)."""
+    a = dict(n_blocks=2, seg_size=20, seg_overlap=False, causal=True, embed_dim=0, embed_norm=False,
+             block_with_embed=None, embedding_free_tse=False, embed_fusion=None)
+    a.update(spec["kw"])
+    a["input_size"], a["hidden_size"], a["output_size"] = spec["args"]
+    return a
 
 
 def oracle_cfg(name):
     """The oracle's description of a wrapper case."""
     c = CASES[name]
     enc = dict(c["enc"])
-    cfg = dict(encoder=enc, masker=full_masker_args(c["masker"]))
-    cfg.update({k: v for k, v in c["wrap"].items() if k != "drop_first_bin"})
+    if "cls" in c["masker"]:
+        cfg = dict(encoder=enc, masker=rnn_args(c["masker"]), masker_kind=c["masker"]["cls"].lower())
+    else:
+        cfg = dict(encoder=enc, masker=full_masker_args(c["masker"]))
+    cfg.update({k: v for k, v in c["wrap"].items() if k not in ("drop_first_bin", "embedding_free_tse")})
     if "speaker_net" in c:
         cfg["speaker_net"] = dict(n_tcn=c["speaker_net"]["n_tcn"])
     return cfg
@@ -154,3 +228,14 @@ def full_masker_args(m):
 
 def namespace(**classes):
     return SimpleNamespace(**classes)
+
+
+def build_demo(ns, c):
+    """The demo harness' model (egs/tse/demo/utils.py:47-72): encoder + streaming masker under the keys
+    `encoder.*` / `masker.*`."""
+    import torch.nn as nn
+    h = c["harness"]
+    net = nn.Module()
+    net.encoder = ns.FreeEncDec(win_length=h["win"], hop_length=h["hop"], laten_length=h["C"], output_active=True)
+    net.masker = ns.StreamingSkiM(*c["args"], **c["kw"])
+    return net

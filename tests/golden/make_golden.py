@@ -33,13 +33,17 @@ from puresound.nnet.base_nn import SoTaskWrapModule  # noqa: E402
 from puresound.nnet.conv_tasnet import TCN, ConvTasNet, GatedTCN  # noqa: E402
 from puresound.nnet.lobe.encoder import ConvEncDec, FreeEncDec  # noqa: E402
 from puresound.nnet.lobe.pooling import AttentiveStatisticsPooling  # noqa: E402
+from puresound.nnet.dprnn import DPRNN  # noqa: E402
+from puresound.nnet.skim import SkiM  # noqa: E402
+from puresound.streaming.skim_inference import StreamingSkiM  # noqa: E402
 
 import cases  # noqa: E402
 from detweights import det_state_dict, det_wave  # noqa: E402
 
 REF = cases.namespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                       ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
-                      AttentiveStatisticsPooling=AttentiveStatisticsPooling)
+                      AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM,
+                      StreamingSkiM=StreamingSkiM)
 
 
 def sub(x: torch.Tensor, cs: int = 7, ts: int = 5) -> np.ndarray:
@@ -60,7 +64,9 @@ def run_wrap(name, c):
     # step through the same reference methods to capture taps (base_nn.py:690-722)
     feats, enr = model._get_feature(noisy.clone(), None if enroll is None else enroll.clone())
     dvec = None
-    if enr is not None:
+    if enr is not None and model.embedding_free_tse:
+        dvec = enr
+    elif enr is not None:
         dvec = enr
         for layer in model.speaker_net:
             dvec = layer(dvec)
@@ -72,7 +78,10 @@ def run_wrap(name, c):
     pre = model._get_waveform(enh)
     out["wav_preclamp"] = pre.numpy()
     small = c["L"] <= 4000
-    if small:
+    if small and "cls" in c["masker"]:
+        out["feats_sub"] = sub(feats)
+        out["mask_sub"] = sub(mask)
+    elif small:
         out["feats_sub"] = sub(feats)
         out["mask_sub"] = sub(mask)
         blk0 = model.masker.tcn_list[0][0]
@@ -112,6 +121,74 @@ def run_encdec(name, c):
     return {"feats": feats.numpy(), "rec": rec.numpy()}
 
 
+def _uniform(seed, shape, lo=-1.0, hi=1.0):
+    g = np.random.Generator(np.random.Philox(key=seed))
+    return torch.tensor(g.uniform(lo, hi, shape), dtype=torch.float32)
+
+
+@torch.no_grad()
+def run_rnn(name, c):
+    """DPRNN / SkiM at module level: x [B,C,T] (+ embedding vector or enrolment features)."""
+    model = cases.build(REF, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    x = _uniform(c["seed"], (c["B"], c["args"][0], c["T"]))
+    out = {"x": x.numpy()}
+    embed = None
+    if c.get("embed") == "vec":
+        embed = _uniform(c["seed"] + 100, (c["B"], c["kw"]["embed_dim"]))
+    elif c.get("embed") == "feat":
+        embed = _uniform(c["seed"] + 100, (c["B"], c["args"][0], c["Te"]))
+    if embed is not None:
+        out["embed"] = embed.numpy()
+    y = model(x.clone(), None if embed is None else embed.clone())
+    out["y"] = y.numpy()
+    return out
+
+
+@torch.no_grad()
+def run_stream(name, c):
+    """StreamingSkiM: offline forward, step_chunk over whole segments, step_frame over every frame; for the demo
+    preset also the harness of egs/tse/demo/utils.py (DemoTseNet.streaming_inference_chunk) on three chunks."""
+    model = cases.build(REF, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    cin, e, k, frames = c["args"][0], c["kw"]["embed_dim"], c["kw"]["seg_size"], c["frames"]
+    x = _uniform(c["seed"], (1, cin, frames), 0.0, 1.0)
+    d = _uniform(c["seed"] + 100, (1, e), 0.0, 1.0)
+    out = {"x": x.numpy(), "embed": d.numpy()}
+    out["y_offline"] = model(x.clone(), d.clone()).numpy()
+    ys, seg_h, seg_c, mem_h, mem_c = [], None, None, None, None
+    for i in range(frames // k):
+        o, seg_h, mem_h, seg_c, mem_c = model.step_chunk(x[..., i * k:(i + 1) * k].permute(0, 2, 1), seg_h, mem_h,
+                                                         seg_c, mem_c, d)
+        ys.append(o)
+    out["y_chunk"] = torch.cat(ys, -1).numpy()
+    out["chunk_seg_h"] = torch.stack(seg_h).numpy()
+    out["chunk_mem_h"] = torch.stack([torch.stack(p) for p in mem_h]).numpy()
+    model.init_status()
+    yf = [model.step_frame(x[..., f].view(1, -1, 1), d) for f in range(frames)]
+    out["y_frame"] = torch.cat(yf, -1).numpy()
+    out["frame_seg_h"] = torch.stack(model.seg_lstm_h_states).numpy()
+    out["frame_seg_c"] = torch.stack(model.seg_lstm_c_states).numpy()
+    if "harness" in c:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("demo_utils", "/root/reference/egs/tse/demo/utils.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        net = mod.DemoTseNet()
+        net.eval()
+        sd = det_state_dict(net)
+        net.load_state_dict(sd)
+        net.masker.init_status()
+        h = c["harness"]
+        wav = det_wave(c["seed"] + 200, 1, h["chunks"] * h["chunk"])
+        pre = None
+        for i in range(h["chunks"]):
+            pre = net.streaming_inference_chunk(wav[:, i * h["chunk"]:(i + 1) * h["chunk"]], d[0], pre)
+        out["harness_wav"] = pre.numpy()
+        out["harness_n_params"] = np.int64(sum(p.numel() for p in net.parameters()))
+    return out
+
+
 def dump_state_dict_keys():
     """Key -> shape of every reference state_dict the mirror modules must reproduce (drop-in checkpoints)."""
     import json
@@ -127,9 +204,13 @@ def dump_state_dict_keys():
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])
     dump_state_dict_keys()
     for name, c in cases.CASES.items():
-        fn = {"wrap": run_wrap, "masker": run_masker, "encdec": run_encdec}[c["kind"]]
+        fn = {"wrap": run_wrap, "masker": run_masker, "encdec": run_encdec, "rnn": run_rnn,
+              "stream": run_stream}[c["kind"]]
+        if only and name not in only:
+            continue
         out = fn(name, c)
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
