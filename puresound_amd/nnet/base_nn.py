@@ -14,6 +14,8 @@ import torch.nn as nn
 from .. import hip
 from .._abi import TcnBlock
 from .conv_tasnet import TCN, ConvTasNet
+from .dprnn import DPRNN
+from .skim import SkiM
 from .lobe.encoder import ConvEncDec, FreeEncDec
 from .lobe.pooling import AttentiveStatisticsPooling
 
@@ -155,14 +157,20 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
                 raise NotImplementedError("HIP inference path with an STFT encoder: (complex, complex) masks")
         elif not isinstance(self.encoder, FreeEncDec) or pairing != "real":
             raise NotImplementedError("HIP inference path: FreeEncDec encoder with (real, real) masks")
-        if not isinstance(self.masker, ConvTasNet):
-            raise NotImplementedError(f"HIP inference path: ConvTasNet masker (got {type(self.masker).__name__})")
-        if self.embedding_free_tse:
-            raise NotImplementedError("embedding_free_tse (DPRNN init-state mode) is not on the HIP path yet")
+        if not isinstance(self.masker, (ConvTasNet, DPRNN, SkiM)):
+            raise NotImplementedError(f"HIP inference path: ConvTasNet / DPRNN / SkiM masker "
+                                      f"(got {type(self.masker).__name__})")
+        recurrent = not isinstance(self.masker, ConvTasNet)
+        if recurrent and stft:
+            raise NotImplementedError("HIP inference path: recurrent maskers run behind the FreeEncDec encoder")
+        if self.embedding_free_tse and not isinstance(self.masker, DPRNN):
+            raise NotImplementedError("embedding_free_tse needs a DPRNN masker (dprnn.py:120-125)")
         if enroll is not None:
             hip.require_device(enroll, "SoTaskWrapModule.inference")
-            if stft or self.encoder_spk is not None or self.speaker_net is None:
+            if stft or self.encoder_spk is not None or (self.speaker_net is None and not self.embedding_free_tse):
                 raise NotImplementedError("HIP speaker branch: shared FreeEncDec encoder + speaker_net")
+        # the dual-path maskers pad the frame axis to whole segments: make the encoder leave room for it
+        need = self.masker.padded_frames_needed if recurrent else None
 
         if stft:
             # _get_feature (STFT branch, base_nn.py:337-345) -> masker -> get_mask + complex apply_tf_masks
@@ -176,11 +184,14 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
 
         def run(part: torch.Tensor, lane: int, out: Optional[torch.Tensor],
                 part_enroll: Optional[torch.Tensor] = None) -> torch.Tensor:
-            dvec = None
-            if part_enroll is not None:                                # base_nn.py:347-350, 697-705
+            dvec, kw = None, {}
+            if part_enroll is not None and self.embedding_free_tse:    # base_nn.py:706-707: the masker gets
+                dvec, te = self.encoder.encode_padded(part_enroll, need)  # the enrolment FEATURES
+                kw = dict(embed_frames=te)
+            elif part_enroll is not None:                              # base_nn.py:347-350, 697-705
                 dvec = self._speaker_embedding(part_enroll, lane)
-            feats, t = self.encoder.encode_padded(part)                # _get_feature, base_nn.py:319-345
-            mask = self.masker.forward_padded(feats, t, dvec, lane=lane)  # base_nn.py:709-714
+            feats, t = self.encoder.encode_padded(part, need)          # _get_feature, base_nn.py:319-345
+            mask = self.masker.forward_padded(feats, t, dvec, lane=lane, **kw)  # base_nn.py:709-714
             # get_mask + apply_tf_masks + _get_waveform + _wav_output_constrain, base_nn.py:716-721
             return self.encoder.decode_padded(feats, t, mask, mask_act, out_mode, out)
 
@@ -189,6 +200,10 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         # MFMA-bound GEMMs.  Results are bit-identical to the single-stream run.
         n = noisy.shape[0]
         lanes = min(int(getattr(self, "hip_streams", 2)), n // 2) if n >= 4 else 1
+        if isinstance(self.masker, SkiM) and self.masker.causal:
+            # the reference's causal Mem-LSTM hand-over leaks the last segment state of utterance n-1 into
+            # utterance n (skim.py:102-109): keep the batch in one piece so the result stays identical to it
+            lanes = 1
         if enroll is not None and enroll.shape[0] != n:
             raise RuntimeError("inference: noisy and enroll must have the same batch size")
         if lanes <= 1:

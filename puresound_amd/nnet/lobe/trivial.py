@@ -14,21 +14,27 @@ from .norm import ChanLN
 
 class _PerFrameCondition:
     """Streaming: the frames of the row are concurrent streams, each with its own embedding, so the embedding
-    columns of the conditioning conv become a per-frame additive term [1, M, ldB] (computed once per embedding)
-    instead of a per-utterance bias."""
+    columns of the conditioning conv become a per-frame additive term [1, M, ldB] instead of a per-utterance bias.
+    The term lives in one buffer that is refreshed in place when the embeddings change, so a captured hipGraph
+    keeps reading the right memory."""
 
     _per_frame = None
 
-    def invalidate_per_frame(self):
-        self._per_frame = None
+    def set_per_frame_condition(self, condition: torch.Tensor, normalize: bool) -> None:
+        p = self._plan_get(condition.device, self._build)
+        rows = hip.embed_bias(condition.float(), p["w_embed"], normalize)          # [B, M]
+        term = hip.pad_rows(rows.t().unsqueeze(0))                                  # [1, M, ldB]
+        if self._per_frame is None or self._per_frame.shape != term.shape or self._per_frame.device != term.device:
+            self._per_frame = term
+        else:
+            self._per_frame.copy_(term)
 
     def _embed_term(self, condition: torch.Tensor, w_embed: torch.Tensor, normalize: bool, per_frame: bool):
         """-> (bias_n, res) for ps_conv1x1_f32."""
         if not per_frame:
             return hip.embed_bias(condition.float(), w_embed, normalize), None
         if self._per_frame is None:
-            rows = hip.embed_bias(condition.float(), w_embed, normalize)      # [B, M]
-            self._per_frame = hip.pad_rows(rows.t().unsqueeze(0))              # [1, M, ldB]
+            raise RuntimeError("per-frame conditioning was not initialised (set_per_frame_condition)")
         return None, self._per_frame
 
 

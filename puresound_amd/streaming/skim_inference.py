@@ -13,6 +13,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from .. import hip
+from ..nnet._plans import lstm_path
 from ..nnet.skim import SkiM
 
 
@@ -89,6 +90,9 @@ class StreamingSkiM(SkiM):
         self._x_in = z(self.input_size)
         self._embed_key = None
         self._embed_static = None
+        for m in getattr(self, "seg_input_fusion", []):
+            if m is not None:
+                m._per_frame = None
         self._graph = None
         self._use_graph = use_graph
         self._out = None
@@ -129,7 +133,6 @@ class StreamingSkiM(SkiM):
                 cur = self.seg_input_fusion[i].forward_padded(cur, b, self._embed_static, self.embed_norm,
                                                               per_frame=True)
             p = self.seg_lstm[i]._plan_get(cur.device, self.seg_lstm[i]._build)
-            from ..nnet._plans import lstm_path
             cur, _ = lstm_path(cur, b, *p, q=b, q_stride=1, steps=1, step_stride=0, h0=self._seg_h[i],
                                c0=self._seg_c[i], state_out=(self._seg_h[i], self._seg_c[i]))
         return self._output(cur, b)
@@ -153,7 +156,7 @@ class StreamingSkiM(SkiM):
                 self._embed_key = key
                 for m in getattr(self, "seg_input_fusion", []):
                     if m is not None:
-                        m.invalidate_per_frame()
+                        m.set_per_frame_condition(self._embed_static, self.embed_norm)
         elif self._embed_static is not None:
             raise RuntimeError("step_frame: the stream was started with an embedding; keep passing it")
         if not self._use_graph:
