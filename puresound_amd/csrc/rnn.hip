@@ -139,6 +139,320 @@ __global__ __launch_bounds__(WREG ? 256 : 1024) void lstm_kernel(LstmK k) {
   }
 }
 
+// ---- MFMA recurrence for H = 64 / 128 ----------------------------------------------------------------------------
+// One workgroup owns 16 sequences (flat index b = n*Q + q, so a group may span two utterances) and H/16 waves; wave
+// w owns hidden units [16w, 16w+16) and ALL FOUR gates of them, so the cell update needs no exchange:
+//   D_g[unit][seq] = gx_g + W_hh,g[16 units x H] * h[H x 16 seqs]      g = i, f, g, o
+// as 4 x H/4 v_mfma_f32_16x16x4_f32 per step with W_hh resident in VGPRs as A fragments.  C/D layout: lane (seq =
+// lane&15, quad = lane>>4) holds units 4*quad + r of its wave in register r -- the same (unit, seq) position in all four
+// gate accumulators -- so c, h stay in registers.  h' goes through LDS once per step ([k-block][quad][seq], written
+// and read conflict-free) to become everybody's B fragments; the k axis is walked in the order (wave, r, quad) the
+// producers hold it in, with W_hh's fragments loaded in the same order.
+template <int H>
+struct LstmMfma {
+  static constexpr int NW = H / 16;  // waves
+  static constexpr int KB = H / 4;   // k-blocks of 4
+  static constexpr int PF = H == 64 ? 4 : 2;
+};
+
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
+}
+
+template <int H, bool CONTIG>
+__global__ __launch_bounds__(H * 4) void lstm_mfma_kernel(LstmK k) {
+  using P = LstmMfma<H>;
+  constexpr int KB = P::KB, PF = CONTIG ? 4 : P::PF;
+  __shared__ float hbuf[2][H * 16];
+  const ps_lstm_args& a = k.a;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = lane & 15, quad = lane >> 4;
+  const int d = blockIdx.z;
+  const int b = blockIdx.x * 16 + col;
+  const bool valid = b < a.N * a.Q;
+  const int n = valid ? b / a.Q : 0, q = valid ? b % a.Q : 0;
+  const int G = 4 * H;
+  const int unit0 = 16 * w + 4 * quad;  // first of this lane's 4 units
+
+  // A fragments: gate g, k-block kb = (w', r'): A[row = lane&15][k = 16w' + 4*quad + r']
+  float wf[4][KB];
+  {
+    const float* wt = a.whh_t + (size_t)d * H * G;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int kk = 16 * (kb >> 2) + 4 * quad + (kb & 3);
+        wf[g][kb] = wt[(size_t)kk * G + g * H + 16 * w + col];
+      }
+  }
+
+  float c[4] = {0.f, 0.f, 0.f, 0.f}, h[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid && (a.h0 || a.c0)) {
+    const int bs = b - a.state_shift;
+    if (bs >= 0) {
+      const int nn = bs / a.Q, qq = bs % a.Q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t off = ((size_t)(nn * a.D + d) * H + unit0 + r) * a.ldq + qq;
+        if (a.h0) h[r] = a.h0[off];
+        if (a.c0) c[r] = a.c0[off];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) hbuf[0][((w * 4 + r) * 4 + quad) * 16 + col] = h[r];
+
+  const float* gp = a.gx + ((size_t)(n * a.D + d) * G + unit0) * a.ldt + (size_t)q * a.q_stride;
+  float* hp = a.hout + ((size_t)(n * a.D + d) * H + unit0) * a.ldt + (size_t)q * a.q_stride;
+  const int steps = a.steps;
+  const bool rev = d == 1;
+  const size_t ldt = a.ldt;
+
+  // pre[u][g][r]: gate pre-activations of the step in ring slot u.  CONTIG (steps are consecutive frames, 16-byte
+  // aligned groups of 4): one 16-byte load per (gate, unit) fetches a whole group of 4 steps, the next group is in
+  // flight while this one is consumed, and h' leaves as 16-byte stores; otherwise scalar loads PF steps ahead.
+  float pre[PF][4][4];
+  f32x4 nxt[4][4];
+  auto load_group = [&](int s0) {  // CONTIG: steps s0 .. s0+3 -> nxt
+    const int f0 = rev ? steps - 4 - s0 : s0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        nxt[g][r] = (valid && s0 < steps) ? *reinterpret_cast<const f32x4*>(gp + (size_t)(g * H + r) * ldt + f0)
+                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto take_group = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pre[u][g][r] = rev ? nxt[g][r][3 - u] : nxt[g][r][u];
+  };
+  if constexpr (CONTIG) {
+    load_group(0);
+  } else {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int ts = rev ? steps - 1 - u : u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          pre[u][g][r] = (valid && u < steps) ? gp[(size_t)(g * H + r) * ldt + (size_t)ts * a.step_stride] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  for (int s0 = 0; s0 < steps; s0 += PF) {
+    float hst[4][4];  // CONTIG: h' of the group, [r][u]
+    if constexpr (CONTIG) {
+      take_group();
+      load_group(s0 + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int s = s0 + u;
+      if (s < steps) {  // uniform
+        const float* hb = hbuf[s & 1];
+        float bf[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) bf[kb] = hb[kb * 64 + lane];
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{pre[u][g][0], pre[u][g][1], pre[u][g][2], pre[u][g][3]};
+        if constexpr (!CONTIG) {  // refill the ring slot with step s + PF
+          const int sn = s + PF;
+          const int ts = rev ? steps - 1 - sn : sn;
+          if (sn < steps) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                pre[u][g][r] = valid ? gp[(size_t)(g * H + r) * ldt + (size_t)ts * a.step_stride] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][kb], bf[kb], acc[g], 0, 0, 0);
+        float* hn = hbuf[(s + 1) & 1];
+        const int ts = rev ? steps - 1 - s : s;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gi = fast_sigmoid(acc[0][r]);
+          const float gf = fast_sigmoid(acc[1][r]);
+          const float gg = fast_tanh(acc[2][r]);
+          const float go = fast_sigmoid(acc[3][r]);
+          c[r] = gf * c[r] + gi * gg;
+          h[r] = go * fast_tanh(c[r]);
+          hn[((w * 4 + r) * 4 + quad) * 16 + col] = h[r];
+          if constexpr (CONTIG) {
+            hst[r][rev ? 3 - u : u] = h[r];
+          } else {
+            if (valid) hp[(size_t)r * ldt + (size_t)ts * a.step_stride] = h[r];
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if constexpr (CONTIG) {
+      if (valid) {
+        const int f0 = rev ? steps - 4 - s0 : s0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<f32x4*>(hp + (size_t)r * ldt + f0) = f32x4{hst[r][0], hst[r][1], hst[r][2], hst[r][3]};
+      }
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t off = ((size_t)(n * a.D + d) * H + unit0 + r) * a.ldq + q;
+      if (a.h_last) a.h_last[off] = h[r];
+      if (a.c_last) a.c_last[off] = c[r];
+    }
+  }
+}
+
+// ---- 4-sequence MFMA recurrence (v_mfma_f32_4x4x1_16B_f32) -------------------------------------------------------
+// For passes with few, long sequences (the inter-segment pass: N*K sequences of S steps) the 16-sequence kernel above
+// leaves most CUs idle and walks the steps at ~2 us each.  Here a workgroup owns only 4 sequences.  The instruction
+// multiplies 16 independent 4x4 blocks: block = hidden unit (16 per wave), block row = gate (i, f, g, o), block column
+// = sequence, K = 1 per issue, so lane (unit b, sequence j) receives the four gate pre-activations of ITS (unit,
+// sequence) in the four result registers and does the cell update alone.  A = W_hh[gate][unit][k] resident (H VGPRs),
+// B = h[k][sequence] broadcast from LDS.  Four independent accumulators hide the dependent-issue latency.
+template <int H, bool CONTIG>
+__global__ __launch_bounds__(H * 4) void lstm_m4_kernel(LstmK k) {
+  constexpr int HS = H + 16;  // LDS row stride: conflict-free h' writes
+  constexpr int PF = CONTIG ? 4 : 8;
+  __shared__ __attribute__((aligned(16))) float hbuf[2][4 * HS];
+  const ps_lstm_args& a = k.a;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = lane & 3, ub = lane >> 2;
+  const int unit = 16 * w + ub;
+  const int d = blockIdx.z;
+  const int b = blockIdx.x * 4 + j;
+  const bool valid = b < a.N * a.Q;
+  const int n = valid ? b / a.Q : 0, q = valid ? b % a.Q : 0;
+  const int G = 4 * H;
+
+  // A operand: lane (unit, i = lane&3) holds W_hh[gate i][unit][k]
+  float wf[H];
+  {
+    const float* wt = a.whh_t + (size_t)d * H * G + j * H + unit;
+#pragma unroll
+    for (int kk = 0; kk < H; ++kk) wf[kk] = wt[(size_t)kk * G];
+  }
+
+  float c = 0.f, h = 0.f;
+  if (valid && (a.h0 || a.c0)) {
+    const int bs = b - a.state_shift;
+    if (bs >= 0) {
+      const int nn = bs / a.Q, qq = bs % a.Q;
+      const size_t off = ((size_t)(nn * a.D + d) * H + unit) * a.ldq + qq;
+      if (a.h0) h = a.h0[off];
+      if (a.c0) c = a.c0[off];
+    }
+  }
+  hbuf[0][j * HS + unit] = h;
+
+  const float* gp = a.gx + ((size_t)(n * a.D + d) * G + unit) * a.ldt + (size_t)q * a.q_stride;
+  float* hp = a.hout + ((size_t)(n * a.D + d) * H + unit) * a.ldt + (size_t)q * a.q_stride;
+  const int steps = a.steps;
+  const bool rev = d == 1;
+  const size_t gstride = (size_t)H * a.ldt;  // between the gates of one unit
+
+  float pre[PF][4];
+  f32x4 nxt[4];
+  auto load_group = [&](int s0) {  // CONTIG: steps s0 .. s0+3 of every gate -> nxt
+    const int f0 = rev ? steps - 4 - s0 : s0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      nxt[g] = (valid && s0 < steps) ? *reinterpret_cast<const f32x4*>(gp + g * gstride + f0)
+                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  if constexpr (CONTIG) {
+    load_group(0);
+  } else {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int ts = rev ? steps - 1 - u : u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        pre[u][g] = (valid && u < steps) ? gp[g * gstride + (size_t)ts * a.step_stride] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  for (int s0 = 0; s0 < steps; s0 += PF) {
+    float hst[4];
+    if constexpr (CONTIG) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[u][g] = rev ? nxt[g][3 - u] : nxt[g][u];
+      load_group(s0 + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int s = s0 + u;
+      if (s < steps) {  // uniform
+        const float* hb = hbuf[s & 1] + j * HS;
+        f32x4 acc[4];
+        acc[0] = f32x4{pre[u][0], pre[u][1], pre[u][2], pre[u][3]};
+        acc[1] = acc[2] = acc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!CONTIG) {
+          const int sn = s + PF;
+          const int ts = rev ? steps - 1 - sn : sn;
+          if (sn < steps) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[u][g] = valid ? gp[g * gstride + (size_t)ts * a.step_stride] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < H / 4; ++kk) {
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(hb + 4 * kk);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[4 * kk + e], hv[e], acc[e], 0, 0, 0);
+        }
+        const f32x4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        const float gi = fast_sigmoid(t[0]);
+        const float gf = fast_sigmoid(t[1]);
+        const float gg = fast_tanh(t[2]);
+        const float go = fast_sigmoid(t[3]);
+        c = gf * c + gi * gg;
+        h = go * fast_tanh(c);
+        hbuf[(s + 1) & 1][j * HS + unit] = h;
+        if constexpr (CONTIG) {
+          hst[rev ? 3 - u : u] = h;
+        } else {
+          const int ts = rev ? steps - 1 - s : s;
+          if (valid) hp[(size_t)ts * a.step_stride] = h;
+        }
+        __syncthreads();
+      }
+    }
+    if constexpr (CONTIG) {
+      if (valid) {
+        const int f0 = rev ? steps - 4 - s0 : s0;
+        *reinterpret_cast<f32x4*>(hp + f0) = f32x4{hst[0], hst[1], hst[2], hst[3]};
+      }
+    }
+  }
+  if (valid) {
+    const size_t off = ((size_t)(n * a.D + d) * H + unit) * a.ldq + q;
+    if (a.h_last) a.h_last[off] = h;
+    if (a.c_last) a.c_last[off] = c;
+  }
+}
+
 // ---- LayerNorm over channels ---------------------------------------------------------------------------------
 struct ClnArgs {
   const float* x;
@@ -248,6 +562,34 @@ extern "C" int ps_lstm_f32(const ps_lstm_args* args, void* stream) {
   const int threads = (4 * a.H + 63) / 64 * 64;
   const size_t lds = (size_t)5 * a.H * sizeof(f32x4);
   dim3 grid((a.Q + LS - 1) / LS, a.N, a.D);
+  if ((a.H == 64 || a.H == 128) && !(g_debug_flags & 2)) {
+    const long long seqs = (long long)a.N * a.Q;
+    const bool contig = a.step_stride == 1 && a.steps % 4 == 0 && a.q_stride % 4 == 0 && a.ldt % 4 == 0 &&
+                        !((uintptr_t)a.gx & 15) && !((uintptr_t)a.hout & 15);
+    // 16 sequences per workgroup when there are enough sequences to fill the chip that way (debug bit 2 / 3 force one)
+    const bool wide = (g_debug_flags & 4) ? true : (g_debug_flags & 8) ? false : (a.H == 64 && contig && seqs >= 16 * 256);
+    LaunchTimer timer("lstm", (hipStream_t)stream);
+    if (wide) {
+      dim3 mgrid((unsigned)((seqs + 15) / 16), 1, a.D);
+      if (a.H == 64 && contig)
+        hipLaunchKernelGGL((lstm_mfma_kernel<64, true>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
+      else if (a.H == 64)
+        hipLaunchKernelGGL((lstm_mfma_kernel<64, false>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
+      else  // H = 128: the 16-byte group path does not fit the 256-VGPR budget of 8 waves
+        hipLaunchKernelGGL((lstm_mfma_kernel<128, false>), mgrid, dim3(512), 0, (hipStream_t)stream, k);
+    } else {
+      dim3 mgrid((unsigned)((seqs + 3) / 4), 1, a.D);
+      if (a.H == 64 && contig)
+        hipLaunchKernelGGL((lstm_m4_kernel<64, true>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
+      else if (a.H == 64)
+        hipLaunchKernelGGL((lstm_m4_kernel<64, false>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
+      else if (contig)
+        hipLaunchKernelGGL((lstm_m4_kernel<128, true>), mgrid, dim3(512), 0, (hipStream_t)stream, k);
+      else
+        hipLaunchKernelGGL((lstm_m4_kernel<128, false>), mgrid, dim3(512), 0, (hipStream_t)stream, k);
+    }
+    return launch_status("ps_lstm_f32");
+  }
   {
     LaunchTimer timer("lstm", (hipStream_t)stream);
     if (a.H <= LSTM_WREG)

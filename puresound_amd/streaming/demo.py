@@ -1,0 +1,125 @@
+"""Streaming TSE harness on the HIP path (mirror of DemoTseNet, egs/tse/demo/utils.py:47-128 of mcw519/PureSound),
+for B concurrent streams.
+
+Per 16-sample hop and stream: slide a 32-sample window, encode it to one frame, run one masker frame step, multiply,
+decode the frame back to 32 samples, average the overlapping 16 samples with the previous output.  The B windows
+are laid side by side as ONE signal [1, B*32] framed with hop = win = 32, so the encoder kernel emits the frame
+axis = stream axis layout [1][C][ldB] the streaming masker works on, and the decoder kernel (hop = win: no
+overlap) returns [1, B*32] = one 32-sample frame per stream.  encoder -> masker step -> mask -> decoder is one
+hipGraph, replayed per hop.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import hip
+from ..nnet.lobe.encoder import FreeEncDec
+from .skim_inference import StreamingSkiM
+
+
+def overlap_add(a: Optional[torch.Tensor], b: torch.Tensor, overlap_length: int) -> torch.Tensor:
+    """egs/tse/demo/utils.py:121-128, on the last axis: the overlapped samples are averaged."""
+    if a is None:
+        return b
+    return torch.cat([a[..., :-overlap_length], (a[..., -overlap_length:] + b[..., :overlap_length]) / 2,
+                      b[..., overlap_length:]], dim=-1)
+
+
+class DemoTseNet(nn.Module):
+    """Encoder + streaming masker of the demo preset (utils.py:47-72)."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.encoder = FreeEncDec(win_length=32, hop_length=16, laten_length=128, output_active=True)
+        self.masker = StreamingSkiM(input_size=128, hidden_size=256, output_size=128, n_blocks=4, seg_size=150,
+                                    seg_overlap=False, causal=True, embed_dim=192, embed_norm=True,
+                                    block_with_embed=[1, 1, 1, 1], embed_fusion="FiLM")
+        self.training = False
+        self.queue = None
+        self.win_size = 32
+        self.hop_size = 16
+        self.ola_size = int(self.win_size - self.hop_size)
+        self._graph = None
+
+    def forward(self, noisy: torch.Tensor, embed: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def init_streams(self, streams: int = 1, use_graph: bool = True) -> None:
+        """Reset the sliding windows and the masker state for `streams` concurrent streams."""
+        self.queue = None
+        self._graph = None
+        self._use_graph = use_graph
+        self.masker.init_status(streams=streams, use_graph=False)   # this harness captures the whole hop itself
+
+    def _hop_body(self):
+        m = self.masker
+        b = m.streams
+        wav = self.queue.reshape(1, b * self.win_size)
+        feats, _ = hip.free_encode(wav, self.encoder.encoder.weight.detach(), self.win_size, True)   # [1, C, ldB]
+        m._x_in = feats
+        mask = m._frame_body()                                                                        # [1, C, ldB]
+        out = hip.free_decode(feats, b, self.encoder.decoder.weight.detach(), self.win_size, mask, "linear", "none")
+        return out.reshape(b, self.win_size)
+
+    @torch.no_grad()
+    def streaming_inference(self, chunk: torch.Tensor, embed: torch.Tensor) -> Optional[torch.Tensor]:
+        """chunk [B,16] new samples per stream, embed [B,E] (or [E]) -> decoded frame [B,32]; None on the first hop
+        (utils.py:78-98)."""
+        hip.require_device(chunk, "DemoTseNet.streaming_inference")
+        if embed.dim() == 1:
+            embed = embed.unsqueeze(0)
+        m = self.masker
+        if not hasattr(m, "streams"):
+            self.init_streams(chunk.shape[0])
+        if self.queue is None:
+            self.queue = torch.cat([torch.zeros_like(chunk), chunk], dim=-1).float().contiguous()
+            return None
+        self.queue[:, :self.hop_size] = self.queue[:, self.hop_size:].clone()
+        self.queue[:, self.hop_size:] = chunk
+        # embedding terms of the FiLM layers: refreshed in place when the embeddings change
+        key = (embed.data_ptr(), embed._version, tuple(embed.shape))
+        if key != m._embed_key:
+            if m._embed_static is None:
+                m._embed_static = embed.detach().reshape(m.streams, -1).float().clone()
+            else:
+                m._embed_static.copy_(embed.reshape(m.streams, -1))
+            m._embed_key = key
+            for f in m.seg_input_fusion:
+                if f is not None:
+                    f.set_per_frame_condition(m._embed_static, m.embed_norm)
+        if not self._use_graph:
+            gen = self._hop_body()
+        else:
+            if self._graph is None:
+                saved = [t.clone() for t in m._seg_h + m._seg_c]
+                s = torch.cuda.Stream(chunk.device)
+                s.wait_stream(torch.cuda.current_stream(chunk.device))
+                with torch.cuda.stream(s):
+                    self._hop_body()
+                torch.cuda.current_stream(chunk.device).wait_stream(s)
+                for t, v in zip(m._seg_h + m._seg_c, saved):
+                    t.copy_(v)
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._gen = self._hop_body()
+                for t, v in zip(m._seg_h + m._seg_c, saved):
+                    t.copy_(v)
+            self._graph.replay()
+            gen = self._gen
+        m.frames_counter += 1
+        if m.frames_counter % m.seg_size == 0:
+            m.update_mem_lstm()
+            m.reset_seg_lstm_status()
+            m.frames_counter = 0
+        return gen.clone()
+
+    @torch.no_grad()
+    def streaming_inference_chunk(self, chunk: torch.Tensor, embed: torch.Tensor,
+                                  pre_wav: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """chunk [B, n*16] -> the running output [B, L] (utils.py:100-118)."""
+        for i in range(chunk.shape[-1] // self.hop_size):
+            cur = self.streaming_inference(chunk[:, i * self.hop_size:(i + 1) * self.hop_size], embed)
+            if cur is not None:
+                pre_wav = overlap_add(pre_wav, cur, self.ola_size)
+        return pre_wav

@@ -485,11 +485,11 @@ def _lstm_sd(inp, hid, bi, seed):
 
 
 @pytest.mark.parametrize("hid,bi,mode", [(8, False, "intra"), (8, True, "inter"), (64, False, "inter"),
-                                         (64, True, "intra"), (20, False, "intra"), (80, True, "inter"),
+                                         (64, True, "intra"), (20, False, "intra"), (80, True, "inter"), (128, True, "inter"), (128, False, "intra"),
                                          (256, False, "intra")])
 def test_lstm_kernel(H, dev, hid, bi, mode):
     from puresound_amd.nnet._plans import lstm_plan
-    n, c, k, s = 2, 12, 5, 7
+    n, c, k, s = (2, 12, 5, 7) if hid not in (64, 128) or mode == "inter" else (2, 12, 8, 9)
     m, sd = _lstm_sd(c, hid, bi, 60)
     x = _rand((n, c, s * k), 61)
     d = 2 if bi else 1
@@ -506,13 +506,23 @@ def test_lstm_kernel(H, dev, hid, bi, mode):
     t = s * k
     gx, _ = H.conv1x1(H.pad_rows(x.to(dev)), t, p["wih"], p["rows"], None, p["bias"])
     to_state = lambda v: H.pad_rows(v.reshape(d, n, q, hid).permute(1, 0, 3, 2).reshape(n, d * hid, q).to(dev))  # noqa: E731
-    hout, (hl, cl) = H.lstm(gx, p["whh_t"], hid, d, q, qs, steps, ss, to_state(h0), to_state(c0), want_state=True)
-    got = hout[..., :t].cpu().transpose(1, 2).reshape(n, s, k, d * hid)
-    got = got.reshape(n * s, k, -1) if mode == "intra" else got.permute(0, 2, 1, 3).reshape(n * k, s, -1)
-    assert rel_max(got.numpy(), ref.numpy()) < 2e-5
     back = lambda v: v[..., :q].cpu().reshape(n, d, hid, q).permute(1, 0, 3, 2).reshape(d, n * q, hid)  # noqa: E731
-    assert rel_max(back(hl).numpy(), hn.numpy()) < 2e-5
-    assert rel_max(back(cl).numpy(), cn.numpy()) < 2e-5
+    # debug flags pick the kernel variant for H = 64 / 128: 0 = by shape, 4 = 16 sequences per workgroup
+    # (16x16x4 MFMA), 8 = 4 sequences per workgroup (4x4x1 MFMA), 2 = the generic VALU kernel
+    from puresound_amd import _abi
+    for flags in ((0, 4, 8, 2) if hid in (64, 128) else (0,)):
+        old = _abi.lib().ps_debug_flags(flags)
+        try:
+            hout, (hl, cl) = H.lstm(gx, p["whh_t"], hid, d, q, qs, steps, ss, to_state(h0), to_state(c0),
+                                    want_state=True)
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
+        got = hout[..., :t].cpu().transpose(1, 2).reshape(n, s, k, d * hid)
+        got = got.reshape(n * s, k, -1) if mode == "intra" else got.permute(0, 2, 1, 3).reshape(n * k, s, -1)
+        assert rel_max(got.numpy(), ref.numpy()) < 2e-5, flags
+        assert rel_max(back(hl).numpy(), hn.numpy()) < 2e-5, flags
+        assert rel_max(back(cl).numpy(), cn.numpy()) < 2e-5, flags
 
 
 @pytest.mark.parametrize("n,c,t", [(2, 16, 77), (1, 128, 300), (2, 512, 65)])
@@ -605,3 +615,37 @@ def test_streaming_skim_matches_reference_golden(PA, dev, golden_dir, name):
     st = DP.SkimStream(det_state_dict(model), "", cases.rnn_args(c), streams=b)
     ref = torch.cat([st.step_frame(xs[..., f].cpu().reshape(b, 1, -1), ds.cpu()) for f in range(n_f)], -1)
     assert rel_max(yb.cpu().numpy(), ref.numpy()) < TOL
+
+
+def test_demo_harness_matches_reference_golden(dev, golden_dir):
+    """DemoTseNet.streaming_inference_chunk (egs/tse/demo/utils.py:78-128) on three 320-sample chunks."""
+    from puresound_amd.streaming.demo import DemoTseNet
+    name = "cfg5_demo"
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    h = c["harness"]
+    net = DemoTseNet().eval()
+    sd = det_state_dict(net)
+    assert sum(v.numel() for v in sd.values()) == int(g["harness_n_params"])
+    net.load_state_dict(sd)
+    net.to(dev)
+    wav = det_wave(c["seed"] + 200, 1, h["chunks"] * h["chunk"])
+    d = torch.tensor(g["embed"]).to(dev)
+    for use_graph in (False, True):
+        net.init_streams(1, use_graph=use_graph)
+        pre = None
+        for i in range(h["chunks"]):
+            pre = net.streaming_inference_chunk(wav[:, i * h["chunk"]:(i + 1) * h["chunk"]].to(dev), d[0], pre)
+        assert pre.shape[-1] == g["harness_wav"].shape[-1]
+        assert rel_max(pre[0].cpu().numpy(), g["harness_wav"]) < TOL, use_graph
+    # 4 streams: stream 2 carries the fixture's audio and embedding
+    b = 4
+    wavs = det_wave(77, b, h["chunks"] * h["chunk"])
+    wavs[2] = wav[0]
+    ds = torch.rand(b, 192, generator=torch.Generator().manual_seed(5))
+    ds[2] = torch.tensor(g["embed"])[0]
+    net.init_streams(b)
+    pre = None
+    for i in range(h["chunks"]):
+        pre = net.streaming_inference_chunk(wavs[:, i * h["chunk"]:(i + 1) * h["chunk"]].to(dev), ds.to(dev), pre)
+    assert rel_max(pre[2].cpu().numpy(), g["harness_wav"]) < TOL
