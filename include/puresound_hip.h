@@ -53,7 +53,7 @@ const char* ps_last_error(void);
  * library is bracketed by hipEvents on the launch stream.  ps_profile_enable(1) clears old records.
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
- * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "chan_layernorm",
+ * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm",
  * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
@@ -199,6 +199,13 @@ typedef struct {
   int N, H, D, Q, q_stride, steps, step_stride, ldt, ldq, state_shift;
 } ps_lstm_args;
 int ps_lstm_f32(const ps_lstm_args* args, void* stream);
+
+/* One cell update per (unit, frame) from COMPLETE gate pre-activations gates [N][D*4H][ld_gates] (W_ih x + W_hh h + both
+ * biases: the streaming step puts [x; h] on the K axis of one ps_conv1x1_f32):  c' = sig(f) c + sig(i) tanh(g) in
+ * place in c [N][D*H][ld_state], h' = sig(o) tanh(c') into h [N][D*H][ld_state].  (SegLSTM with a one-frame
+ * sequence, streaming/skim_inference.py:198-207.) */
+int ps_lstm_cell_f32(const float* gates, float* c, float* h, int N, int H, int D, int T, int ld_gates, int ld_state,
+                     void* stream);
 
 /* y = [res +] [mul *] act( LN_C(x) * gamma + beta ): statistics over the C channels of each frame, biased two-pass
  * variance, 1/sqrt(var + eps).  nn.LayerNorm(C) on [.., C] rows (eps 1e-5; dprnn.py:157,171, skim.py:85-98,226,

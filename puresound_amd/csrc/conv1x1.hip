@@ -609,6 +609,31 @@ extern "C" int ps_conv1x1_f32(const float* x, const float* wt, float* y, int N, 
     set_error("ps_conv1x1_f32: residual and output statistics cannot be combined (no Conv-TasNet stage needs both)");
     return PS_E_UNSUPPORTED;
   }
+  if (pro) {
+    if (pro->norm == PS_NORM_GLOBAL && (!pro->stats || pro->parts <= 0 || pro->count <= 0 || !pro->gamma ||
+                                        !pro->beta)) {
+      set_error("ps_conv1x1_f32: PS_NORM_GLOBAL prologue needs stats/parts/count/gamma/beta");
+      return PS_E_INVALID;
+    }
+    if (pro->norm == PS_NORM_AFFINE && (!pro->gamma || !pro->beta)) {
+      set_error("ps_conv1x1_f32: PS_NORM_AFFINE prologue needs gamma/beta");
+      return PS_E_INVALID;
+    }
+    if (pro->prelu && !pro->slope) {
+      set_error("ps_conv1x1_f32: prelu prologue needs slope");
+      return PS_E_INVALID;
+    }
+  }
+  // short rows (streaming step, state rows): channel-split kernel instead of 256 x 128 tiles (debug bit 4 = off)
+  if (T <= 64 && !ostats && !(pro && pro->norm == PS_NORM_GLOBAL) && !(g_debug_flags & 16)) {
+    conv1x1_small_launch(x, wt, y, N, K, M, T, ldt, pro, bias, bias_n, res, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      set_error("ps_conv1x1_f32: launch failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    return 0;
+  }
   Conv1x1Args a{};
   a.x = x;
   a.wt = wt;

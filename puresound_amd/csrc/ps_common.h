@@ -73,6 +73,11 @@ __device__ __forceinline__ NormScalars load_norm_scalars(const ps_prologue& p, i
   return s;
 }
 
+// conv1x1_small.hip: rows of at most 64 frames (no global-norm prologue, no statistics); enqueue only
+int conv1x1_small_launch(const float* x, const float* wt, float* y, int N, int K, int M, int T, int ldt,
+                         const ps_prologue* pro, const float* bias, const float* bias_n, const float* res,
+                         hipStream_t stream);
+
 __device__ __forceinline__ float prelu(float v, float slope) { return v >= 0.f ? v : slope * v; }
 
 }  // namespace ps

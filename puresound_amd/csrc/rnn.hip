@@ -469,30 +469,37 @@ struct ClnArgs {
 
 // 64 frames x 4 channel quarters per workgroup; three passes over the (L1/L2 resident) 64 x C tile: mean,
 // centred second moment (the reference's two-pass variance), normalise + epilogue.
-__global__ __launch_bounds__(256) void chan_layernorm_kernel(ClnArgs a) {
-  __shared__ float red[4][64];
+template <int PARTS>
+__global__ __launch_bounds__(64 * PARTS) void chan_layernorm_kernel(ClnArgs a) {
+  __shared__ float red[PARTS][64];
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + lane, n = blockIdx.y;
   const bool live = t < a.T;
   const size_t base = (size_t)n * a.C * a.ldt + (live ? t : 0);
   float s = 0.f;
-  for (int ch = part; ch < a.C; ch += 4) s += live ? a.x[base + (size_t)ch * a.ldt] : 0.f;
+  for (int ch = part; ch < a.C; ch += PARTS) s += live ? a.x[base + (size_t)ch * a.ldt] : 0.f;
   red[part][lane] = s;
   __syncthreads();
-  const float mean = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (float)a.C;
+  float tot = 0.f;
+#pragma unroll
+  for (int p = 0; p < PARTS; ++p) tot += red[p][lane];
+  const float mean = tot / (float)a.C;
   __syncthreads();
   float q = 0.f;
-  for (int ch = part; ch < a.C; ch += 4) {
+  for (int ch = part; ch < a.C; ch += PARTS) {
     const float dv = live ? a.x[base + (size_t)ch * a.ldt] - mean : 0.f;
     q += dv * dv;
   }
   red[part][lane] = q;
   __syncthreads();
-  const float var = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (float)a.C;
+  tot = 0.f;
+#pragma unroll
+  for (int p = 0; p < PARTS; ++p) tot += red[p][lane];
+  const float var = tot / (float)a.C;
   const float rstd = 1.f / sqrtf(var + a.eps);
   if (!live) return;
   const float slope = a.slope ? a.slope[0] : 1.f;
-  for (int ch = part; ch < a.C; ch += 4) {
+  for (int ch = part; ch < a.C; ch += PARTS) {
     const size_t off = base + (size_t)ch * a.ldt;
     float v = (a.x[off] - mean) * rstd * a.gamma[ch] + a.beta[ch];
     if (a.slope) v = prelu(v, slope);
@@ -501,6 +508,25 @@ __global__ __launch_bounds__(256) void chan_layernorm_kernel(ClnArgs a) {
     if (a.res) v += a.res[off];
     a.y[off] = v;
   }
+}
+
+// One LSTM cell update per (unit, frame) from complete gate pre-activations (the streaming step: the recurrent
+// product W_hh h is part of the gates GEMM there, its K axis being [x; h]).
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ gates, float* __restrict__ c,
+                                                        float* __restrict__ h, int H, int T, int ldg, int lds_) {
+  const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int nd = blockIdx.z;  // utterance * directions + direction
+  if (t >= T || j >= H) return;
+  const float* g = gates + ((size_t)nd * 4 * H + j) * ldg + t;
+  const size_t so = ((size_t)nd * H + j) * lds_ + t;
+  const float gi = sigmoidf_(g[0]);
+  const float gf = sigmoidf_(g[(size_t)H * ldg]);
+  const float gg = tanhf(g[(size_t)2 * H * ldg]);
+  const float go = sigmoidf_(g[(size_t)3 * H * ldg]);
+  const float cn = gf * c[so] + gi * gg;
+  c[so] = cn;
+  h[so] = go * tanhf(cn);
 }
 
 __global__ __launch_bounds__(256) void film_apply_kernel(const float* __restrict__ x, const float* __restrict__ sb,
@@ -610,7 +636,11 @@ extern "C" int ps_chan_layernorm_f32(const float* x, const float* gamma, const f
   ClnArgs a{x, gamma, beta, res, prelu_slope, mul, y, eps, sigmoid, C, T, ldt};
   {
     LaunchTimer timer("chan_layernorm", (hipStream_t)stream);
-    hipLaunchKernelGGL(chan_layernorm_kernel, dim3((T + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, a);
+    // few frames (streaming step, state rows): split the channels 16 ways instead of 4 to shorten the serial walk
+    if ((long long)((T + 63) / 64) * N < 64)
+      hipLaunchKernelGGL((chan_layernorm_kernel<16>), dim3((T + 63) / 64, N), dim3(1024), 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((chan_layernorm_kernel<4>), dim3((T + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, a);
   }
   return launch_status("ps_chan_layernorm_f32");
 }
@@ -631,4 +661,19 @@ extern "C" int ps_film_apply_f32(const float* x, const float* scale_bias, float*
                        scale_bias, y, C, T, ldt);
   }
   return launch_status("ps_film_apply_f32");
+}
+
+extern "C" int ps_lstm_cell_f32(const float* gates, float* c, float* h, int N, int H, int D, int T, int ld_gates,
+                                int ld_state, void* stream) {
+  if (!gates || !c || !h || N <= 0 || H <= 0 || D < 1 || D > 2 || T <= 0 || ld_gates < T || ld_state < T ||
+      (long long)N * D > 65535) {
+    set_error("ps_lstm_cell_f32: bad argument (N=%d H=%d D=%d T=%d)", N, H, D, T);
+    return PS_E_INVALID;
+  }
+  {
+    LaunchTimer timer("lstm_cell", (hipStream_t)stream);
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3((T + 63) / 64, (H + 3) / 4, N * D), dim3(256), 0, (hipStream_t)stream,
+                       gates, c, h, H, T, ld_gates, ld_state);
+  }
+  return launch_status("ps_lstm_cell_f32");
 }

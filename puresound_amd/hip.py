@@ -185,7 +185,7 @@ def lstm(gx: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int, q: int, 
     n, rows, ldt = gx.shape
     if rows != dirs * 4 * hidden or tuple(whh_t.shape) != (dirs, hidden, 4 * hidden):
         raise RuntimeError("lstm: gx must be [N, D*4H, ldt] and whh_t [D, H, 4H]")
-    hout = torch.zeros(n, dirs * hidden, ldt, dtype=torch.float32, device=gx.device)
+    hout = torch.empty(n, dirs * hidden, ldt, dtype=torch.float32, device=gx.device)
     a = LstmArgs()
     a.gx, a.whh_t, a.hout = ptr(gx), ptr(whh_t), ptr(hout)
     ldq = padded_frames(q)
@@ -216,23 +216,37 @@ def lstm(gx: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int, q: int, 
 
 def chan_layernorm(x: torch.Tensor, t: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
                    res: Optional[torch.Tensor] = None, slope: Optional[torch.Tensor] = None, sigmoid: bool = False,
-                   mul: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   mul: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[res +] [mul *] act(LN over channels of every frame) on padded [N,C,ldt]."""
     require_device(x, "chan_layernorm")
     n, c, ldt = x.shape
-    y = torch.zeros_like(x)
+    y = out if out is not None else torch.empty_like(x)
     check(lib().ps_chan_layernorm_f32(ptr(x), ptr(gamma), ptr(beta), float(eps), ptr(slope), int(sigmoid), ptr(mul),
                                       ptr(res), ptr(y), n, c, t, ldt, stream_ptr(x.device)), "ps_chan_layernorm_f32")
     return y
 
 
-def film_apply(x: torch.Tensor, scale_bias: torch.Tensor, t: int) -> torch.Tensor:
+def lstm_cell(gates: torch.Tensor, c: torch.Tensor, h: torch.Tensor, hidden: int, dirs: int, t: int) -> None:
+    """One cell update per (unit, frame): gates padded [N,D*4H,ld] (complete pre-activations), c in place, h out
+    (both [N,D*H,ld'] rows, possibly views into larger row blocks)."""
+    require_device(gates, "lstm_cell")
+    n = gates.shape[0]
+    if gates.shape[1] != dirs * 4 * hidden or tuple(c.shape[:2]) != (n, dirs * hidden) or c.shape != h.shape \
+            or c.stride(1) != h.stride(1):
+        raise RuntimeError("lstm_cell: gates [N,D*4H,ld], c/h [N,D*H,ld']")
+    if n > 1 and (not c.is_contiguous() or not h.is_contiguous()):
+        raise RuntimeError("lstm_cell: state views are supported for N = 1 only")
+    check(lib().ps_lstm_cell_f32(ptr(gates), ptr(c), ptr(h), n, hidden, dirs, t, gates.shape[2], c.stride(1),
+                                 stream_ptr(gates.device)), "ps_lstm_cell_f32")
+
+
+def film_apply(x: torch.Tensor, scale_bias: torch.Tensor, t: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """scale_bias padded [N,2C,ldt] (scale rows, then bias rows), x padded [N,C,ldt] -> scale * x + bias."""
     require_device(x, "film_apply")
     n, c, ldt = x.shape
     if tuple(scale_bias.shape) != (n, 2 * c, ldt):
         raise RuntimeError("film_apply: scale_bias must be [N, 2C, ldt]")
-    y = torch.zeros_like(x)
+    y = out if out is not None else torch.empty_like(x)
     check(lib().ps_film_apply_f32(ptr(x), ptr(scale_bias), ptr(y), n, c, t, ldt, stream_ptr(x.device)),
           "ps_film_apply_f32")
     return y

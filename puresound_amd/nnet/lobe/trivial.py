@@ -4,6 +4,8 @@ FiLM: x' = LN(x); [scale; bias] = one stacked 1x1 conv on [x'; e] (the embedding
 bias, ps_embed_bias_f32); out = scale * x' + bias.  Gate: in_conv -> (ChanLN+PReLU) * sigmoid(ChanLN+PReLU) ->
 out_conv + x.  Both work on the padded channel-major layout; the reference's [N,C,T] forward() is kept.
 """
+from typing import Optional
+
 import torch
 import torch.nn as nn
 
@@ -60,7 +62,7 @@ class FiLM(_PerFrameCondition, PlanCache, nn.Module):
         return p
 
     def forward_padded(self, x: torch.Tensor, t: int, condition: torch.Tensor, normalize: bool = False,
-                       per_frame: bool = False) -> torch.Tensor:
+                       per_frame: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x padded [N,C,ldt], condition [N,E] -> padded [N,C,ldt].  `normalize` folds the caller's
         F.normalize(condition) into the embedding GEMV.  per_frame: condition [T,E], one embedding per frame."""
         p = self._plan_get(x.device, self._build)
@@ -70,7 +72,7 @@ class FiLM(_PerFrameCondition, PlanCache, nn.Module):
         bias_n, res = self._embed_term(condition, p["w_embed"], normalize, per_frame)
         sb, _ = hip.conv1x1(x, t, p["wt"], 2 * c, None, None, bias_n, res,
                             out=torch.empty(n, 2 * c, ldt, dtype=torch.float32, device=x.device))
-        return hip.film_apply(x, sb, t)
+        return hip.film_apply(x, sb, t, out)
 
     def forward(self, x: torch.Tensor, condition: torch.Tensor) -> torch.Tensor:
         """x [N,C,T], condition [N,E] -> [N,C,T]."""
@@ -107,7 +109,7 @@ class Gate(_PerFrameCondition, PlanCache, nn.Module):
                     slope_left=_f32(self.left_conv[2].weight, device), slope_right=_f32(self.right_conv[2].weight, device))
 
     def forward_padded(self, x: torch.Tensor, t: int, condition: torch.Tensor, normalize: bool = False,
-                       per_frame: bool = False) -> torch.Tensor:
+                       per_frame: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         p = self._plan_get(x.device, self._build)
         n, c, ldt = x.shape
         h = self.hidden_size
@@ -120,8 +122,8 @@ class Gate(_PerFrameCondition, PlanCache, nn.Module):
         b, _ = hip.conv1x1(y, t, p["w_right"], h, None, None, bias_n, res, out=new(h))
         prod = hip.chan_layernorm(b, t, p["ln_right"]["gamma"], p["ln_right"]["beta"], p["ln_right"]["eps"],
                                   slope=p["slope_right"], sigmoid=True, mul=left)
-        out, _ = hip.conv1x1(prod, t, p["w_out"], c, res=x, out=new(c))
-        return out
+        y, _ = hip.conv1x1(prod, t, p["w_out"], c, res=x, out=out if out is not None else new(c))
+        return y
 
     def forward(self, x: torch.Tensor, condition: torch.Tensor) -> torch.Tensor:
         hip.require_device(x, "Gate.forward")

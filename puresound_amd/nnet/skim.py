@@ -106,6 +106,17 @@ class SegLSTM(PlanCache, nn.Module):
             raise RuntimeError("SegLSTM: dropout is active; the HIP path is inference only -- call .eval()")
         return (lstm_plan(self.lstm, device), linear_plan(self.proj, device), layernorm_plan(self.norm, device))
 
+    def step_plan(self, device):
+        """Streaming step: [W_ih | W_hh] as ONE weight whose K axis is [x; h], so the gates of a frame step are a
+        single GEMM followed by ps_lstm_cell_f32 (unidirectional only)."""
+        if self.bi_direct:
+            raise NotImplementedError("merged-gate streaming step: causal SegLSTM only")
+        p = self._plan_get(device, self._build)
+        if "w_gates" not in p[0]:
+            w = torch.cat([_f32(self.lstm.weight_ih_l0, device), _f32(self.lstm.weight_hh_l0, device)], dim=1)
+            p[0]["w_gates"] = hip.pack_wt(w)
+        return p
+
     def forward_padded(self, x: torch.Tensor, tp: int, q: int, k: int, h0, c0, state_shift: int = 0):
         """x padded [N,C,ldt] with q sequences of k contiguous frames per utterance; states in state layout."""
         p = self._plan_get(x.device, self._build)

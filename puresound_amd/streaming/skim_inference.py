@@ -83,7 +83,13 @@ class StreamingSkiM(SkiM):
         ldb = hip.padded_frames(streams)
         z = lambda rows: torch.zeros(1, rows, ldb, dtype=torch.float32, device=dev)  # noqa: E731
         rows = d * self.hidden_size
-        self._seg_h = [z(rows) for _ in range(self.n_blocks)]
+        # causal: block i keeps [x'; h] in one row block so that its gates are one GEMM over K = C + H; the h state
+        # is the lower part of that block
+        self._xh = [z(self.input_size + rows) for _ in range(self.n_blocks)] if self.causal else None
+        if self.causal:
+            self._seg_h = [xh[:, self.input_size:, :] for xh in self._xh]
+        else:
+            self._seg_h = [z(rows) for _ in range(self.n_blocks)]
         self._seg_c = [z(rows) for _ in range(self.n_blocks)]
         self._mem_h = [(z(rows), z(rows)) for _ in range(self.n_blocks - 1)]
         self._mem_c = [(z(rows), z(rows)) for _ in range(self.n_blocks - 1)]
@@ -127,14 +133,33 @@ class StreamingSkiM(SkiM):
         """One frame of every stream through all blocks; reads _x_in / _embed_static, updates the seg states in
         place, returns padded [1, C_out, ldB]."""
         b = self.streams
+        c_in, hid = self.input_size, self.hidden_size
         cur = self._x_in
         for i in range(self.n_blocks):
-            if self._embed_static is not None and self.block_with_embed[i]:
-                cur = self.seg_input_fusion[i].forward_padded(cur, b, self._embed_static, self.embed_norm,
-                                                              per_frame=True)
-            p = self.seg_lstm[i]._plan_get(cur.device, self.seg_lstm[i]._build)
-            cur, _ = lstm_path(cur, b, *p, q=b, q_stride=1, steps=1, step_stride=0, h0=self._seg_h[i],
-                               c0=self._seg_c[i], state_out=(self._seg_h[i], self._seg_c[i]))
+            fused = self._embed_static is not None and self.block_with_embed[i]
+            if not self.causal:
+                if fused:
+                    cur = self.seg_input_fusion[i].forward_padded(cur, b, self._embed_static, self.embed_norm,
+                                                                  per_frame=True)
+                p = self.seg_lstm[i]._plan_get(cur.device, self.seg_lstm[i]._build)
+                cur, _ = lstm_path(cur, b, *p, q=b, q_stride=1, steps=1, step_stride=0, h0=self._seg_h[i],
+                                   c0=self._seg_c[i], state_out=(self._seg_h[i], self._seg_c[i]))
+                continue
+            rnn, proj, norm = self.seg_lstm[i].step_plan(cur.device)
+            xh = self._xh[i]
+            x_rows, h_rows = xh[:, :c_in, :], xh[:, c_in:, :]
+            if fused:
+                self.seg_input_fusion[i].forward_padded(cur, b, self._embed_static, self.embed_norm, per_frame=True,
+                                                        out=x_rows)
+            else:
+                x_rows.copy_(cur)
+            ldb = xh.shape[-1]
+            gates, _ = hip.conv1x1(xh, b, rnn["w_gates"], 4 * hid, None, rnn["bias"],
+                                   out=torch.empty(1, 4 * hid, ldb, dtype=torch.float32, device=xh.device))
+            hip.lstm_cell(gates, self._seg_c[i], h_rows, hid, 1, b)
+            pr, _ = hip.conv1x1(h_rows, b, proj["wt"], proj["M"], None, proj["bias"],
+                                out=torch.empty(1, proj["M"], ldb, dtype=torch.float32, device=xh.device))
+            cur = hip.chan_layernorm(pr, b, norm["gamma"], norm["beta"], norm["eps"], res=x_rows)
         return self._output(cur, b)
 
     @torch.no_grad()
