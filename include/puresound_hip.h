@@ -53,7 +53,7 @@ const char* ps_last_error(void);
  * library is bracketed by hipEvents on the launch stream.  ps_profile_enable(1) clears old records.
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
- * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm",
+ * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product",
  * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
@@ -170,6 +170,23 @@ int ps_embed_bias_f32(const float* dvec, const float* w_embed, float* bias_n, in
  * ------------------------------------------------------------------------------------------- */
 int ps_attn_stats_pool_f32(const float* logits, const float* x, float* out, int N, int C, int T, int ldt,
                            float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GatedTCN (conv_tasnet.py:129-215): its dense dilated convolutions run as ps_conv1x1_f32 over unfolded taps.
+ *
+ * ps_unfold_taps_f32: y[n][j*(K+E) + k][t] = x'[n][k][t + j*dilation - left] (0 outside [0,T)), where
+ *   x' = scale[n][k] * x + shift[n][k] when scale/shift are given (FiLM conditioning, conv_tasnet.py:196-201) and
+ *   rows k >= K are the constant embed[n][k-K] (the concatenated, repeated embedding, conv_tasnet.py:186-191; it
+ *   is zero-padded by the convolution like any other channel).  The conv weight W[m][k][j] is then the matrix
+ *   Wu[m][j*(K+E)+k].
+ * ps_gated_product_f32: y = PReLU(norm(left)) * sigmoid(PReLU(norm(right))) with gLN (partial statistics from the
+ *   producing ps_conv1x1_f32) or folded bN1d prologues (conv_tasnet.py:203-206); cLN goes through
+ *   ps_chan_layernorm_f32 instead.
+ * ------------------------------------------------------------------------------------------- */
+int ps_unfold_taps_f32(const float* x, float* y, int N, int K, int T, int ldt, int P, int dilation, int left,
+                       const float* scale, const float* shift, const float* embed, int E, void* stream);
+int ps_gated_product_f32(const float* left, const float* right, float* y, int N, int H, int T, int ldt,
+                         const ps_prologue* pro_left, const ps_prologue* pro_right, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Recurrent maskers (DPRNN dprnn.py:111-191, SkiM skim.py:198-229,45-114,410-469, StreamingSkiM

@@ -140,11 +140,29 @@ __global__ __launch_bounds__(256) void free_decode_generic_kernel(const float* _
     const int j = s - t * hop;
     const float* f = feats + (size_t)n * C * ldt + t;
     const float* m = mask ? mask + (size_t)n * C * ldt + t : nullptr;
-    for (int c = 0; c < C; ++c) {
+    // four independent partial sums keep several channel loads in flight (the walk is latency bound)
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    int c = 0;
+    for (; c + 4 <= C; c += 4) {
+      float e0 = f[(size_t)c * ldt], e1 = f[(size_t)(c + 1) * ldt], e2 = f[(size_t)(c + 2) * ldt],
+            e3 = f[(size_t)(c + 3) * ldt];
+      if (m) {
+        e0 *= mask_act(m[(size_t)c * ldt], mask_mode);
+        e1 *= mask_act(m[(size_t)(c + 1) * ldt], mask_mode);
+        e2 *= mask_act(m[(size_t)(c + 2) * ldt], mask_mode);
+        e3 *= mask_act(m[(size_t)(c + 3) * ldt], mask_mode);
+      }
+      p0 = fmaf(w[(size_t)c * win + j], e0, p0);
+      p1 = fmaf(w[(size_t)(c + 1) * win + j], e1, p1);
+      p2 = fmaf(w[(size_t)(c + 2) * win + j], e2, p2);
+      p3 = fmaf(w[(size_t)(c + 3) * win + j], e3, p3);
+    }
+    for (; c < C; ++c) {
       float e = f[(size_t)c * ldt];
       if (m) e *= mask_act(m[(size_t)c * ldt], mask_mode);
-      accv = fmaf(w[(size_t)c * win + j], e, accv);
+      p0 = fmaf(w[(size_t)c * win + j], e, p0);
     }
+    accv += (p0 + p1) + (p2 + p3);
   }
   out[(size_t)n * Lout + s] = out_constrain(accv, out_mode);
 }

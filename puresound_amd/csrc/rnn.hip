@@ -677,3 +677,125 @@ extern "C" int ps_lstm_cell_f32(const float* gates, float* c, float* h, int N, i
   }
   return launch_status("ps_lstm_cell_f32");
 }
+
+// ---- GatedTCN pieces (conv_tasnet.py:129-215) -----------------------------------------------------------------
+namespace ps {
+
+// Unfold a dense dilated convolution into a 1x1 one: row (j, k) of the output is input channel k shifted by tap j
+// (zero outside [0, T)), so W[m][k][j] becomes a plain [M][P*Kc] matrix for ps_conv1x1_f32.  Optional per-(utterance,
+// channel) FiLM scale/shift applied before the zero padding, and E constant embedding rows appended per tap (the
+// reference concatenates the repeated embedding BEFORE F.conv1d pads, so its taps drop out at the edges too).
+__global__ __launch_bounds__(256) void unfold_taps_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift,
+                                                          const float* __restrict__ embed, int K, int E, int T, int ldt,
+                                                          int P, int dilation, int left) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int row = blockIdx.y;  // j * (K + E) + k
+  const int n = blockIdx.z;
+  const int Kc = K + E;
+  const int j = row / Kc, k = row % Kc;
+  if (t >= T) return;
+  const int src = t + j * dilation - left;
+  float v = 0.f;
+  if (src >= 0 && src < T) {
+    if (k < K) {
+      v = x[((size_t)n * K + k) * ldt + src];
+      if (scale) v = v * scale[(size_t)n * K + k] + shift[(size_t)n * K + k];
+    } else {
+      v = embed[(size_t)n * E + (k - K)];
+    }
+  }
+  y[((size_t)n * P * Kc + row) * ldt + t] = v;
+}
+
+struct GateArgs {
+  const float* l;
+  const float* r;
+  float* y;
+  ps_prologue pl, pr;
+  int H, T, ldt;
+};
+
+// y = PReLU(norm(l)) * sigmoid(PReLU(norm(r))): the two branch tails of the gated block, norms gLN / folded bN1d.
+__global__ __launch_bounds__(256) void gated_product_kernel(GateArgs a) {
+  __shared__ double red[8];
+  const int n = blockIdx.z, ch = blockIdx.y;
+  const NormScalars nl = load_norm_scalars(a.pl, n, red);
+  const NormScalars nr = load_norm_scalars(a.pr, n, red);
+  const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t >= a.T) return;
+  const float scl = a.pl.norm != PS_NORM_NONE ? a.pl.gamma[ch] * nl.rstd : 1.f;
+  const float shl = (a.pl.norm != PS_NORM_NONE ? a.pl.beta[ch] : 0.f) - nl.mean * scl;
+  const float scr = a.pr.norm != PS_NORM_NONE ? a.pr.gamma[ch] * nr.rstd : 1.f;
+  const float shr = (a.pr.norm != PS_NORM_NONE ? a.pr.beta[ch] : 0.f) - nr.mean * scr;
+  const float sl = a.pl.prelu ? a.pl.slope[0] : 1.f, sr = a.pr.prelu ? a.pr.slope[0] : 1.f;
+  const size_t off = ((size_t)n * a.H + ch) * a.ldt + t;
+  const f32x4 lv = *reinterpret_cast<const f32x4*>(a.l + off);
+  const f32x4 rv = *reinterpret_cast<const f32x4*>(a.r + off);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float lf = prelu(lv[e] * scl + shl, sl);
+    const float rf = prelu(rv[e] * scr + shr, sr);
+    o[e] = lf * sigmoidf_(rf);
+  }
+  *reinterpret_cast<f32x4*>(a.y + off) = o;
+}
+
+}  // namespace ps
+
+extern "C" int ps_unfold_taps_f32(const float* x, float* y, int N, int K, int T, int ldt, int P, int dilation, int left,
+                                  const float* scale, const float* shift, const float* embed, int E, void* stream) {
+  if (!x || !y || N <= 0 || K <= 0 || T <= 0 || ldt < T || P <= 0 || dilation <= 0 || left < 0 || E < 0 ||
+      (E > 0 && !embed) || ((scale == nullptr) != (shift == nullptr)) || (long long)P * (K + E) > 65535 || N > 65535) {
+    set_error("ps_unfold_taps_f32: bad argument (N=%d K=%d T=%d P=%d dilation=%d left=%d E=%d)", N, K, T, P, dilation,
+              left, E);
+    return PS_E_INVALID;
+  }
+  {
+    LaunchTimer timer("unfold_taps", (hipStream_t)stream);
+    hipLaunchKernelGGL(unfold_taps_kernel, dim3((T + 255) / 256, P * (K + E), N), dim3(256), 0, (hipStream_t)stream, x,
+                       y, scale, shift, embed, K, E, T, ldt, P, dilation, left);
+  }
+  return launch_status("ps_unfold_taps_f32");
+}
+
+static int check_gate_prologue(const ps_prologue& p, const char* side) {
+  if (p.norm != PS_NORM_NONE && (!p.gamma || !p.beta)) {
+    set_error("ps_gated_product_f32: %s norm needs gamma/beta", side);
+    return PS_E_INVALID;
+  }
+  if (p.norm == PS_NORM_GLOBAL && (!p.stats || p.parts <= 0 || p.count <= 0)) {
+    set_error("ps_gated_product_f32: %s PS_NORM_GLOBAL needs stats/parts/count", side);
+    return PS_E_INVALID;
+  }
+  if (p.prelu && !p.slope) {
+    set_error("ps_gated_product_f32: %s prelu needs slope", side);
+    return PS_E_INVALID;
+  }
+  return 0;
+}
+
+extern "C" int ps_gated_product_f32(const float* left, const float* right, float* y, int N, int H, int T, int ldt,
+                                    const ps_prologue* pro_left, const ps_prologue* pro_right, void* stream) {
+  if (!left || !right || !y || !pro_left || !pro_right || N <= 0 || H <= 0 || T <= 0 || ldt < T || H > 65535 ||
+      N > 65535) {
+    set_error("ps_gated_product_f32: bad argument (N=%d H=%d T=%d ldt=%d)", N, H, T, ldt);
+    return PS_E_INVALID;
+  }
+  if (ldt % 4 || ((uintptr_t)left & 15) || ((uintptr_t)right & 15) || ((uintptr_t)y & 15)) {
+    set_error("ps_gated_product_f32: rows must be 16-byte aligned");
+    return PS_E_ALIGN;
+  }
+  int rc = check_gate_prologue(*pro_left, "left");
+  if (rc) return rc;
+  rc = check_gate_prologue(*pro_right, "right");
+  if (rc) return rc;
+  GateArgs a{left, right, y, *pro_left, *pro_right, H, T, ldt};
+  {
+    LaunchTimer timer("gated_product", (hipStream_t)stream);
+    hipLaunchKernelGGL(gated_product_kernel, dim3((T + 1023) / 1024, H, N), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  return launch_status("ps_gated_product_f32");
+}

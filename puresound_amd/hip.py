@@ -226,6 +226,29 @@ def chan_layernorm(x: torch.Tensor, t: int, gamma: torch.Tensor, beta: torch.Ten
     return y
 
 
+def unfold_taps(x: torch.Tensor, t: int, taps: int, dilation: int, left: int, scale: Optional[torch.Tensor] = None,
+                shift: Optional[torch.Tensor] = None, embed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x padded [N,K,ldt] -> [N, taps*(K+E), ldt]: tap-shifted copies (zero outside [0,T)), optional per-(n,k) affine
+    before the padding, optional constant embedding rows."""
+    require_device(x, "unfold_taps")
+    n, k, ldt = x.shape
+    e = 0 if embed is None else embed.shape[1]
+    y = torch.empty(n, taps * (k + e), ldt, dtype=torch.float32, device=x.device)
+    check(lib().ps_unfold_taps_f32(ptr(x), ptr(y), n, k, t, ldt, taps, dilation, left, ptr(scale), ptr(shift),
+                                   ptr(embed), e, stream_ptr(x.device)), "ps_unfold_taps_f32")
+    return y
+
+
+def gated_product(left: torch.Tensor, right: torch.Tensor, t: int, pro_left: Prologue, pro_right: Prologue) -> torch.Tensor:
+    """PReLU(norm(left)) * sigmoid(PReLU(norm(right))) on padded [N,H,ldt]."""
+    require_device(left, "gated_product")
+    n, h, ldt = left.shape
+    y = torch.empty_like(left)
+    check(lib().ps_gated_product_f32(ptr(left), ptr(right), ptr(y), n, h, t, ldt, C.byref(pro_left), C.byref(pro_right),
+                                     stream_ptr(left.device)), "ps_gated_product_f32")
+    return y
+
+
 def lstm_cell(gates: torch.Tensor, c: torch.Tensor, h: torch.Tensor, hidden: int, dirs: int, t: int) -> None:
     """One cell update per (unit, frame): gates padded [N,D*4H,ld] (complete pre-activations), c in place, h out
     (both [N,D*H,ld'] rows, possibly views into larger row blocks)."""
@@ -260,6 +283,20 @@ def embed_bias(dvec: torch.Tensor, w_embed: torch.Tensor, normalize: bool) -> to
     check(lib().ps_embed_bias_f32(ptr(dvec.contiguous()), ptr(w_embed), ptr(out), n, e, m, int(normalize),
                                   stream_ptr(dvec.device)), "ps_embed_bias_f32")
     return out
+
+
+_EYE = {}
+
+
+def l2_normalize(dvec: torch.Tensor) -> torch.Tensor:
+    """F.normalize(dvec, p=2, dim=1) through ps_embed_bias_f32 with an identity weight (exact: every output is one
+    product with 1 plus zeros)."""
+    require_device(dvec, "l2_normalize")
+    e = dvec.shape[1]
+    key = (str(dvec.device), e)
+    if key not in _EYE:
+        _EYE[key] = torch.eye(e, dtype=torch.float32, device=dvec.device)
+    return embed_bias(dvec.float(), _EYE[key], True)
 
 
 def conv_tasnet(blocks: "C.Array[TcnBlock]", n_blocks: int, x_pad: torch.Tensor, t: int, c: int, h: int,

@@ -13,9 +13,9 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from .._abi import TcnBlock, ptr
+from .._abi import PS_NORM_GLOBAL, TcnBlock, ptr
 from .lobe.cnn import DepthwiseSeparableConv1d
-from .lobe.norm import get_norm, norm_plan
+from .lobe.norm import ChanLN, get_norm, norm_plan
 
 
 _PLAN_SERIAL = [0]
@@ -125,13 +125,19 @@ class TCN(_PlanCache, nn.Module):
         return hip.unpad_rows(out, t)
 
 
-class GatedTCN(nn.Module):
-    """Gated TCN block (conv_tasnet.py:93-215).  Parameter tree only: its dense 3-tap convolutions are a
-    later row of the hot-path table (used by the UnetTcn presets, not by the Conv-TasNet configs)."""
+class GatedTCN(_PlanCache, nn.Module):
+    """Gated TCN block (conv_tasnet.py:93-215): 1x1 in_conv; left = PReLU(norm(dense dilated conv)); right =
+    sigmoid(PReLU(norm(dense dilated conv of [h; e] or of FiLM(h)))); out_conv(left * right); + residual.
+
+    The dense P-tap convolutions are GEMMs with K = P*H: ps_unfold_taps_f32 lays the P shifted copies of h (with the
+    conv's zero padding, the FiLM affine and the repeated embedding rows) side by side and ps_conv1x1_f32 does the
+    rest on MFMA, its epilogue producing the gLN statistics the gating kernel needs."""
 
     def __init__(self, in_channels: int, hid_channels: int, kernel: int, dilation: int, dropout: float = 0.0,
                  emb_dim: int = 0, causal: bool = False, tcn_norm: str = "gLN", use_film: bool = False):
         super().__init__()
+        self.in_channels, self.hid_channels, self.kernel, self.dilation, self.emb_dim = \
+            in_channels, hid_channels, kernel, dilation, emb_dim
         self.causal = causal
         self.padd = (kernel - 1) * dilation // 2 if not causal else (kernel - 1) * dilation
         self.tcn_norm = tcn_norm
@@ -153,9 +159,94 @@ class GatedTCN(nn.Module):
                       padding=self.padd, groups=1),
             norm_cls(hid_channels), nn.PReLU(), nn.Dropout(p=dropout), nn.Sigmoid())
         self.out_conv = nn.Conv1d(hid_channels, in_channels, kernel_size=1, bias=False, groups=1)
+        self._plan = None
+        self._plan_sig = None
+
+    @staticmethod
+    def _unfolded(w: torch.Tensor) -> torch.Tensor:
+        """[M, Kc, P] -> [M, P*Kc] with column j*Kc + k (the row order of ps_unfold_taps_f32)."""
+        return w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()
+
+    def plan(self, device: torch.device) -> dict:
+        sig = (_param_signature(self), str(device))
+        if self._plan is not None and self._plan_sig == sig:
+            return self._plan
+        if self.training and (self.left_conv[3].p > 0 or self.right_conv[3].p > 0):
+            raise RuntimeError("GatedTCN: dropout is active; the HIP path is inference only -- call .eval()")
+        span = (self.kernel - 1) * self.dilation
+        if not self.causal and span % 2:
+            raise RuntimeError("GatedTCN: (kernel-1)*dilation is odd, the symmetric padding changes the length "
+                               "(the reference fails at the residual add)")
+        f32 = dict(dtype=torch.float32, device=device)
+        t = dict(w_in=hip.pack_wt(self.in_conv.weight.detach().to(**f32)),
+                 w_left=hip.pack_wt(self._unfolded(self.left_conv[0].weight.detach().to(**f32))),
+                 w_right=hip.pack_wt(self._unfolded(self.right_conv[0].weight.detach().to(**f32))),
+                 w_out=hip.pack_wt(self.out_conv.weight.detach().to(**f32)))
+        for side, seq in (("left", self.left_conv), ("right", self.right_conv)):
+            if seq[2].weight.numel() != 1:
+                raise NotImplementedError("PReLU with per-channel slopes is not on the HIP path")
+            t[side + "_slope"] = seq[2].weight.detach().to(**f32).contiguous()
+            mod = seq[1]
+            if isinstance(mod, ChanLN):
+                t[side + "_kind"] = "cln"
+                g, b = mod.gamma.detach(), mod.beta.detach()
+            else:
+                kind, g, b = norm_plan(mod)
+                if kind == PS_NORM_GLOBAL and self.causal:
+                    # the reference normalises over the T + padding frames it trims only after out_conv
+                    raise NotImplementedError("GatedTCN on HIP: gLN/gGN with causal=True is not supported")
+                t[side + "_kind"] = kind
+            t[side + "_gamma"], t[side + "_beta"] = g.to(**f32).contiguous(), b.to(**f32).contiguous()
+        if self.use_film:
+            t["w_film"] = torch.cat([self.cond_scale.weight.detach()[:, :, 0], self.cond_bias.weight.detach()[:, :, 0]],
+                                    0).to(**f32).contiguous()
+        self._plan, self._plan_sig = t, sig
+        return t
+
+    def forward_padded(self, x: torch.Tensor, t: int, embed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """padded [N,C,ldt] -> padded [N,C,ldt] (embed is used as given: ConvTasNet normalises it beforehand)."""
+        p = self.plan(x.device)
+        n, c, ldt = x.shape
+        h, k, d = self.hid_channels, self.kernel, self.dilation
+        left = self.padd
+        new = lambda rows: torch.empty(n, rows, ldt, dtype=torch.float32, device=x.device)  # noqa: E731
+        y, _ = hip.conv1x1(x, t, p["w_in"], h, out=new(h))
+        scale = shift = emb_rows = None
+        if embed is not None:
+            embed = embed.float().contiguous()
+            if self.use_film:
+                sb = hip.embed_bias(embed, p["w_film"], False)              # [N, 2H]: scale | bias
+                scale, shift = sb[:, :h].contiguous(), sb[:, h:].contiguous()
+            else:
+                emb_rows = embed
+        col_l = hip.unfold_taps(y, t, k, d, left)
+        col_r = col_l if (scale is None and emb_rows is None) else hip.unfold_taps(y, t, k, d, left, scale, shift,
+                                                                                  emb_rows)
+        cln = p["left_kind"] == "cln"
+        want = (not cln) and p["left_kind"] == PS_NORM_GLOBAL
+        lo, ls = hip.conv1x1(col_l, t, p["w_left"], h, want_stats=want, out=new(h))
+        ro, rs = hip.conv1x1(col_r, t, p["w_right"], h, want_stats=want, out=new(h))
+        if cln:
+            lf = hip.chan_layernorm(lo, t, p["left_gamma"], p["left_beta"], 1e-8, slope=p["left_slope"])
+            g = hip.chan_layernorm(ro, t, p["right_gamma"], p["right_beta"], 1e-8, slope=p["right_slope"],
+                                   sigmoid=True, mul=lf)
+        else:
+            pl = hip.make_prologue(p["left_kind"], True, ls, h * t, 1e-8, p["left_gamma"], p["left_beta"],
+                                   p["left_slope"])
+            pr = hip.make_prologue(p["right_kind"], True, rs, h * t, 1e-8, p["right_gamma"], p["right_beta"],
+                                   p["right_slope"])
+            g = hip.gated_product(lo, ro, t, pl, pr)
+        out, _ = hip.conv1x1(g, t, p["w_out"], c, res=x, out=new(c))
+        return out
 
     def forward(self, x: torch.Tensor, embed: Optional[torch.Tensor] = None) -> torch.Tensor:
-        raise NotImplementedError("GatedTCN has no HIP kernel yet (dense dilated 3-tap convs; UnetTcn presets)")
+        """x [N,C,T], embed [N,E] -> [N,C,T] (conv_tasnet.py:178-215)."""
+        hip.require_device(x, "GatedTCN.forward")
+        if embed is not None and not self.use_film and self.emb_dim == 0:
+            raise RuntimeError("GatedTCN.forward: block built with emb_dim=0 but embed is given "
+                               "(the reference fails in right_conv)")
+        t = x.shape[-1]
+        return hip.unpad_rows(self.forward_padded(hip.pad_rows(x), t, embed), t)
 
 
 class ConvTasNet(_PlanCache, nn.Module):
@@ -205,7 +296,7 @@ class ConvTasNet(_PlanCache, nn.Module):
     # -- plan: one ps_tcn_block per TCN, in execution order -------------------------------------------
     def block_array(self, device: torch.device):
         if self.tcn_layer.lower() != "normal":
-            raise NotImplementedError("tcn_layer='gated' has no HIP kernel yet")
+            raise RuntimeError("block_array: only the normal TCN stack runs through ps_conv_tasnet_f32")
         mods = [m for stack in self.tcn_list for m in stack]
         plans = [m.plan(device) for m in mods]  # each TCN re-validates its own fingerprint
         sig = tuple(p["serial"] for p in plans)
@@ -218,6 +309,8 @@ class ConvTasNet(_PlanCache, nn.Module):
                        lane: int = 0) -> torch.Tensor:
         """Padded-layout entry used by the fused wrapper: [N,C,ldt] -> mask logits [N,C,ldt].
         `lane` selects the cached scratch buffer (one per concurrent HIP stream of the caller)."""
+        if self.tcn_layer.lower() == "gated":
+            return self._forward_gated(x_pad, t, dvec)
         blocks, n_blocks = self.block_array(x_pad.device)
         need_embed = any(self.tcn_with_embed)
         if need_embed and dvec is None:
@@ -235,6 +328,15 @@ class ConvTasNet(_PlanCache, nn.Module):
         return hip.conv_tasnet(blocks, n_blocks, x_pad, t, self.input_dim, self.tcn_dim,
                                None if dvec is None else dvec.contiguous().float(),
                                bool(self.embed_norm), ws)
+
+    def _forward_gated(self, x: torch.Tensor, t: int, dvec: Optional[torch.Tensor]) -> torch.Tensor:
+        """tcn_layer="gated": block by block (conv_tasnet.py:348-357)."""
+        if dvec is not None and self.embed_norm:
+            dvec = hip.l2_normalize(dvec.float())
+        for stack in self.tcn_list:
+            for i, blk in enumerate(stack):
+                x = blk.forward_padded(x, t, dvec if (self.tcn_with_embed[i] and dvec is not None) else None)
+        return x
 
     def forward(self, x: torch.Tensor, dvec: Optional[torch.Tensor] = None):
         """x [N,C,T], dvec [N,E] -> mask logits [N,C,T] (conv_tasnet.py:338-359)."""

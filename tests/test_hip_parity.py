@@ -215,7 +215,7 @@ def test_abi_rejects_bad_arguments(H, dev):
 # ------------------------------------------------------------------------------------------------
 # masker and wrapper against the reference's golden vectors
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["ctn_embed", "ctn_dil3_k5"])
+@pytest.mark.parametrize("name", ["ctn_embed", "ctn_dil3_k5", "ctn_gated", "ctn_gated_causal"])
 def test_masker_matches_reference_golden(PA, dev, golden_dir, name):
     g = _load(golden_dir, name)
     model = cases.build(PA.NS, name).eval()
@@ -649,3 +649,20 @@ def test_demo_harness_matches_reference_golden(dev, golden_dir):
     for i in range(h["chunks"]):
         pre = net.streaming_inference_chunk(wavs[:, i * h["chunk"]:(i + 1) * h["chunk"]].to(dev), ds.to(dev), pre)
     assert rel_max(pre[2].cpu().numpy(), g["harness_wav"]) < TOL
+
+
+@pytest.mark.parametrize("norm,causal,film", [("gLN", False, True), ("cLN", True, False), ("bN1d", True, True),
+                                               ("gLN", False, False)])
+def test_gated_tcn_block_matches_oracle(PA, dev, norm, causal, film):
+    """GatedTCN (conv_tasnet.py:93-215): concat / FiLM conditioning, gLN / cLN / bN1d, causal trim."""
+    blk = PA.NS.GatedTCN(12, 10, 3, 2, emb_dim=5, causal=causal, tcn_norm=norm, use_film=film).eval()
+    sd = det_state_dict(blk)
+    blk.load_state_dict(sd)
+    blk.to(dev)
+    x, e = _rand((2, 12, 61), 81), _rand((2, 5), 82)
+    ref = O.gated_tcn_block(x, sd, "", 3, 2, causal, norm, film, e)
+    y = blk(x.to(dev), e.to(dev))
+    assert rel_max(y.cpu().numpy(), ref.numpy()) < 2e-5
+    ref0 = O.gated_tcn_block(x, sd, "", 3, 2, causal, norm, film, None) if film else None
+    if film:  # FiLM blocks also run unconditioned (x_r = x)
+        assert rel_max(blk(x.to(dev)).cpu().numpy(), ref0.numpy()) < 2e-5
