@@ -53,7 +53,7 @@ const char* ps_last_error(void);
  * library is bracketed by hipEvents on the launch stream.  ps_profile_enable(1) clears old records.
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
- * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product",
+ * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product", "segment_overlap",
  * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
@@ -216,6 +216,14 @@ typedef struct {
   int N, H, D, Q, q_stride, steps, step_stride, ldt, ldq, state_shift;
 } ps_lstm_args;
 int ps_lstm_f32(const ps_lstm_args* args, void* stream);
+
+/* 50 % overlapped segmentation of the dual-path maskers (SplitMerge.split / merge, lobe/trivial.py:178-241; SkiM.split /
+ * merge, skim.py:334-408) on rows of frames:
+ *   merge = 0: dst frame s*K + k = src frame (s/2)*K + k + (s odd ? K/2 : 0) - K/2, zero outside [0, T_src); T_dst =
+ *              S*K with S even = 2 * (T_src + rest + K/2) / K, rest = K - (K/2 + T_src % K) % K
+ *   merge = 1: dst frame t = (even-segment cover + odd-segment cover) / 2, T_dst = the original frame count. */
+int ps_segment_overlap_f32(const float* src, float* dst, int64_t rows, int T_src, int ld_src, int T_dst, int ld_dst,
+                           int K, int merge, void* stream);
 
 /* One cell update per (unit, frame) from COMPLETE gate pre-activations gates [N][D*4H][ld_gates] (W_ih x + W_hh h + both
  * biases: the streaming step puts [x; h] on the K axis of one ps_conv1x1_f32):  c' = sig(f) c + sig(i) tanh(g) in

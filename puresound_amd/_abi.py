@@ -70,6 +70,7 @@ SIGNATURES = {
     "ps_lstm_f32": (C.c_int, [C.POINTER(LstmArgs), _vp]),
     "ps_unfold_taps_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 7 + [_vp, _vp, _vp, C.c_int, _vp]),
     "ps_gated_product_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [C.POINTER(Prologue), C.POINTER(Prologue), _vp]),
+    "ps_segment_overlap_f32": (C.c_int, [_vp, _vp, C.c_int64] + [C.c_int] * 6 + [_vp]),
     "ps_lstm_cell_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_chan_layernorm_f32": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
     "ps_film_apply_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),

@@ -799,3 +799,66 @@ extern "C" int ps_gated_product_f32(const float* left, const float* right, float
   }
   return launch_status("ps_gated_product_f32");
 }
+
+// ---- 50 % overlapped segmentation (SplitMerge.split / merge, lobe/trivial.py:178-241; SkiM.split / merge) ------------
+namespace ps {
+
+// mode 0 (split): dst frame s*K + k <- src frame (s/2)*K + k + (s&1)*K/2 - K/2 (zero outside [0, T_src))
+// mode 1 (merge): dst frame t <- (src[even cover] + src[odd cover]) / 2
+__global__ __launch_bounds__(256) void segment_overlap_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              int T_src, int ld_src, int T_dst, int ld_dst, int K,
+                                                              int mode) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  const size_t row = blockIdx.y;
+  if (f >= T_dst) return;
+  const float* s = src + row * ld_src;
+  const int stride = K / 2;
+  float v;
+  if (mode == 0) {
+    const int seg = f / K, k = f % K;
+    const int t = (seg >> 1) * K + k + (seg & 1) * stride - stride;
+    v = (t >= 0 && t < T_src) ? s[t] : 0.f;
+  } else {
+    const int e = stride + f;
+    const int fa = (2 * (e / K)) * K + e % K;
+    const int fb = (2 * (f / K) + 1) * K + f % K;
+    v = (s[fa] + s[fb]) * 0.5f;
+  }
+  dst[row * ld_dst + f] = v;
+}
+
+}  // namespace ps
+
+extern "C" int ps_segment_overlap_f32(const float* src, float* dst, int64_t rows, int T_src, int ld_src, int T_dst,
+                                      int ld_dst, int K, int merge, void* stream) {
+  if (!src || !dst || rows <= 0 || rows > 65535 * 32768LL || T_src <= 0 || T_dst <= 0 || ld_src < T_src ||
+      ld_dst < T_dst || K < 2) {
+    set_error("ps_segment_overlap_f32: bad argument");
+    return PS_E_INVALID;
+  }
+  const int stride = K / 2;
+  if (!merge) {
+    // every source index the split reads is checked in the kernel; the destination must be whole segment pairs
+    if (T_dst % (2 * K)) {
+      set_error("ps_segment_overlap_f32: split destination must hold an even number of %d-frame segments", K);
+      return PS_E_INVALID;
+    }
+  } else {
+    // the last merged frame reads even-stream index stride + T_dst - 1 and odd-stream index T_dst - 1
+    const long long e = (long long)stride + T_dst - 1;
+    const long long fa = (2 * (e / K)) * K + e % K, fb = (2LL * ((T_dst - 1) / K) + 1) * K + (T_dst - 1) % K;
+    if (fa >= T_src || fb >= T_src) {
+      set_error("ps_segment_overlap_f32: merge source is too short (%d frames)", T_src);
+      return PS_E_INVALID;
+    }
+  }
+  using namespace ps;
+  LaunchTimer timer("segment_overlap", (hipStream_t)stream);
+  const int64_t chunk = 65535;
+  for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+    const int64_t nr = rows - r0 < chunk ? rows - r0 : chunk;
+    hipLaunchKernelGGL(segment_overlap_kernel, dim3((T_dst + 255) / 256, (unsigned)nr), dim3(256), 0,
+                       (hipStream_t)stream, src + r0 * ld_src, dst + r0 * ld_dst, T_src, ld_src, T_dst, ld_dst, K, merge);
+  }
+  return launch_status("ps_segment_overlap_f32");
+}

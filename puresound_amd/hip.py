@@ -249,6 +249,34 @@ def gated_product(left: torch.Tensor, right: torch.Tensor, t: int, pro_left: Pro
     return y
 
 
+def overlap_geometry(t: int, k: int) -> tuple[int, int]:
+    """(rest, S*K) of the 50 % overlapped segmentation of t frames into k-frame segments."""
+    stride = k // 2
+    rest = k - (stride + t % k) % k
+    return rest, 2 * ((t + rest + stride) // k) * k
+
+
+def segment_split(x: torch.Tensor, t: int, k: int) -> tuple[torch.Tensor, int]:
+    """padded [N,C,ldt] with t frames -> (padded [N,C,ld'] holding S*K frames of overlapped segments, S*K)."""
+    require_device(x, "segment_split")
+    n, c, ldt = x.shape
+    _, tp = overlap_geometry(t, k)
+    y = torch.empty(n, c, padded_frames(tp), dtype=torch.float32, device=x.device)
+    check(lib().ps_segment_overlap_f32(ptr(x), ptr(y), n * c, t, ldt, tp, y.shape[-1], k, 0, stream_ptr(x.device)),
+          "ps_segment_overlap_f32")
+    return y, tp
+
+
+def segment_merge(x: torch.Tensor, tp: int, t: int, k: int) -> torch.Tensor:
+    """inverse of segment_split: padded [N,C,ld'] with tp segment frames -> padded [N,C,ldt] with t frames."""
+    require_device(x, "segment_merge")
+    n, c, ld = x.shape
+    y = torch.empty(n, c, padded_frames(t), dtype=torch.float32, device=x.device)
+    check(lib().ps_segment_overlap_f32(ptr(x), ptr(y), n * c, tp, ld, t, y.shape[-1], k, 1, stream_ptr(x.device)),
+          "ps_segment_overlap_f32")
+    return y
+
+
 def lstm_cell(gates: torch.Tensor, c: torch.Tensor, h: torch.Tensor, hidden: int, dirs: int, t: int) -> None:
     """One cell update per (unit, frame): gates padded [N,D*4H,ld] (complete pre-activations), c in place, h out
     (both [N,D*H,ld'] rows, possibly views into larger row blocks)."""

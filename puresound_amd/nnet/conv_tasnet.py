@@ -85,7 +85,11 @@ class TCN(_PlanCache, nn.Module):
         t["in_embed_w"] = w_in[:, c:, 0].contiguous() if self.emb_dim > 0 else None
         kinds = {}
         for name, mod in (("in", self.in_conv[1]), ("dw", dsc.depthwise[1]), ("pw", dsc.pointwise[1])):
-            kinds[name], g, b = norm_plan(mod)
+            if isinstance(mod, ChanLN):
+                # per-frame LayerNorm over channels: no fused prologue form, the block runs stage by stage
+                kinds[name], g, b = "cln", mod.gamma.detach().float(), mod.beta.detach().float()
+            else:
+                kinds[name], g, b = norm_plan(mod)
             t[name + "_gamma"], t[name + "_beta"] = g.to(**f32).contiguous(), b.to(**f32).contiguous()
         t["in_slope"] = self.in_conv[2].weight.detach().to(**f32).contiguous()
         t["dw_slope"] = dsc.depthwise[2].weight.detach().to(**f32).contiguous()
@@ -101,15 +105,46 @@ class TCN(_PlanCache, nn.Module):
         t["out_b"] = self.out_conv.bias.detach().to(**f32).contiguous()
         b = TcnBlock()
         b.C, b.H, b.P, b.dilation, b.causal = c, h, self.kernel, self.dilation, int(self.causal)
-        b.in_norm, b.dw_norm, b.pw_norm = kinds["in"], kinds["dw"], kinds["pw"]
+        fused = "cln" not in kinds.values()
+        b.in_norm, b.dw_norm, b.pw_norm = [kinds[k] if fused else 0 for k in ("in", "dw", "pw")]
         b.E = self.emb_dim
         for k, v in t.items():
             setattr(b, k, ptr(v))
         _PLAN_SERIAL[0] += 1
         # tensors kept alive alongside the raw pointers
-        self._plan = {"block": b, "tensors": t, "serial": _PLAN_SERIAL[0]}
+        self._plan = {"block": b, "tensors": t, "serial": _PLAN_SERIAL[0], "kinds": kinds, "fused": fused}
         self._plan_sig = sig
         return self._plan
+
+    def forward_padded_staged(self, x: torch.Tensor, t: int, embed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Stage-by-stage block for norm mixes the fused driver has no form for (cLN): every 1x1 conv is its own
+        ps_conv1x1_f32, cLN + PReLU is ps_chan_layernorm_f32, gLN / bN1d stay consumer prologues.
+        `embed` is used as given (already normalised by ConvTasNet)."""
+        p = self.plan(x.device)
+        w, kinds = p["tensors"], p["kinds"]
+        n, c, ldt = x.shape
+        h = self.hid_channels
+        new = lambda rows: torch.empty(n, rows, ldt, dtype=torch.float32, device=x.device)  # noqa: E731
+
+        def settle(y, stats, name, rows):
+            """-> (tensor, prologue) the next stage consumes for the norm + PReLU that follow `y`."""
+            if kinds[name] == "cln":
+                return hip.chan_layernorm(y, t, w[name + "_gamma"], w[name + "_beta"], 1e-8,
+                                          slope=w[name + "_slope"]), None
+            return y, hip.make_prologue(kinds[name], True, stats, rows * t, 1e-8, w[name + "_gamma"], w[name + "_beta"],
+                                        w[name + "_slope"])
+
+        bias_n = None if embed is None else hip.embed_bias(embed.float(), w["in_embed_w"], False)
+        y, st = hip.conv1x1(x, t, w["in_wt"], h, None, None, bias_n, want_stats=kinds["in"] == PS_NORM_GLOBAL,
+                            out=new(h))
+        a, pro = settle(y, st, "in", h)
+        left = (self.kernel - 1) * self.dilation if self.causal else ((self.kernel - 1) // 2) * self.dilation
+        y, st = hip.dwconv(a, t, w["dw_w"], w["dw_b"], self.dilation, left, pro, kinds["dw"] == PS_NORM_GLOBAL)
+        a, pro = settle(y, st, "dw", h)
+        y, st = hip.conv1x1(a, t, w["pw_wt"], h, pro, w["pw_b"], want_stats=kinds["pw"] == PS_NORM_GLOBAL, out=new(h))
+        a, pro = settle(y, st, "pw", h)
+        out, _ = hip.conv1x1(a, t, w["out_wt"], c, pro, w["out_b"], res=x, out=new(c))
+        return out
 
     def forward(self, x: torch.Tensor, embed: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x [N,C,T], embed [N,E] -> [N,C,T] (conv_tasnet.py:67-90)."""
@@ -118,8 +153,10 @@ class TCN(_PlanCache, nn.Module):
             raise RuntimeError(f"TCN.forward: block built with emb_dim={self.emb_dim} but embed is "
                                f"{'given' if embed is not None else 'missing'} (the reference fails in in_conv)")
         p = self.plan(x.device)
-        blocks = (TcnBlock * 1)(p["block"])
         t = x.shape[-1]
+        if not p["fused"]:
+            return hip.unpad_rows(self.forward_padded_staged(hip.pad_rows(x), t, embed), t)
+        blocks = (TcnBlock * 1)(p["block"])
         out = hip.conv_tasnet(blocks, 1, hip.pad_rows(x), t, self.in_channels, self.hid_channels,
                               None if embed is None else embed.contiguous(), False)
         return hip.unpad_rows(out, t)
@@ -311,6 +348,8 @@ class ConvTasNet(_PlanCache, nn.Module):
         `lane` selects the cached scratch buffer (one per concurrent HIP stream of the caller)."""
         if self.tcn_layer.lower() == "gated":
             return self._forward_gated(x_pad, t, dvec)
+        if not all(m.plan(x_pad.device)["fused"] for stack in self.tcn_list for m in stack):
+            return self._forward_staged(x_pad, t, dvec)
         blocks, n_blocks = self.block_array(x_pad.device)
         need_embed = any(self.tcn_with_embed)
         if need_embed and dvec is None:
@@ -328,6 +367,17 @@ class ConvTasNet(_PlanCache, nn.Module):
         return hip.conv_tasnet(blocks, n_blocks, x_pad, t, self.input_dim, self.tcn_dim,
                                None if dvec is None else dvec.contiguous().float(),
                                bool(self.embed_norm), ws)
+
+    def _forward_staged(self, x: torch.Tensor, t: int, dvec: Optional[torch.Tensor]) -> torch.Tensor:
+        """Normal TCN blocks with a cLN somewhere: block by block, stage by stage."""
+        if any(self.tcn_with_embed) and dvec is None:
+            raise RuntimeError("ConvTasNet.forward: tcn_with_embed is set but no dvec was given")
+        if dvec is not None and self.embed_norm:
+            dvec = hip.l2_normalize(dvec.float())
+        for stack in self.tcn_list:
+            for i, blk in enumerate(stack):
+                x = blk.forward_padded_staged(x, t, dvec if self.tcn_with_embed[i] else None)
+        return x
 
     def _forward_gated(self, x: torch.Tensor, t: int, dvec: Optional[torch.Tensor]) -> torch.Tensor:
         """tcn_layer="gated": block by block (conv_tasnet.py:348-357)."""

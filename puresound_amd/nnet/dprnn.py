@@ -73,8 +73,9 @@ class DPRNN(PlanCache, nn.Module):
 
     # -- segment geometry -------------------------------------------------------------------------------
     def padded_frames_needed(self, t: int) -> int:
-        """T' = T + rest, rest = K - T % K in [1, K] (dprnn.py:142-147)."""
-        return t + self.seg_size - t % self.seg_size
+        """T' = T + rest, rest = K - T % K in [1, K] (dprnn.py:142-147); overlapped segments are re-laid out
+        into a buffer of their own, so the input rows only need their T frames."""
+        return t if self.seg_overlap else t + self.seg_size - t % self.seg_size
 
     def _run_blocks(self, x: torch.Tensor, tp: int, embed, init_states, want_states: bool):
         p = self._plan_get(x.device, self._build)
@@ -94,7 +95,10 @@ class DPRNN(PlanCache, nn.Module):
     def hidden_states_padded(self, e_pad: torch.Tensor, te: int):
         """DPRNN._get_hidden_states (dprnn.py:193-244): final inter-LSTM states of an enrolment pass, per block,
         in state layout [N, D*H, ldq]."""
-        tp = self.padded_frames_needed(te)
+        if self.seg_overlap:
+            e_pad, tp = hip.segment_split(e_pad, te, self.seg_size)
+        else:
+            tp = self.padded_frames_needed(te)
         if e_pad.shape[-1] < tp:
             raise RuntimeError("DPRNN: enrolment rows are shorter than the segment padding")
         _, states = self._run_blocks(e_pad, tp, None, None, True)
@@ -105,8 +109,9 @@ class DPRNN(PlanCache, nn.Module):
         """padded [N,C,ldt] (zero beyond T, ldt >= padded_frames_needed(T)) -> mask logits padded [N,C_out,ldt].
         embed: [N,E] vector, or in embedding-free mode the padded enrolment features with `embed_frames` frames."""
         if self.seg_overlap:
-            raise NotImplementedError("DPRNN on HIP: seg_overlap=True (50 % overlapped segments) is not supported yet")
-        tp = self.padded_frames_needed(t)
+            x_pad, tp = hip.segment_split(x_pad, t, self.seg_size)     # SplitMerge.split (dprnn.py:136-139)
+        else:
+            tp = self.padded_frames_needed(t)
         if x_pad.shape[-1] < tp:
             raise RuntimeError(f"DPRNN: rows hold {x_pad.shape[-1]} frames, the segment padding needs {tp}")
         init = None
@@ -116,6 +121,8 @@ class DPRNN(PlanCache, nn.Module):
             init = self.hidden_states_padded(embed, embed_frames)
             embed = None
         x, _ = self._run_blocks(x_pad, tp, embed, init, False)
+        if self.seg_overlap:
+            x = hip.segment_merge(x, tp, t, self.seg_size)              # SplitMerge.merge (dprnn.py:182-185)
         p = self._plan
         pro = hip.make_prologue(0, True, None, 0.0, 0.0, None, None, p["out_slope"])
         y, _ = hip.conv1x1(x, t, p["out"]["wt"], p["out"]["M"], pro, p["out"]["bias"])

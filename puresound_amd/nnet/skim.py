@@ -180,8 +180,8 @@ class SkiM(PlanCache, nn.Module):
         return dict(out=linear_plan(self.output_fc[1], device), out_slope=_f32(self.output_fc[0].weight, device))
 
     def padded_frames_needed(self, t: int) -> int:
-        """T' = T + rest, rest = K - T % K in [1, K] (skim.py:429-433)."""
-        return t + self.seg_size - t % self.seg_size
+        """T' = T + rest, rest = K - T % K in [1, K] (skim.py:429-433); overlapped segments get their own buffer."""
+        return t if self.seg_overlap else t + self.seg_size - t % self.seg_size
 
     def _fuse(self, i: int, x: torch.Tensor, tp: int, embed: Optional[torch.Tensor]) -> torch.Tensor:
         if embed is not None and self.block_with_embed[i]:
@@ -198,8 +198,9 @@ class SkiM(PlanCache, nn.Module):
                        lane: int = 0) -> torch.Tensor:
         """padded [N,C,ldt] (zero beyond T, ldt >= padded_frames_needed(T)), embed [N,E] -> mask logits padded."""
         if self.seg_overlap:
-            raise NotImplementedError("SkiM on HIP: seg_overlap=True (50 % overlapped segments) is not supported yet")
-        tp = self.padded_frames_needed(t)
+            x_pad, tp = hip.segment_split(x_pad, t, self.seg_size)     # SkiM.split (skim.py:334-369)
+        else:
+            tp = self.padded_frames_needed(t)
         if x_pad.shape[-1] < tp:
             raise RuntimeError(f"SkiM: rows hold {x_pad.shape[-1]} frames, the segment padding needs {tp}")
         k = self.seg_size
@@ -213,6 +214,8 @@ class SkiM(PlanCache, nn.Module):
             if i < self.n_blocks - 1:
                 h, c, _, _ = self.mem_lstm[i].forward_state(h, c, s)
                 shift = 1 if self.causal else 0
+        if self.seg_overlap:
+            x = hip.segment_merge(x, tp, t, self.seg_size)              # SkiM.merge (skim.py:371-408)
         return self._output(x, t)
 
     def forward(self, x: torch.Tensor, embed: Optional[torch.Tensor] = None) -> torch.Tensor:

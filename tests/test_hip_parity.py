@@ -215,7 +215,7 @@ def test_abi_rejects_bad_arguments(H, dev):
 # ------------------------------------------------------------------------------------------------
 # masker and wrapper against the reference's golden vectors
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["ctn_embed", "ctn_dil3_k5", "ctn_gated", "ctn_gated_causal"])
+@pytest.mark.parametrize("name", ["ctn_embed", "ctn_dil3_k5", "ctn_gated", "ctn_gated_causal", "tcn_cln"])
 def test_masker_matches_reference_golden(PA, dev, golden_dir, name):
     g = _load(golden_dir, name)
     model = cases.build(PA.NS, name).eval()
@@ -473,7 +473,7 @@ def test_full_batch_properties(PA, dev, golden_dir):
 # ------------------------------------------------------------------------------------------------
 from oracle import dualpath_oracle as DP  # noqa: E402
 
-RNN_CASES = [n for n, c in cases.CASES.items() if c["kind"] == "rnn" and not c["kw"].get("seg_overlap", False)]
+RNN_CASES = [n for n, c in cases.CASES.items() if c["kind"] == "rnn"]
 
 
 def _lstm_sd(inp, hid, bi, seed):
@@ -550,10 +550,22 @@ def test_recurrent_masker_matches_reference_golden(PA, dev, golden_dir, name):
     assert rel_max(y.cpu().numpy(), g["y"]) < TOL
 
 
-def test_overlapped_segments_are_rejected(PA, dev):
-    m = cases.build(PA.NS, "dprnn_overlap").eval().to(dev)
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 16, 25, device=dev))
+@pytest.mark.parametrize("t,k", [(25, 6), (24, 6), (27, 6), (53, 10), (7, 4)])
+def test_segment_split_merge_kernels(H, dev, t, k):
+    """SplitMerge.split / merge (lobe/trivial.py:178-241) incl. the reference's identity property
+    (test/test_lobe.py:50-54)."""
+    x = _rand((2, 5, t), 91)
+    seg, rest = DP.split_overlap(x, k)                       # [N,S,K,C]
+    xs, tp = H.segment_split(H.pad_rows(x.to(dev)), t, k)
+    assert tp == seg.shape[1] * k and H.overlap_geometry(t, k)[0] == rest
+    ref = seg.permute(0, 3, 1, 2).reshape(2, 5, tp)
+    assert torch.equal(xs[..., :tp].cpu(), ref)
+    back = H.segment_merge(xs, tp, t, k)
+    assert torch.equal(back[..., :t].cpu(), x)
+    y = _rand((2, 5, tp), 92)                                # merge of arbitrary segment data
+    refm = DP.merge_overlap(y.reshape(2, 5, -1, k).permute(0, 2, 3, 1), rest)
+    got = H.segment_merge(H.pad_rows(y.to(dev)), tp, t, k)
+    assert torch.allclose(got[..., :t].cpu(), refm, atol=1e-7)
 
 
 @pytest.mark.parametrize("name", ["cfg4_short", "cfg4_tse_short"])
