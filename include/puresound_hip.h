@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 1
+#define PS_ABI_VERSION 2
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -54,6 +54,7 @@ const char* ps_last_error(void);
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
  * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product", "segment_overlap",
+ * "film_conv", "lstm_gates_cell", "proj_layernorm",
  * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
@@ -224,6 +225,29 @@ int ps_lstm_f32(const ps_lstm_args* args, void* stream);
  *   merge = 1: dst frame t = (even-segment cover + odd-segment cover) / 2, T_dst = the original frame count. */
 int ps_segment_overlap_f32(const float* src, float* dst, int64_t rows, int T_src, int ld_src, int T_dst, int ld_dst,
                            int K, int merge, void* stream);
+
+/* Fused forms of the streaming frame step (StreamingSkiM.step_frame, streaming/skim_inference.py:176-218; frames =
+ * concurrent streams).  All three share the short-row GEMM (16 output channels x <= 64 frames per workgroup).
+ *
+ * ps_film_conv_f32: FiLM conditioning after its input norm (lobe/trivial.py:160-167):
+ *     y[c] = (Ws x + rs)[c] * x[c] + (Wb x + rb)[c]
+ *   wt_pairs = packed weight of the [2C][C] matrix whose rows (2c, 2c+1) are (cond_scale row c, cond_bias row c)
+ *   restricted to the feature columns; res_pairs [N][2C][ldt] = the embedding columns' per-frame contribution in the
+ *   same row order (NULL = none).
+ * ps_lstm_gates_cell_f32: gates = W [x; h] + b, then the LSTM cell, for a one-frame SegLSTM step
+ *   (skim.py:215-222 with seg_size 1).  xh [N][K][ldt] holds x on top of h_{t-1} (K = C + H); wt_units / bias_units
+ *   are [W_ih | W_hh] and b_ih + b_hh with rows reordered unit-major (row 4u+g = gate g of unit u, gates i,f,g,o).
+ *   c [N][H][ld_state] is updated in place, h' goes to h [N][H][ld_state], which must NOT alias the h rows of xh.
+ * ps_proj_layernorm_f32: y = res + LN(W x + b; gamma, beta, eps) (skim.py:223-227), optionally also
+ *   y2 = LN(y; gamma2, beta2, eps2) (the next block's FiLM input norm) and x_copy = x (hands h' back to the xh block).
+ *   M <= 256. */
+int ps_film_conv_f32(const float* x, const float* wt_pairs, const float* res_pairs, float* y, int N, int C, int T,
+                     int ldt, void* stream);
+int ps_lstm_gates_cell_f32(const float* xh, const float* wt_units, const float* bias_units, float* c, float* h, int N,
+                           int K, int H, int T, int ldt, int ld_state, void* stream);
+int ps_proj_layernorm_f32(const float* x, const float* wt, const float* bias, const float* gamma, const float* beta,
+                          float eps, const float* res, float* y, const float* gamma2, const float* beta2, float eps2,
+                          float* y2, float* x_copy, int N, int K, int M, int T, int ldt, void* stream);
 
 /* One cell update per (unit, frame) from COMPLETE gate pre-activations gates [N][D*4H][ld_gates] (W_ih x + W_hh h + both
  * biases: the streaming step puts [x; h] on the K axis of one ps_conv1x1_f32):  c' = sig(f) c + sig(i) tanh(g) in

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -71,6 +71,10 @@ SIGNATURES = {
     "ps_unfold_taps_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 7 + [_vp, _vp, _vp, C.c_int, _vp]),
     "ps_gated_product_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [C.POINTER(Prologue), C.POINTER(Prologue), _vp]),
     "ps_segment_overlap_f32": (C.c_int, [_vp, _vp, C.c_int64] + [C.c_int] * 6 + [_vp]),
+    "ps_film_conv_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
+    "ps_lstm_gates_cell_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp] + [C.c_int] * 6 + [_vp]),
+    "ps_proj_layernorm_f32": (C.c_int, [_vp] * 5 + [C.c_float, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp] + [C.c_int] * 5
+                              + [_vp]),
     "ps_lstm_cell_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_chan_layernorm_f32": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
     "ps_film_apply_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),

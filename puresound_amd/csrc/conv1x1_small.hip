@@ -81,6 +81,182 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(SmallArgs a) {
   }
 }
 
+// ---- fused streaming-step forms --------------------------------------------------------------------------------
+// The reduction above leaves every finishing thread with four CONSECUTIVE output rows of one frame.  Packing the weight
+// rows so that those four rows belong together turns two elementwise kernels of the streaming step into epilogues:
+//   FiLM   rows (2c, 2c+1) = (cond_scale row c, cond_bias row c)  ->  y[c] = scale * x[c] + bias      (x = the GEMM input)
+//   cell   rows 4u .. 4u+3 = gates i, f, g, o of hidden unit u    ->  c' = sig(f) c + sig(i) tanh(g), h' = sig(o) tanh(c')
+struct FusedArgs {
+  SmallArgs g;
+  float* c_state;  // cell: [N][H][ld_state], in place
+  float* h_out;    // cell: [N][H][ld_state]
+  int ld_state;
+};
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int NCB, int EPI>  // EPI 1 = FiLM, 2 = LSTM cell
+__global__ __launch_bounds__(256) void conv1x1_small_fused_kernel(FusedArgs fa) {
+  const SmallArgs& a = fa.g;
+  __shared__ f32x4 part[4][NCB][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * 16, n = blockIdx.y;
+  const int t0 = blockIdx.z * (NCB * 16);
+  const int m = m0 + r;
+  const float* wp = a.wt + ((size_t)(m >> 8) * a.Kp) * 256 + (m & 255);
+  const float* xp = a.x + (size_t)n * a.K * a.ldt + t0 + r;
+  f32x4 acc[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk4 = a.Kp / 4;
+#pragma unroll 4
+  for (int i = w; i < nk4; i += 4) {
+    const int k = 4 * i + kq;
+    const float av = wp[(size_t)k * 256];
+    const bool kin = k < a.K;
+    float bv[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) bv[cb] = kin ? xp[(size_t)k * a.ldt + cb * 16] : 0.f;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[cb], acc[cb], 0, 0, 0);
+  }
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) part[w][cb][lane] = acc[cb];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < NCB * 64; idx += 256) {
+    const int cb = idx >> 6, ln = idx & 63;
+    f32x4 s = (part[0][cb][ln] + part[1][cb][ln]) + (part[2][cb][ln] + part[3][cb][ln]);
+    const int t = t0 + cb * 16 + (ln & 15);
+    const int mq = m0 + 4 * (ln >> 4);  // first of the four rows
+    if (t >= a.T || mq >= a.M) continue;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      if (a.bias) s[reg] += a.bias[mq + reg];
+      if (a.res) s[reg] += a.res[((size_t)n * a.M + mq + reg) * a.ldt + t];
+    }
+    if constexpr (EPI == 1) {
+      const int c0 = mq >> 1, C = a.M >> 1;
+      const float x0 = a.x[((size_t)n * a.K + c0) * a.ldt + t], x1 = a.x[((size_t)n * a.K + c0 + 1) * a.ldt + t];
+      a.y[((size_t)n * C + c0) * a.ldt + t] = s[0] * x0 + s[1];
+      a.y[((size_t)n * C + c0 + 1) * a.ldt + t] = s[2] * x1 + s[3];
+    } else {
+      const int u = mq >> 2, H = a.M >> 2;
+      const size_t so = ((size_t)n * H + u) * fa.ld_state + t;
+      const float cn = sigm(s[1]) * fa.c_state[so] + sigm(s[0]) * tanhf(s[2]);
+      fa.c_state[so] = cn;
+      fa.h_out[so] = sigm(s[3]) * tanhf(cn);
+    }
+  }
+}
+
+// Projection + LayerNorm + residual (+ the NEXT block's input LayerNorm) of the streaming step: a workgroup owns ALL M
+// output channels of 16 frames (waves split the channel blocks, each walks the whole K), the [M][16] tile meets in
+// LDS and every frame is normalised over its M channels there:
+//   y  = res + LN(W x + b; gamma, beta, eps)         y2 = LN(y; gamma2, beta2, eps2)   (optional)
+struct ProjLnArgs {
+  const float* x;
+  const float* wt;
+  const float* bias;
+  const float* gamma;
+  const float* beta;
+  const float* res;
+  float* y;
+  const float* gamma2;
+  const float* beta2;
+  float* y2;
+  float* x_copy;  // optional: the input rows are also written here (same layout), frames [0, T)
+  float eps, eps2;
+  int K, Kp, M, T, ldt;
+};
+
+constexpr int PLN_MAXM = 256;
+
+template <int NRB>  // row blocks of 16 output channels: 8 (M <= 128) or 16 (M <= 256)
+__global__ __launch_bounds__(256) void proj_layernorm_kernel(ProjLnArgs a) {
+  __shared__ f32x4 part[4][NRB][64];
+  __shared__ float tile[NRB * 16][17];
+  __shared__ float red[16][17];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int t0 = blockIdx.x * 16, n = blockIdx.y;
+  const float* xp = a.x + (size_t)n * a.K * a.ldt + t0 + r;
+  // the four waves split K; every wave accumulates all row blocks of its K share
+  f32x4 acc[NRB];
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk4 = a.Kp / 4;
+#pragma unroll 2
+  for (int i = w; i < nk4; i += 4) {
+    const int k = 4 * i + kq;
+    const float bv = (k < a.K) ? xp[(size_t)k * a.ldt] : 0.f;
+    if (a.x_copy && k < a.K && t0 + r < a.T) a.x_copy[((size_t)n * a.K + k) * a.ldt + t0 + r] = bv;
+    float av[NRB];
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) {
+      const int m = j * 16 + r;  // weights are zero padded to 256 rows per tile
+      av[j] = a.wt[((size_t)(m >> 8) * a.Kp + k) * 256 + (m & 255)];
+    }
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv, acc[j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) part[w][j][lane] = acc[j];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < NRB * 64; idx += 256) {
+    const int j = idx >> 6, ln = idx & 63;
+    const f32x4 s = (part[0][j][ln] + part[1][j][ln]) + (part[2][j][ln] + part[3][j][ln]);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int m = j * 16 + 4 * (ln >> 4) + reg;
+      if (m < a.M) tile[m][ln & 15] = s[reg] + (a.bias ? a.bias[m] : 0.f);
+    }
+  }
+  __syncthreads();
+  // 16 frames x 16 channel parts
+  const int f = threadIdx.x & 15, cp = threadIdx.x >> 4;
+  const int t = t0 + f;
+  auto frame_stats = [&](float& mean, float& rstd, float eps) {
+    float s = 0.f;
+    for (int m = cp; m < a.M; m += 16) s += tile[m][f];
+    red[cp][f] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) tot += red[p][f];
+    mean = tot / (float)a.M;
+    __syncthreads();
+    float q = 0.f;
+    for (int m = cp; m < a.M; m += 16) {
+      const float dv = tile[m][f] - mean;
+      q += dv * dv;
+    }
+    red[cp][f] = q;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) tot += red[p][f];
+    rstd = 1.f / sqrtf(tot / (float)a.M + eps);
+    __syncthreads();
+  };
+  float mean, rstd;
+  frame_stats(mean, rstd, a.eps);
+  for (int m = cp; m < a.M; m += 16) {
+    float v = (tile[m][f] - mean) * rstd * a.gamma[m] + a.beta[m];
+    const size_t off = ((size_t)n * a.M + m) * a.ldt + t;
+    if (a.res && t < a.T) v += a.res[off];
+    if (t < a.T) a.y[off] = v;
+    tile[m][f] = v;
+  }
+  if (a.y2) {
+    __syncthreads();
+    frame_stats(mean, rstd, a.eps2);
+    if (t < a.T)
+      for (int m = cp; m < a.M; m += 16)
+        a.y2[((size_t)n * a.M + m) * a.ldt + t] = (tile[m][f] - mean) * rstd * a.gamma2[m] + a.beta2[m];
+  }
+}
+
 int conv1x1_small_launch(const float* x, const float* wt, float* y, int N, int K, int M, int T, int ldt,
                          const ps_prologue* pro, const float* bias, const float* bias_n, const float* res,
                          hipStream_t stream) {
@@ -121,3 +297,101 @@ int conv1x1_small_launch(const float* x, const float* wt, float* y, int N, int K
 }
 
 }  // namespace ps
+
+using namespace ps;
+
+static int small_status(const char* who) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", who, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+static int fused_launch(const char* who, int epi, FusedArgs& fa, int N, hipStream_t stream) {
+  const SmallArgs& a = fa.g;
+  const int ncb = a.T <= 16 ? 1 : a.T <= 32 ? 2 : 4;
+  dim3 grid((a.M + 15) / 16, N, (a.T + ncb * 16 - 1) / (ncb * 16));
+  LaunchTimer timer(who, stream);
+#define PS_FUSED(NCB)                                                                              \
+  if (epi == 1)                                                                                    \
+    hipLaunchKernelGGL((conv1x1_small_fused_kernel<NCB, 1>), grid, dim3(256), 0, stream, fa);      \
+  else                                                                                             \
+    hipLaunchKernelGGL((conv1x1_small_fused_kernel<NCB, 2>), grid, dim3(256), 0, stream, fa);
+  if (ncb == 1) {
+    PS_FUSED(1)
+  } else if (ncb == 2) {
+    PS_FUSED(2)
+  } else {
+    PS_FUSED(4)
+  }
+#undef PS_FUSED
+  return 0;
+}
+
+extern "C" int ps_film_conv_f32(const float* x, const float* wt_pairs, const float* res_pairs, float* y, int N, int C,
+                                int T, int ldt, void* stream) {
+  if (!x || !wt_pairs || !y || N <= 0 || C <= 0 || C % 2 || T <= 0 || ldt < T || N > 65535) {
+    set_error("ps_film_conv_f32: bad argument (N=%d C=%d T=%d ldt=%d; C must be even)", N, C, T, ldt);
+    return PS_E_INVALID;
+  }
+  FusedArgs fa{};
+  fa.g.x = x;
+  fa.g.wt = wt_pairs;
+  fa.g.y = y;
+  fa.g.res = res_pairs;
+  fa.g.K = C;
+  fa.g.Kp = (C + 15) / 16 * 16;
+  fa.g.M = 2 * C;
+  fa.g.T = T;
+  fa.g.ldt = ldt;
+  fused_launch("film_conv", 1, fa, N, (hipStream_t)stream);
+  return small_status("ps_film_conv_f32");
+}
+
+extern "C" int ps_lstm_gates_cell_f32(const float* xh, const float* wt_units, const float* bias_units, float* c,
+                                      float* h, int N, int K, int H, int T, int ldt, int ld_state, void* stream) {
+  if (!xh || !wt_units || !c || !h || N <= 0 || K <= 0 || H <= 0 || T <= 0 || ldt < T || ld_state < T || N > 65535) {
+    set_error("ps_lstm_gates_cell_f32: bad argument (N=%d K=%d H=%d T=%d)", N, K, H, T);
+    return PS_E_INVALID;
+  }
+  FusedArgs fa{};
+  fa.g.x = xh;
+  fa.g.wt = wt_units;
+  fa.g.bias = bias_units;
+  fa.g.K = K;
+  fa.g.Kp = (K + 15) / 16 * 16;
+  fa.g.M = 4 * H;
+  fa.g.T = T;
+  fa.g.ldt = ldt;
+  fa.c_state = c;
+  fa.h_out = h;
+  fa.ld_state = ld_state;
+  fused_launch("lstm_gates_cell", 2, fa, N, (hipStream_t)stream);
+  return small_status("ps_lstm_gates_cell_f32");
+}
+
+extern "C" int ps_proj_layernorm_f32(const float* x, const float* wt, const float* bias, const float* gamma,
+                                     const float* beta, float eps, const float* res, float* y, const float* gamma2,
+                                     const float* beta2, float eps2, float* y2, float* x_copy, int N, int K, int M,
+                                     int T, int ldt, void* stream) {
+  if (!x || !wt || !gamma || !beta || !y || N <= 0 || K <= 0 || M <= 0 || T <= 0 || ldt < T || N > 65535 ||
+      (y2 && (!gamma2 || !beta2))) {
+    set_error("ps_proj_layernorm_f32: bad argument (N=%d K=%d M=%d T=%d)", N, K, M, T);
+    return PS_E_INVALID;
+  }
+  if (M > PLN_MAXM) {
+    set_error("ps_proj_layernorm_f32: M=%d > %d output channels", M, PLN_MAXM);
+    return PS_E_UNSUPPORTED;
+  }
+  ProjLnArgs a{x, wt, bias, gamma, beta, res, y, gamma2, beta2, y2, x_copy, eps, eps2, K, (K + 15) / 16 * 16, M, T, ldt};
+  {
+    LaunchTimer timer("proj_layernorm", (hipStream_t)stream);
+    if (M <= 128)
+      hipLaunchKernelGGL((proj_layernorm_kernel<8>), dim3((T + 15) / 16, N), dim3(256), 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((proj_layernorm_kernel<16>), dim3((T + 15) / 16, N), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  return small_status("ps_proj_layernorm_f32");
+}

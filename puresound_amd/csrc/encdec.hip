@@ -18,11 +18,11 @@ template <int WIN>
 __global__ __launch_bounds__(256) void free_encode_kernel(const float* __restrict__ wav,
                                                           const float* __restrict__ w,
                                                           float* __restrict__ feats, int L, int C, int win,
-                                                          int hop, int T, int ldt, int relu) {
+                                                          int hop, int T, int ldt, int relu, int cchunk) {
   const int n = blockIdx.z;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  const int c0 = blockIdx.y * ENC_CCHUNK;
-  const int c1 = min(c0 + ENC_CCHUNK, C);
+  const int c0 = blockIdx.y * cchunk;
+  const int c1 = min(c0 + cchunk, C);
   const bool live = t < T;
   const float* xs = wav + (size_t)n * L + (size_t)(live ? t : 0) * hop;
   float* out = feats + ((size_t)n * C) * ldt + t;
@@ -167,6 +167,33 @@ __global__ __launch_bounds__(256) void free_decode_generic_kernel(const float* _
   out[(size_t)n * Lout + s] = out_constrain(accv, out_mode);
 }
 
+// hop == win (no overlap; the streaming harness decodes one frame per stream): one workgroup per frame, threads =
+// win output samples x 256/win channel parts, partial sums meet in LDS.
+__global__ __launch_bounds__(256) void free_decode_frame_kernel(const float* __restrict__ feats,
+                                                                const float* __restrict__ mask, int mask_mode,
+                                                                const float* __restrict__ w, float* __restrict__ out,
+                                                                int C, int T, int ldt, int win, int out_mode) {
+  __shared__ float red[256];
+  const int t = blockIdx.x, n = blockIdx.y;
+  const int parts = 256 / win;
+  const int j = threadIdx.x % win, cp = threadIdx.x / win;
+  const float* f = feats + (size_t)n * C * ldt + t;
+  const float* m = mask ? mask + (size_t)n * C * ldt + t : nullptr;
+  float s = 0.f;
+  for (int c = cp; c < C; c += parts) {
+    float e = f[(size_t)c * ldt];
+    if (m) e *= mask_act(m[(size_t)c * ldt], mask_mode);
+    s = fmaf(w[(size_t)c * win + j], e, s);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (cp == 0) {
+    float tot = 0.f;
+    for (int p = 0; p < parts; ++p) tot += red[p * win + j];
+    out[((size_t)n * T + t) * win + j] = out_constrain(tot, out_mode);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                        int64_t rows, int T, int ldt) {
@@ -262,15 +289,20 @@ extern "C" int ps_free_encode_f32(const float* wav, const float* w, float* feats
               (L - win) / hop + 1, ldt, kTileT);
     return PS_E_INVALID;
   }
-  dim3 grid((T + 255) / 256, (C + ENC_CCHUNK - 1) / ENC_CCHUNK, N);
+  // few frames (streaming: one frame per stream): spread the channels over more workgroups
+  const int cchunk = ((long long)N * ((T + 255) / 256) * ((C + ENC_CCHUNK - 1) / ENC_CCHUNK) < 64) ? 4 : ENC_CCHUNK;
+  dim3 grid((T + 255) / 256, (C + cchunk - 1) / cchunk, N);
   hipStream_t s = (hipStream_t)stream;
   LaunchTimer timer("free_encode", s);
   if (win == 32)
-    hipLaunchKernelGGL(free_encode_kernel<32>, grid, dim3(256), 0, s, wav, w, feats, L, C, win, hop, T, ldt, relu);
+    hipLaunchKernelGGL(free_encode_kernel<32>, grid, dim3(256), 0, s, wav, w, feats, L, C, win, hop, T, ldt, relu,
+                       cchunk);
   else if (win == 16)
-    hipLaunchKernelGGL(free_encode_kernel<16>, grid, dim3(256), 0, s, wav, w, feats, L, C, win, hop, T, ldt, relu);
+    hipLaunchKernelGGL(free_encode_kernel<16>, grid, dim3(256), 0, s, wav, w, feats, L, C, win, hop, T, ldt, relu,
+                       cchunk);
   else
-    hipLaunchKernelGGL(free_encode_kernel<0>, grid, dim3(256), 0, s, wav, w, feats, L, C, win, hop, T, ldt, relu);
+    hipLaunchKernelGGL(free_encode_kernel<0>, grid, dim3(256), 0, s, wav, w, feats, L, C, win, hop, T, ldt, relu,
+                       cchunk);
   return check_launch("ps_free_encode_f32");
 }
 
@@ -294,6 +326,9 @@ extern "C" int ps_free_decode_f32(const float* feats, const float* mask, int mas
     constexpr int BTF = 255;
     hipLaunchKernelGGL((free_decode_kernel<16, 8>), dim3((T + BTF - 1) / BTF, N), dim3(256), 0, s, feats, mask,
                        mask_act, w, out, C, T, ldt, out_mode);
+  } else if (hop == win && win <= 256 && 256 % win == 0 && T <= 65535) {
+    hipLaunchKernelGGL(free_decode_frame_kernel, dim3(T, N), dim3(256), 0, s, feats, mask, mask_act, w, out, C, T, ldt,
+                       win, out_mode);
   } else {
     const int Lout = (T - 1) * hop + win;
     hipLaunchKernelGGL(free_decode_generic_kernel, dim3((Lout + 255) / 256, N), dim3(256), 0, s, feats, mask,

@@ -277,6 +277,43 @@ def segment_merge(x: torch.Tensor, tp: int, t: int, k: int) -> torch.Tensor:
     return y
 
 
+def film_conv(x: torch.Tensor, t: int, wt_pairs: torch.Tensor, res_pairs: Optional[torch.Tensor],
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """FiLM (after its input norm) in one kernel: (Ws x + rs) * x + (Wb x + rb); weight rows paired (scale, bias)."""
+    require_device(x, "film_conv")
+    n, c, ldt = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    check(lib().ps_film_conv_f32(ptr(x), ptr(wt_pairs), ptr(res_pairs), ptr(y), n, c, t, ldt, stream_ptr(x.device)),
+          "ps_film_conv_f32")
+    return y
+
+
+def lstm_gates_cell(xh: torch.Tensor, t: int, wt_units: torch.Tensor, bias_units: torch.Tensor, c: torch.Tensor,
+                    h: torch.Tensor, hidden: int) -> None:
+    """gates GEMM over [x; h] + LSTM cell; c in place, h' into `h` (not the h rows of xh)."""
+    require_device(xh, "lstm_gates_cell")
+    n, k, ldt = xh.shape
+    if n != 1 and (not c.is_contiguous() or not h.is_contiguous()):
+        raise RuntimeError("lstm_gates_cell: state views are supported for N = 1 only")
+    check(lib().ps_lstm_gates_cell_f32(ptr(xh), ptr(wt_units), ptr(bias_units), ptr(c), ptr(h), n, k, hidden, t, ldt,
+                                       c.stride(1), stream_ptr(xh.device)), "ps_lstm_gates_cell_f32")
+
+
+def proj_layernorm(x: torch.Tensor, t: int, wt: torch.Tensor, bias: Optional[torch.Tensor], m: int,
+                   gamma: torch.Tensor, beta: torch.Tensor, eps: float, res: Optional[torch.Tensor],
+                   norm2: Optional[tuple] = None, x_copy: Optional[torch.Tensor] = None):
+    """y = res + LN(W x + b) (+ y2 = LN2(y), + copy of x); returns (y, y2)."""
+    require_device(x, "proj_layernorm")
+    n, k, ldt = x.shape
+    y = torch.empty(n, m, ldt, dtype=torch.float32, device=x.device)
+    y2 = torch.empty_like(y) if norm2 is not None else None
+    g2, b2, e2 = norm2 if norm2 is not None else (None, None, 0.0)
+    check(lib().ps_proj_layernorm_f32(ptr(x), ptr(wt), ptr(bias), ptr(gamma), ptr(beta), float(eps), ptr(res), ptr(y),
+                                      ptr(g2), ptr(b2), float(e2), ptr(y2), ptr(x_copy), n, k, m, t, ldt,
+                                      stream_ptr(x.device)), "ps_proj_layernorm_f32")
+    return y, y2
+
+
 def lstm_cell(gates: torch.Tensor, c: torch.Tensor, h: torch.Tensor, hidden: int, dirs: int, t: int) -> None:
     """One cell update per (unit, frame): gates padded [N,D*4H,ld] (complete pre-activations), c in place, h out
     (both [N,D*H,ld'] rows, possibly views into larger row blocks)."""

@@ -22,14 +22,20 @@ class _PerFrameCondition:
 
     _per_frame = None
 
+    _per_frame_pairs = None
+
     def set_per_frame_condition(self, condition: torch.Tensor, normalize: bool) -> None:
         p = self._plan_get(condition.device, self._build)
-        rows = hip.embed_bias(condition.float(), p["w_embed"], normalize)          # [B, M]
-        term = hip.pad_rows(rows.t().unsqueeze(0))                                  # [1, M, ldB]
-        if self._per_frame is None or self._per_frame.shape != term.shape or self._per_frame.device != term.device:
-            self._per_frame = term
-        else:
-            self._per_frame.copy_(term)
+        for attr, key in (("_per_frame", "w_embed"), ("_per_frame_pairs", "w_embed_pairs")):
+            if key not in p:
+                continue
+            rows = hip.embed_bias(condition.float(), p[key], normalize)             # [B, M]
+            term = hip.pad_rows(rows.t().unsqueeze(0))                               # [1, M, ldB]
+            cur = getattr(self, attr)
+            if cur is None or cur.shape != term.shape or cur.device != term.device:
+                setattr(self, attr, term)
+            else:
+                cur.copy_(term)
 
     def _embed_term(self, condition: torch.Tensor, w_embed: torch.Tensor, normalize: bool, per_frame: bool):
         """-> (bias_n, res) for ps_conv1x1_f32."""
@@ -57,6 +63,10 @@ class FiLM(_PerFrameCondition, PlanCache, nn.Module):
         ws, wb = _f32(self.cond_scale.weight, device)[:, :, 0], _f32(self.cond_bias.weight, device)[:, :, 0]
         p = dict(wt=hip.pack_wt(torch.cat([ws[:, :c], wb[:, :c]], 0)),
                  w_embed=torch.cat([ws[:, c:], wb[:, c:]], 0).contiguous())
+        # rows paired (scale c, bias c) for the one-kernel streaming form (ps_film_conv_f32)
+        pairs = torch.stack([ws, wb], 1).reshape(2 * c, -1)
+        p["wt_pairs"] = hip.pack_wt(pairs[:, :c].contiguous())
+        p["w_embed_pairs"] = pairs[:, c:].contiguous()
         if self.inp_norm:
             p["norm"] = layernorm_plan(self.norm, device)
         return p
@@ -73,6 +83,12 @@ class FiLM(_PerFrameCondition, PlanCache, nn.Module):
         sb, _ = hip.conv1x1(x, t, p["wt"], 2 * c, None, None, bias_n, res,
                             out=torch.empty(n, 2 * c, ldt, dtype=torch.float32, device=x.device))
         return hip.film_apply(x, sb, t, out)
+
+    def step_normed(self, xn: torch.Tensor, t: int, out: torch.Tensor) -> torch.Tensor:
+        """Streaming: xn is the ALREADY input-normalised frame block [1,C,ldB]; one kernel, per-frame embeddings
+        from set_per_frame_condition."""
+        p = self._plan_get(xn.device, self._build)
+        return hip.film_conv(xn, t, p["wt_pairs"], self._per_frame_pairs, out)
 
     def forward(self, x: torch.Tensor, condition: torch.Tensor) -> torch.Tensor:
         """x [N,C,T], condition [N,E] -> [N,C,T]."""

@@ -115,6 +115,12 @@ class SegLSTM(PlanCache, nn.Module):
         if "w_gates" not in p[0]:
             w = torch.cat([_f32(self.lstm.weight_ih_l0, device), _f32(self.lstm.weight_hh_l0, device)], dim=1)
             p[0]["w_gates"] = hip.pack_wt(w)
+            # unit-major rows (4u + g) for the fused gates + cell kernel
+            h = self.hidden_size
+            order = (torch.arange(4, device=device).reshape(1, 4) * h + torch.arange(h, device=device).reshape(h, 1)
+                     ).reshape(-1)
+            p[0]["w_units"] = hip.pack_wt(w[order].contiguous())
+            p[0]["bias_units"] = p[0]["bias"][order].contiguous()
         return p
 
     def forward_padded(self, x: torch.Tensor, tp: int, q: int, k: int, h0, c0, state_shift: int = 0):
@@ -191,7 +197,8 @@ class SkiM(PlanCache, nn.Module):
     def _output(self, x: torch.Tensor, t: int) -> torch.Tensor:
         p = self._plan_get(x.device, self._build)
         pro = hip.make_prologue(0, True, None, 0.0, 0.0, None, None, p["out_slope"])
-        y, _ = hip.conv1x1(x, t, p["out"]["wt"], p["out"]["M"], pro, p["out"]["bias"])
+        y, _ = hip.conv1x1(x, t, p["out"]["wt"], p["out"]["M"], pro, p["out"]["bias"],
+                           out=torch.empty(x.shape[0], p["out"]["M"], x.shape[2], dtype=torch.float32, device=x.device))
         return y
 
     def forward_padded(self, x_pad: torch.Tensor, t: int, embed: Optional[torch.Tensor] = None,

@@ -14,6 +14,7 @@ import torch
 
 from .. import hip
 from ..nnet._plans import lstm_path
+from ..nnet.lobe.trivial import FiLM
 from ..nnet.skim import SkiM
 
 
@@ -91,6 +92,7 @@ class StreamingSkiM(SkiM):
         else:
             self._seg_h = [z(rows) for _ in range(self.n_blocks)]
         self._seg_c = [z(rows) for _ in range(self.n_blocks)]
+        self._h_new = [z(rows) for _ in range(self.n_blocks)]
         self._mem_h = [(z(rows), z(rows)) for _ in range(self.n_blocks - 1)]
         self._mem_c = [(z(rows), z(rows)) for _ in range(self.n_blocks - 1)]
         self._x_in = z(self.input_size)
@@ -134,7 +136,7 @@ class StreamingSkiM(SkiM):
         place, returns padded [1, C_out, ldB]."""
         b = self.streams
         c_in, hid = self.input_size, self.hidden_size
-        cur = self._x_in
+        cur, cur_ln = self._x_in, None
         for i in range(self.n_blocks):
             fused = self._embed_static is not None and self.block_with_embed[i]
             if not self.causal:
@@ -148,18 +150,30 @@ class StreamingSkiM(SkiM):
             rnn, proj, norm = self.seg_lstm[i].step_plan(cur.device)
             xh = self._xh[i]
             x_rows, h_rows = xh[:, :c_in, :], xh[:, c_in:, :]
-            if fused:
+            film = (fused and isinstance(self.seg_input_fusion[i], FiLM) and self.seg_input_fusion[i].inp_norm
+                    and c_in % 2 == 0)      # the paired-row kernel needs an even channel count
+            if film:
+                if cur_ln is None:      # block 0 (or after an unfused block): the input norm as its own kernel
+                    ln = self.seg_input_fusion[i]._plan_get(cur.device, self.seg_input_fusion[i]._build)["norm"]
+                    cur_ln = hip.chan_layernorm(cur, b, ln["gamma"], ln["beta"], ln["eps"])
+                self.seg_input_fusion[i].step_normed(cur_ln, b, x_rows)
+            elif fused:
                 self.seg_input_fusion[i].forward_padded(cur, b, self._embed_static, self.embed_norm, per_frame=True,
                                                         out=x_rows)
             else:
                 x_rows.copy_(cur)
-            ldb = xh.shape[-1]
-            gates, _ = hip.conv1x1(xh, b, rnn["w_gates"], 4 * hid, None, rnn["bias"],
-                                   out=torch.empty(1, 4 * hid, ldb, dtype=torch.float32, device=xh.device))
-            hip.lstm_cell(gates, self._seg_c[i], h_rows, hid, 1, b)
-            pr, _ = hip.conv1x1(h_rows, b, proj["wt"], proj["M"], None, proj["bias"],
-                                out=torch.empty(1, proj["M"], ldb, dtype=torch.float32, device=xh.device))
-            cur = hip.chan_layernorm(pr, b, norm["gamma"], norm["beta"], norm["eps"], res=x_rows)
+            # h' must not land in the rows the gates GEMM is still reading: it goes to a side buffer and the
+            # projection kernel, which reads all of it anyway, hands it back to the [x'; h] block
+            h_new = self._h_new[i]
+            hip.lstm_gates_cell(xh, b, rnn["w_units"], rnn["bias_units"], self._seg_c[i], h_new, hid)
+            nxt = self.seg_input_fusion[i + 1] if (i + 1 < self.n_blocks and self._embed_static is not None
+                                                   and self.block_with_embed[i + 1]) else None
+            norm2 = None
+            if isinstance(nxt, FiLM) and nxt.inp_norm and c_in % 2 == 0:
+                ln = nxt._plan_get(cur.device, nxt._build)["norm"]
+                norm2 = (ln["gamma"], ln["beta"], ln["eps"])
+            cur, cur_ln = hip.proj_layernorm(h_new, b, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"],
+                                             norm["eps"], x_rows, norm2, x_copy=h_rows)
         return self._output(cur, b)
 
     @torch.no_grad()

@@ -678,3 +678,46 @@ def test_gated_tcn_block_matches_oracle(PA, dev, norm, causal, film):
     ref0 = O.gated_tcn_block(x, sd, "", 3, 2, causal, norm, film, None) if film else None
     if film:  # FiLM blocks also run unconditioned (x_r = x)
         assert rel_max(blk(x.to(dev)).cpu().numpy(), ref0.numpy()) < 2e-5
+
+
+def test_fused_streaming_step_kernels(H, dev):
+    """ps_film_conv_f32 / ps_lstm_gates_cell_f32 / ps_proj_layernorm_f32 against their unfused compositions."""
+    n, c, hid, t = 1, 12, 8, 37
+    x = _rand((n, c, t), 101)
+    ws, wb = _rand((c, c), 102, -0.3, 0.3), _rand((c, c), 103, -0.3, 0.3)
+    rs, rb = _rand((n, c, t), 104), _rand((n, c, t), 105)
+    ref = (torch.matmul(ws, x) + rs) * x + (torch.matmul(wb, x) + rb)
+    pairs = torch.stack([ws, wb], 1).reshape(2 * c, c)
+    res_pairs = torch.stack([rs, rb], 2).reshape(n, 2 * c, t)
+    y = H.film_conv(H.pad_rows(x.to(dev)), t, H.pack_wt(pairs.to(dev)), H.pad_rows(res_pairs.to(dev)))
+    assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 2e-5
+    # gates + cell
+    xh = _rand((n, c + hid, t), 106)
+    w, bias = _rand((4 * hid, c + hid), 107, -0.3, 0.3), _rand((4 * hid,), 108)
+    c0 = _rand((n, hid, t), 109)
+    a = torch.matmul(w, xh) + bias.reshape(1, -1, 1)
+    gi, gf, gg, go = [a[:, k * hid:(k + 1) * hid] for k in range(4)]
+    c_ref = torch.sigmoid(gf) * c0 + torch.sigmoid(gi) * torch.tanh(gg)
+    h_ref = torch.sigmoid(go) * torch.tanh(c_ref)
+    order = (torch.arange(4).reshape(1, 4) * hid + torch.arange(hid).reshape(hid, 1)).reshape(-1)
+    c_d = H.pad_rows(c0.to(dev))
+    h_d = torch.zeros_like(c_d)
+    H.lstm_gates_cell(H.pad_rows(xh.to(dev)), t, H.pack_wt(w[order].contiguous().to(dev)), bias[order].to(dev), c_d,
+                      h_d, hid)
+    assert rel_max(c_d[..., :t].cpu().numpy(), c_ref.numpy()) < 2e-5
+    assert rel_max(h_d[..., :t].cpu().numpy(), h_ref.numpy()) < 2e-5
+    # projection + LayerNorm + residual (+ second LayerNorm, + copy)
+    for m, k in ((12, 8), (128, 256), (200, 20)):
+        hx, res = _rand((n, k, t), 110), _rand((n, m, t), 111)
+        wp, bp = _rand((m, k), 112, -0.3, 0.3), _rand((m,), 113)
+        g1, b1, g2, b2 = _rand((m,), 114, 0.5, 1.5), _rand((m,), 115), _rand((m,), 116, 0.5, 1.5), _rand((m,), 117)
+        p_ref = torch.matmul(wp, hx) + bp.reshape(1, -1, 1)
+        y_ref = res + DP.layer_norm(p_ref.transpose(1, 2), g1, b1).transpose(1, 2)
+        y2_ref = DP.layer_norm(y_ref.transpose(1, 2), g2, b2, 1e-5).transpose(1, 2)
+        hx_d = H.pad_rows(hx.to(dev))
+        cp = torch.zeros_like(hx_d)
+        y, y2 = H.proj_layernorm(hx_d, t, H.pack_wt(wp.to(dev)), bp.to(dev), m, g1.to(dev), b1.to(dev), 1e-5,
+                                 H.pad_rows(res.to(dev)), (g2.to(dev), b2.to(dev), 1e-5), x_copy=cp)
+        assert rel_max(y[..., :t].cpu().numpy(), y_ref.numpy()) < 2e-5
+        assert rel_max(y2[..., :t].cpu().numpy(), y2_ref.numpy()) < 2e-5
+        assert torch.equal(cp[..., :t].cpu(), hx)
