@@ -43,20 +43,33 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(SmallArgs a) {
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nk4 = a.Kp / 4;
-#pragma unroll 4
-  for (int i = w; i < nk4; i += 4) {
-    const int k = 4 * i + kq;
-    const float av = wp[(size_t)k * 256];
-    const bool kin = k < a.K;
-    float bv[NCB];
+  // explicit batches: all loads of UN k-steps are issued before their MFMAs (the loop is latency bound)
+  constexpr int UN = 8;
+  for (int i0 = w; i0 < nk4; i0 += 4 * UN) {
+    float av[UN], bv[UN][NCB];
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-      float v = kin ? xp[(size_t)k * a.ldt + cb * 16] : 0.f;
-      if constexpr (TR) v = kin ? small_transform(a, v, k, slope) : 0.f;
-      bv[cb] = v;
+    for (int u = 0; u < UN; ++u) {
+      const int k = 4 * (i0 + 4 * u) + kq;
+      const bool in = (i0 + 4 * u) < nk4;
+      const bool kin = in && k < a.K;
+      av[u] = in ? wp[(size_t)k * 256] : 0.f;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) bv[u][cb] = kin ? xp[(size_t)k * a.ldt + cb * 16] : 0.f;
+    }
+    if constexpr (TR) {
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int k = 4 * (i0 + 4 * u) + kq;
+        const bool kin = (i0 + 4 * u) < nk4 && k < a.K;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) bv[u][cb] = kin ? small_transform(a, bv[u][cb], k, slope) : 0.f;
+      }
     }
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[cb], acc[cb], 0, 0, 0);
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][cb], acc[cb], 0, 0, 0);
   }
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) part[w][cb][lane] = acc[cb];
@@ -110,16 +123,23 @@ __global__ __launch_bounds__(256) void conv1x1_small_fused_kernel(FusedArgs fa) 
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nk4 = a.Kp / 4;
-#pragma unroll 4
-  for (int i = w; i < nk4; i += 4) {
-    const int k = 4 * i + kq;
-    const float av = wp[(size_t)k * 256];
-    const bool kin = k < a.K;
-    float bv[NCB];
+  // explicit batches: all loads of UN k-steps are issued before their MFMAs (the loop is latency bound)
+  constexpr int UN = 8;
+  for (int i0 = w; i0 < nk4; i0 += 4 * UN) {
+    float av[UN], bv[UN][NCB];
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) bv[cb] = kin ? xp[(size_t)k * a.ldt + cb * 16] : 0.f;
+    for (int u = 0; u < UN; ++u) {
+      const int k = 4 * (i0 + 4 * u) + kq;
+      const bool in = (i0 + 4 * u) < nk4;
+      av[u] = in ? wp[(size_t)k * 256] : 0.f;
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[cb], acc[cb], 0, 0, 0);
+      for (int cb = 0; cb < NCB; ++cb) bv[u][cb] = (in && k < a.K) ? xp[(size_t)k * a.ldt + cb * 16] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][cb], acc[cb], 0, 0, 0);
   }
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) part[w][cb][lane] = acc[cb];
@@ -186,19 +206,28 @@ __global__ __launch_bounds__(256) void proj_layernorm_kernel(ProjLnArgs a) {
 #pragma unroll
   for (int j = 0; j < NRB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nk4 = a.Kp / 4;
-#pragma unroll 2
-  for (int i = w; i < nk4; i += 4) {
-    const int k = 4 * i + kq;
-    const float bv = (k < a.K) ? xp[(size_t)k * a.ldt] : 0.f;
-    if (a.x_copy && k < a.K && t0 + r < a.T) a.x_copy[((size_t)n * a.K + k) * a.ldt + t0 + r] = bv;
-    float av[NRB];
+  constexpr int UN = NRB == 8 ? 4 : 2;
+  for (int i0 = w; i0 < nk4; i0 += 4 * UN) {
+    float bv[UN], av[UN][NRB];
 #pragma unroll
-    for (int j = 0; j < NRB; ++j) {
-      const int m = j * 16 + r;  // weights are zero padded to 256 rows per tile
-      av[j] = a.wt[((size_t)(m >> 8) * a.Kp + k) * 256 + (m & 255)];
+    for (int u = 0; u < UN; ++u) {
+      const int k = 4 * (i0 + 4 * u) + kq;
+      const bool in = (i0 + 4 * u) < nk4;
+      bv[u] = (in && k < a.K) ? xp[(size_t)k * a.ldt] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) {
+        const int m = j * 16 + r;  // weights are zero padded to 256 rows per tile
+        av[u][j] = in ? a.wt[((size_t)(m >> 8) * a.Kp + k) * 256 + (m & 255)] : 0.f;
+      }
     }
 #pragma unroll
-    for (int j = 0; j < NRB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv, acc[j], 0, 0, 0);
+    for (int u = 0; u < UN; ++u) {
+      const int k = 4 * (i0 + 4 * u) + kq;
+      if (a.x_copy && (i0 + 4 * u) < nk4 && k < a.K && t0 + r < a.T)
+        a.x_copy[((size_t)n * a.K + k) * a.ldt + t0 + r] = bv[u];
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][j], bv[u], acc[j], 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int j = 0; j < NRB; ++j) part[w][j][lane] = acc[j];
