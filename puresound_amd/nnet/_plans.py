@@ -10,6 +10,11 @@ import torch.nn as nn
 from .. import hip
 
 
+import os
+
+FUSE_PROJ_LN = os.environ.get("PS_FUSE_PROJ_LN", "1") == "1"   # 0: separate projection GEMM + LayerNorm kernels
+
+
 def param_signature(module: nn.Module, device) -> tuple:
     sig = [(t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers())]
     sig.append(module.training)
@@ -84,6 +89,9 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
                         out=torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev))
     hseq, state = hip.lstm(gx, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride, h0, c0, want_state,
                            state_shift, state_out)
+    if proj["M"] <= 256 and FUSE_PROJ_LN:
+        y, _ = hip.proj_layernorm(hseq, t, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"], norm["eps"], x)
+        return y, state
     p, _ = hip.conv1x1(hseq, t, proj["wt"], proj["M"], None, proj["bias"],
                        out=torch.empty(n, proj["M"], ldt, dtype=torch.float32, device=dev))
     return hip.chan_layernorm(p, t, norm["gamma"], norm["beta"], norm["eps"], res=x), state
