@@ -54,7 +54,7 @@ const char* ps_last_error(void);
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
  * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product", "segment_overlap",
- * "film_conv", "lstm_gates_cell", "proj_layernorm",
+ * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average",
  * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
@@ -248,6 +248,11 @@ int ps_lstm_gates_cell_f32(const float* xh, const float* wt_units, const float* 
 int ps_proj_layernorm_f32(const float* x, const float* wt, const float* bias, const float* gamma, const float* beta,
                           float eps, const float* res, float* y, const float* gamma2, const float* beta2, float eps2,
                           float* y2, float* x_copy, int N, int K, int M, int T, int ldt, void* stream);
+
+/* Streaming harness overlap-add (egs/tse/demo/utils.py:121-128): out[b][j] = (tail[b][j] + cur[b][j]) / 2 for
+ * j < overlap (tail = the last `overlap` samples of the running output, row stride ld_tail), cur[b][j] otherwise. */
+int ps_overlap_average_f32(const float* tail, int ld_tail, const float* cur, float* out, int B, int win, int overlap,
+                           void* stream);
 
 /* One cell update per (unit, frame) from COMPLETE gate pre-activations gates [N][D*4H][ld_gates] (W_ih x + W_hh h + both
  * biases: the streaming step puts [x; h] on the K axis of one ps_conv1x1_f32):  c' = sig(f) c + sig(i) tanh(g) in

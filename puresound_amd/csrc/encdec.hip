@@ -194,6 +194,17 @@ __global__ __launch_bounds__(256) void free_decode_frame_kernel(const float* __r
   }
 }
 
+// Averaging overlap-add of the streaming harness (egs/tse/demo/utils.py:121-128): the first `ov` samples of the new
+// frame are averaged with the tail of the running output, the rest is copied.
+__global__ __launch_bounds__(256) void overlap_average_kernel(const float* __restrict__ tail, int ld_tail,
+                                                              const float* __restrict__ cur, float* __restrict__ out,
+                                                              int win, int ov) {
+  const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (j >= win) return;
+  const float v = cur[(size_t)b * win + j];
+  out[(size_t)b * win + j] = j < ov ? (tail[(size_t)b * ld_tail + j] + v) * 0.5f : v;
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                        int64_t rows, int T, int ldt) {
@@ -335,6 +346,18 @@ extern "C" int ps_free_decode_f32(const float* feats, const float* mask, int mas
                        mask_act, w, out, C, T, ldt, win, hop, out_mode);
   }
   return check_launch("ps_free_decode_f32");
+}
+
+extern "C" int ps_overlap_average_f32(const float* tail, int ld_tail, const float* cur, float* out, int B, int win,
+                                      int overlap, void* stream) {
+  if (!tail || !cur || !out || B <= 0 || B > 65535 || win <= 0 || overlap < 0 || overlap > win || ld_tail < overlap) {
+    set_error("ps_overlap_average_f32: bad argument (B=%d win=%d overlap=%d)", B, win, overlap);
+    return PS_E_INVALID;
+  }
+  LaunchTimer timer("overlap_average", (hipStream_t)stream);
+  hipLaunchKernelGGL(overlap_average_kernel, dim3((win + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, tail,
+                     ld_tail, cur, out, win, overlap);
+  return check_launch("ps_overlap_average_f32");
 }
 
 extern "C" int ps_embed_bias_f32(const float* dvec, const float* w_embed, float* bias_n, int N, int E, int M,

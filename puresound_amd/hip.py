@@ -314,6 +314,21 @@ def proj_layernorm(x: torch.Tensor, t: int, wt: torch.Tensor, bias: Optional[tor
     return y, y2
 
 
+def overlap_average(prev: torch.Tensor, cur: torch.Tensor, overlap: int) -> torch.Tensor:
+    """Streaming harness OLA: returns the new [B, win] block whose first `overlap` samples are the average of the
+    tail of `prev` [B, L] and the head of `cur` [B, win]."""
+    require_device(cur, "overlap_average")
+    b, win = cur.shape
+    if prev.shape[0] != b or prev.shape[1] < overlap or prev.stride(1) != 1:
+        raise RuntimeError("overlap_average: prev must be [B, L >= overlap] with contiguous rows")
+    cur = cur.contiguous()
+    out = torch.empty_like(cur)
+    tail = prev[:, prev.shape[1] - overlap:]
+    check(lib().ps_overlap_average_f32(ptr(tail), prev.stride(0), ptr(cur), ptr(out), b, win, overlap,
+                                       stream_ptr(cur.device)), "ps_overlap_average_f32")
+    return out
+
+
 def lstm_cell(gates: torch.Tensor, c: torch.Tensor, h: torch.Tensor, hidden: int, dirs: int, t: int) -> None:
     """One cell update per (unit, frame): gates padded [N,D*4H,ld] (complete pre-activations), c in place, h out
     (both [N,D*H,ld'] rows, possibly views into larger row blocks)."""

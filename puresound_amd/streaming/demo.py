@@ -22,8 +22,10 @@ def overlap_add(a: Optional[torch.Tensor], b: torch.Tensor, overlap_length: int)
     """egs/tse/demo/utils.py:121-128, on the last axis: the overlapped samples are averaged."""
     if a is None:
         return b
-    return torch.cat([a[..., :-overlap_length], (a[..., -overlap_length:] + b[..., :overlap_length]) / 2,
-                      b[..., overlap_length:]], dim=-1)
+    squeeze = b.dim() == 1
+    a2, b2 = (a.unsqueeze(0), b.unsqueeze(0)) if squeeze else (a, b)
+    out = torch.cat([a2[:, :a2.shape[1] - overlap_length], hip.overlap_average(a2, b2, overlap_length)], dim=-1)
+    return out[0] if squeeze else out
 
 
 class DemoTseNet(nn.Module):
