@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+                    help="matrix-pipe arithmetic of the 1x1 convs; the BASELINE metric is fp32 (default). The other "
+                         "modes are experiments and are labelled as such in the output line")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -111,6 +114,9 @@ def main():
     from puresound_amd.batch_shard import gather_utterances
     lib = _abi.lib()  # no HIP extension, no benchmark
     model = build_model(dev)
+    if args.gemm != "fp32":
+        model.masker.set_gemm_precision(args.gemm)
+        args.no_roofline = True  # the roofline object describes the fp32 MFMA kernel only
 
     g = torch.Generator().manual_seed(1234 + rank)
     noisy = ((torch.rand(B_PER_GPU, L, generator=g) * 2 - 1) * 0.5).to(dev)  # synthetic 16 kHz waveforms
@@ -147,7 +153,8 @@ def main():
         "metric": "audio samples/sec (16 kHz) on ns Conv-TasNet, batch=32x4s per GPU",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.gemm == "fp32" else ("f32 storage/accumulate, " + args.gemm + " products (EXPERIMENT)"),
+        "data": "synthetic",
         "config": {"workload": "egs/ns Conv-TasNet, learned-conv encoder (32/16/512), R=3 X=8 H=256, "
                                "batch=32x4 s fp32 per GPU (BASELINE configs[1])",
                    "global_batch": total_b, "samples_per_utt": L, "parallelism": f"dp{world}",

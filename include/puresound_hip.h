@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 2
+#define PS_ABI_VERSION 3
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -54,7 +54,7 @@ const char* ps_last_error(void);
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
  * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product", "segment_overlap",
- * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average",
+ * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "conv1x1_bf16",
  * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
@@ -173,6 +173,20 @@ int ps_attn_stats_pool_f32(const float* logits, const float* x, float* out, int 
                            float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * ps_conv1x1_bf16_f32: the same operation as ps_conv1x1_f32 (same prologue, bias, residual, statistics, fp32 tensors
+ * in HBM, fp32 accumulation) with the products on the bf16 matrix pipe.
+ *   planes = 1: operands rounded to bf16 -- the arithmetic BASELINE.json names for its bf16 configurations.
+ *   planes = 3: fp32-accurate: each operand is the sum of three bf16 terms and the six products down to 2^-16 of the
+ *               leading one are accumulated (dropped terms <= 2^-24 relative).
+ * wt_planes: the weight split the same way and laid out [ceil(M/256)][ceil(K/16)][planes][256][16] bf16 (zero
+ * padded); ps_conv1x1_bf16_weight_bytes gives its size.  K <= 512 when a prologue transform is present.
+ * ------------------------------------------------------------------------------------------- */
+size_t ps_conv1x1_bf16_weight_bytes(int M, int K, int planes);
+int ps_conv1x1_bf16_f32(const float* x, const void* wt_planes, float* y, int N, int K, int M, int T, int ldt, int planes,
+                        const ps_prologue* pro, const float* bias, const float* bias_n, const float* res,
+                        double* ostats, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * GatedTCN (conv_tasnet.py:129-215): its dense dilated convolutions run as ps_conv1x1_f32 over unfolded taps.
  *
  * ps_unfold_taps_f32: y[n][j*(K+E) + k][t] = x'[n][k][t + j*dilation - left] (0 outside [0,T)), where
@@ -287,6 +301,10 @@ typedef struct ps_tcn_block {
   const float *dw_w, *dw_b, *dw_gamma, *dw_beta, *dw_slope;
   const float *pw_wt, *pw_b, *pw_gamma, *pw_beta, *pw_slope; /* pw_wt: kernel layout */
   const float *out_wt, *out_b;                                /* out_wt: kernel layout */
+  /* matrix-pipe arithmetic of the three 1x1 convs: 0 = exact fp32 MFMA (the *_wt pointers above);
+   * 1 / 3 = ps_conv1x1_bf16_f32 with that many planes over the plane-packed weights below */
+  int gemm_planes;
+  const void *in_wb, *pw_wb, *out_wb;
 } ps_tcn_block;
 
 /* bytes of scratch ps_conv_tasnet_f32 needs for a batch (3 hidden maps + stats + embed bias) */

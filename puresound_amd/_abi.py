@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -42,7 +42,8 @@ class TcnBlock(C.Structure):
                 ("in_gamma", _vp), ("in_beta", _vp), ("in_slope", _vp),
                 ("dw_w", _vp), ("dw_b", _vp), ("dw_gamma", _vp), ("dw_beta", _vp), ("dw_slope", _vp),
                 ("pw_wt", _vp), ("pw_b", _vp), ("pw_gamma", _vp), ("pw_beta", _vp), ("pw_slope", _vp),
-                ("out_wt", _vp), ("out_b", _vp)]
+                ("out_wt", _vp), ("out_b", _vp),
+                ("gemm_planes", C.c_int), ("in_wb", _vp), ("pw_wb", _vp), ("out_wb", _vp)]
 
 
 # name -> (restype, argtypes); every symbol include/puresound_hip.h declares
@@ -65,6 +66,8 @@ SIGNATURES = {
     "ps_complex_mask_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
     "ps_istft_ola_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_conv1x1_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 5 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
+    "ps_conv1x1_bf16_weight_bytes": (C.c_size_t, [C.c_int] * 3),
+    "ps_conv1x1_bf16_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 6 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
     "ps_dwconv_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp]),
     "ps_attn_stats_pool_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
     "ps_lstm_f32": (C.c_int, [C.POINTER(LstmArgs), _vp]),

@@ -177,8 +177,18 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
     if (rc) return rc;
     bias_n = w.bias_n;
   }
-  rc = ps_conv1x1_f32(x_in, b.in_wt, w.y1, N, b.C, b.H, T, ldt, nullptr, nullptr, bias_n, nullptr,
-                      b.in_norm == PS_NORM_GLOBAL ? w.s1 : nullptr, stream);
+  // the three GEMMs: exact fp32 MFMA, or the bf16 pipe with 1 / 3 operand planes
+  auto gemm = [&](const float* x, const float* wt, const void* wb, float* y, int K, int M, const ps_prologue* pro,
+                  const float* bias, const float* bn, const float* res, double* st) {
+    if (b.gemm_planes == 0) return ps_conv1x1_f32(x, wt, y, N, K, M, T, ldt, pro, bias, bn, res, st, stream);
+    return ps_conv1x1_bf16_f32(x, wb, y, N, K, M, T, ldt, b.gemm_planes, pro, bias, bn, res, st, stream);
+  };
+  if (b.gemm_planes != 0 && (!b.in_wb || !b.pw_wb || !b.out_wb)) {
+    set_error("ps_conv_tasnet_f32: gemm_planes=%d needs the plane-packed weights in_wb / pw_wb / out_wb", b.gemm_planes);
+    return PS_E_INVALID;
+  }
+  rc = gemm(x_in, b.in_wt, b.in_wb, w.y1, b.C, b.H, nullptr, nullptr, bias_n, nullptr,
+            b.in_norm == PS_NORM_GLOBAL ? w.s1 : nullptr);
   if (rc) return rc;
 
   // 2) depthwise: prologue = in_conv's norm + PReLU; stats of y2
@@ -208,8 +218,8 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
   p2.gamma = b.dw_gamma;
   p2.beta = b.dw_beta;
   p2.slope = b.dw_slope;
-  rc = ps_conv1x1_f32(w.y2, b.pw_wt, w.y3, N, b.H, b.H, T, ldt, &p2, b.pw_b, nullptr, nullptr,
-                      b.pw_norm == PS_NORM_GLOBAL ? w.s3 : nullptr, stream);
+  rc = gemm(w.y2, b.pw_wt, b.pw_wb, w.y3, b.H, b.H, &p2, b.pw_b, nullptr, nullptr,
+            b.pw_norm == PS_NORM_GLOBAL ? w.s3 : nullptr);
   if (rc) return rc;
 
   // 4) out_conv + bias + residual: prologue = pointwise norm + PReLU
@@ -223,7 +233,7 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
   p3.gamma = b.pw_gamma;
   p3.beta = b.pw_beta;
   p3.slope = b.pw_slope;
-  return ps_conv1x1_f32(w.y3, b.out_wt, x_out, N, b.H, b.C, T, ldt, &p3, b.out_b, nullptr, x_in, nullptr, stream);
+  return gemm(w.y3, b.out_wt, b.out_wb, x_out, b.H, b.C, &p3, b.out_b, nullptr, x_in, nullptr);
 }
 
 extern "C" int ps_conv_tasnet_f32(const ps_tcn_block* blocks, int n_blocks, const float* x_in, float* x_out,

@@ -149,6 +149,42 @@ def conv1x1(x: torch.Tensor, t: int, wt: torch.Tensor, m: int, pro: Optional[Pro
     return y, stats
 
 
+def pack_wt_bf16(w: torch.Tensor, planes: int) -> torch.Tensor:
+    """[M,K] (or [M,K,1]) fp32 weight -> bf16 plane image [ceil(M/256)][ceil(K/16)][planes][256][16] for
+    ps_conv1x1_bf16_f32: plane p holds bf16 of what the planes before it left over (planes = 1: plain rounding)."""
+    if w.dim() == 3:
+        w = w[:, :, 0]
+    m, k = w.shape
+    mt, ks = (m + 255) // 256, (k + 15) // 16
+    rest = torch.zeros(mt * 256, ks * 16, dtype=torch.float32, device=w.device)
+    rest[:m, :k] = w.detach().float()
+    out = torch.empty(mt, ks, planes, 256, 16, dtype=torch.bfloat16, device=w.device)
+    for p in range(planes):
+        h = rest.to(torch.bfloat16)
+        out[:, :, p] = h.reshape(mt, 256, ks, 16).permute(0, 2, 1, 3)
+        rest = rest - h.float()
+    return out.contiguous()
+
+
+def conv1x1_bf16(x: torch.Tensor, t: int, wt_planes: torch.Tensor, m: int, pro: Optional[Prologue] = None,
+                 bias: Optional[torch.Tensor] = None, bias_n: Optional[torch.Tensor] = None,
+                 res: Optional[torch.Tensor] = None, want_stats: bool = False,
+                 out: Optional[torch.Tensor] = None) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """ps_conv1x1_f32's contract on the bf16 matrix pipe; the plane count is read off wt_planes (pack_wt_bf16)."""
+    require_device(x, "conv1x1_bf16")
+    n, k, ldt = x.shape
+    planes = wt_planes.shape[2]
+    y = out if out is not None else torch.empty(n, m, ldt, dtype=torch.float32, device=x.device)
+    stats = None
+    if want_stats:
+        parts = lib().ps_conv1x1_stats_parts(m, t)
+        stats = torch.zeros(n, parts, 2, dtype=torch.float64, device=x.device)
+    check(lib().ps_conv1x1_bf16_f32(ptr(x), ptr(wt_planes), ptr(y), n, k, m, t, ldt, planes,
+                                    C.byref(pro) if pro is not None else None, ptr(bias), ptr(bias_n), ptr(res),
+                                    ptr(stats), stream_ptr(x.device)), "ps_conv1x1_bf16_f32")
+    return y, stats
+
+
 def dwconv(x: torch.Tensor, t: int, w: torch.Tensor, b: Optional[torch.Tensor], dilation: int, left: int,
            pro: Optional[Prologue] = None, want_stats: bool = False) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
     """x padded [N,H,ldt], w [H,1,P] -> y padded [N,H,ldt] (+ partial stats)."""

@@ -21,6 +21,9 @@ from .lobe.norm import ChanLN, get_norm, norm_plan
 _PLAN_SERIAL = [0]
 
 
+GEMM_PLANES = {"fp32": 0, "bf16": 1, "bf16x3": 3}
+
+
 class _PlanCache:
     """Packed-weight caches hold raw device pointers (ctypes) -- never pickle / deepcopy them."""
 
@@ -67,8 +70,13 @@ class TCN(_PlanCache, nn.Module):
         self._plan_sig = None
 
     # -- kernel-side weight layout ----------------------------------------------------------------
+    #: arithmetic of the three 1x1 convs: "fp32" (exact fp32 MFMA, default), "bf16" (bf16 products, fp32 accumulate:
+    #: what BASELINE.json names for its bf16 configurations) or "bf16x3" (fp32-accurate 3-way bf16 split)
+    gemm_precision = "fp32"
+
     def plan(self, device: torch.device) -> dict:
-        sig = (_param_signature(self), str(device))
+        planes = GEMM_PLANES[self.gemm_precision]
+        sig = (_param_signature(self), str(device), planes)
         if self._plan is not None and self._plan_sig == sig:
             return self._plan
         if self.training and self.dconv[1].p > 0:
@@ -108,6 +116,11 @@ class TCN(_PlanCache, nn.Module):
         fused = "cln" not in kinds.values()
         b.in_norm, b.dw_norm, b.pw_norm = [kinds[k] if fused else 0 for k in ("in", "dw", "pw")]
         b.E = self.emb_dim
+        b.gemm_planes = planes
+        if planes:
+            t["in_wb"] = hip.pack_wt_bf16(w_in[:, :c, 0], planes)
+            t["pw_wb"] = hip.pack_wt_bf16(dsc.pointwise[0].weight.detach().to(**f32), planes)
+            t["out_wb"] = hip.pack_wt_bf16(self.out_conv.weight.detach().to(**f32), planes)
         for k, v in t.items():
             setattr(b, k, ptr(v))
         _PLAN_SERIAL[0] += 1
@@ -329,6 +342,15 @@ class ConvTasNet(_PlanCache, nn.Module):
         self._blocks = None
         self._blocks_sig = None
         self._workspace = None
+
+    def set_gemm_precision(self, name: str) -> "ConvTasNet":
+        """"fp32" (default) | "bf16" | "bf16x3" for the 1x1 convs of every normal TCN block (see TCN.gemm_precision)."""
+        if name not in GEMM_PLANES:
+            raise ValueError(f"gemm precision must be one of {sorted(GEMM_PLANES)}")
+        for stack in self.tcn_list:
+            for m in stack:
+                m.gemm_precision = name
+        return self
 
     # -- plan: one ps_tcn_block per TCN, in execution order -------------------------------------------
     def block_array(self, device: torch.device):

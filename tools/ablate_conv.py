@@ -41,4 +41,16 @@ for name, (K, M, pro, res) in shapes.items():
         us = e0.elapsed_time(e1) / reps * 1e3
         res_line.append(f"{fname}={us:.0f}us")
     lib.ps_debug_flags(0)
+    for planes in (3, 1):
+        wb = hip.pack_wt_bf16(torch.randn(M, K, device=dev) * 0.05, planes)
+        for _ in range(3):
+            hip.conv1x1_bf16(x, T, wb, M, p, bias, None, r, want_stats=not res, out=y)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            hip.conv1x1_bf16(x, T, wb, M, p, bias, None, r, want_stats=not res, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        res_line.append(f"bf16x{planes}={e0.elapsed_time(e1) / 10 * 1e3:.0f}us")
     print(name, f"(peak {flop / 157.3e12 * 1e6:.0f}us)", "  ".join(res_line), flush=True)
