@@ -42,6 +42,8 @@ struct BfArgs {
   double* ostats;
   ps_prologue pro;
   int K, M, T, ldt, ksteps, tiles_t, tiles_m;
+  unsigned long long* stamps;  // ps_debug_buffer(): 6 x u64 per workgroup (s_memtime buckets), diagnostics only
+  int ablate;  // profiling only (ps_debug_flags bits 24..26): 1 = no MFMA, 2 = no epilogue, 4 = no activation split
 };
 
 template <int PLANES>
@@ -86,28 +88,35 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
   constexpr int A_PIECES = 2 * PLANES;  // 16-byte pieces per thread per K-step
   const u32x4v* wsrc = reinterpret_cast<const u32x4v*>(a.wt) + (size_t)mt * a.ksteps * (L::A_BYTES / 16);
   const int bt = tid & 127, bh = tid >> 7;  // activation staging: frame, k-half
-  const float* xsrc = a.x + (size_t)n * a.K * a.ldt + t0 + bt;
-  const bool t_in = t0 + bt < a.ldt;  // rows are padded to ldt >= T; pad frames are never stored as results
   // weights (L2 resident) are fetched one K-step ahead, activations (HBM) two: breg is a two-deep register queue
-  u32x4v areg[A_PIECES];
+  constexpr int A_DEPTH = PLANES == 1 ? 2 : 1;  // weight K-steps in flight (register budget)
+  u32x4v areg[A_DEPTH][A_PIECES];
   float breg[2][8];
-  auto load_a = [&](int ks) {
+  const int a_last = a.ksteps - 1;
+  auto load_a = [&](int ks, auto q_c) {  // K-steps past the end re-read the last one (never stored)
+    constexpr int q = decltype(q_c)::value;
+    const int kc = ks < a_last ? ks : a_last;
 #pragma unroll
-    for (int i = 0; i < A_PIECES; ++i) areg[i] = wsrc[(size_t)ks * (L::A_BYTES / 16) + tid + 256 * i];
+    for (int i = 0; i < A_PIECES; ++i) areg[q][i] = wsrc[(size_t)kc * (L::A_BYTES / 16) + tid + 256 * i];
   };
+  // activation loads go through a buffer descriptor over this utterance's [K][ldt] slab: rows k >= K and K-steps
+  // past the end read 0.0f, so the loads carry no predicate (a predicated load made hipcc wait on each one)
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x) + (size_t)n * a.K * a.ldt, 0, a.K * a.ldt * 4, 0x00020000);
+  const int xb_voff = (8 * bh * a.ldt + t0 + bt) * 4;
   auto load_b = [&](int ks, auto q_c) {
     constexpr int q = decltype(q_c)::value;
+    const int soff = ks * XB_K * a.ldt * 4;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = ks * XB_K + 8 * bh + j;
-      breg[q][j] = (ks < a.ksteps && k < a.K && t_in) ? xsrc[(size_t)k * a.ldt] : 0.f;
-    }
+    for (int j = 0; j < 8; ++j)
+      breg[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, xb_voff, soff + j * a.ldt * 4, 0));
   };
   auto store_step = [&](int ks, int slot, auto q_c) {
     constexpr int q = decltype(q_c)::value;
     unsigned char* sa = smem + slot * L::SLOT;
 #pragma unroll
-    for (int i = 0; i < A_PIECES; ++i) reinterpret_cast<u32x4v*>(sa)[tid + 256 * i] = areg[i];
+    for (int i = 0; i < A_PIECES; ++i) reinterpret_cast<u32x4v*>(sa)[tid + 256 * i] = areg[A_DEPTH - 1][i];
+    if (a.ablate & 4) return;
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
       for (int r = 0; r < 16; ++r) acc[mi][ti][r] = 0.f;
 
   auto compute = [&](int slot) {
+    if (a.ablate & 1) return;
     const unsigned char* sa = smem + slot * L::SLOT;
     const unsigned char* sb = sa + L::A_BYTES;
     bf16x8 bf[PLANES][2];
@@ -182,27 +192,64 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
   // ---- K loop -----------------------------------------------------------------------------------------------------
   using q0 = std::integral_constant<int, 0>;
   using q1 = std::integral_constant<int, 1>;
-  load_a(0);
-  load_b(0, q0{});
+  // queues: areg[A_DEPTH-1] / breg[1] hold the NEXT step to be written to LDS, the lower entries the ones after it
+  load_a(0, std::integral_constant<int, A_DEPTH - 1>{});
+  load_b(0, q1{});
+  store_step(0, 0, q1{});
+  load_a(1, std::integral_constant<int, A_DEPTH - 1>{});
+  if constexpr (A_DEPTH == 2) load_a(2, q0{});
   load_b(1, q1{});
-  store_step(0, 0, q0{});
-  __syncthreads();
-  // one loop body (a second copy of the MFMA block makes the register allocator duplicate the accumulators):
-  // breg[1] holds B(ks+1); B(ks+2) is fetched into breg[0] and moved over after breg[1] has been consumed
+  load_b(2, q0{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // one loop body (a second copy of the MFMA block makes the register allocator duplicate the accumulators)
+  unsigned long long st_c = 0, st_s = 0, st_b = 0, st_t0 = 0, st_prev = 0;
+#define BF_STAMP(bucket)                                               \
+  if (a.stamps) {                                                      \
+    unsigned long long now;                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory"); \
+    bucket += now - st_prev;                                           \
+    st_prev = now;                                                     \
+  }
+  if (a.stamps) {
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0)::"memory");
+    st_prev = st_t0;
+  }
   for (int ks = 0; ks < a.ksteps; ++ks) {
     const bool more = ks + 1 < a.ksteps;
-    if (more) load_a(ks + 1);
-    load_b(ks + 2, q0{});
     compute(ks & 1);
+    BF_STAMP(st_c)
+    // the staging phase (VALU, LDS writes, load issue) runs at raised priority: next to the partner workgroup's
+    // MFMA stream a wave at equal priority gets an issue slot only every few tens of cycles
+    __builtin_amdgcn_s_setprio(3);
     if (more) store_step(ks + 1, (ks + 1) & 1, q1{});
+    // advance the queues and refill their tails: A(ks + 1 + A_DEPTH), B(ks + 3)
+    if constexpr (A_DEPTH == 2) {
+#pragma unroll
+      for (int i = 0; i < A_PIECES; ++i) areg[1][i] = areg[0][i];
+      load_a(ks + 3, q0{});
+    } else {
+      load_a(ks + 2, q0{});
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) breg[1][j] = breg[0][j];
-    __syncthreads();
+    load_b(ks + 3, q0{});
+    // raw barrier: __syncthreads() would also wait for the loads in flight (vmcnt(0)) and put the whole memory
+    // latency into every step; only this wave's LDS writes have to be complete here
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BF_STAMP(st_s)
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    BF_STAMP(st_b)
   }
+  unsigned long long st_loop_end = st_prev;
 
   // ---- epilogue: element (mi, ti, r) = row m0 + 128 wm + 32 mi + (r&3) + 8 (r>>2) + 4 lh, column t0 + 64 wt + 32 ti + lr.
   // All accesses go through buffer descriptors (rows >= M read 0 / drop their stores), so there are no per-element
   // branches; the 32 residual values of a row block are in flight together before the first add.
+  if (a.ablate & 2) return;
   float fsum = 0.f, fsq = 0.f;
   const int slab = a.M * a.ldt * 4;
   const __amdgpu_buffer_rsrc_t yr =
@@ -250,6 +297,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
                                               tile_off + rc * a.ldt * 4 + ti * 128, 0);
       }
     }
+  }
+  if (a.stamps && tid == 0) {
+    unsigned long long now;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+    unsigned long long* d = a.stamps + ((size_t)(n * a.tiles_m + mt) * a.tiles_t + blockIdx.x) * 6;
+    d[0] = st_t0;
+    d[1] = st_c;
+    d[2] = st_s;
+    d[3] = st_b;
+    d[4] = now - st_loop_end;  // epilogue
+    d[5] = now;
   }
   if constexpr (STATS) {
     const double s = wave_sum((double)fsum), q = wave_sum((double)fsq);
@@ -346,6 +404,8 @@ extern "C" int ps_conv1x1_bf16_f32(const float* x, const void* wt_planes, float*
   a.ksteps = (K + XB_K - 1) / XB_K;
   a.tiles_t = (T + XB_T - 1) / XB_T;
   a.tiles_m = (M + XB_M - 1) / XB_M;
+  a.ablate = (g_debug_flags >> 24) & 15;
+  a.stamps = (unsigned long long*)g_debug_buffer;
   {
     LaunchTimer timer("conv1x1_bf16", (hipStream_t)stream);
     if (planes == 1)

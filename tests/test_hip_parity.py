@@ -784,3 +784,58 @@ def test_conv_tasnet_on_the_bf16_matrix_pipe(PA, dev, golden_dir, precision, tol
         assert l2 < tol
     model.masker.set_gemm_precision("fp32")
     assert rel_max(model.inference(noisy).cpu().numpy(), g["wav"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["cfg3_short", "cfg4_short", "cfg4_tse_short"])
+def test_full_size_properties_of_the_other_baseline_configs(PA, dev, name):
+    """BASELINE configs 3 and 4 at their full size (32 x 4 s per GPU, + 4 s enrolment): one full-length utterance
+    against the oracle, and the batch properties -- utterances independent (row i of the batch == its B=1 run bit
+    for bit), length law, |y| <= 1, finite."""
+    c = cases.CASES[name]
+    model = cases.build(PA.NS, name).eval()
+    sd = det_state_dict(model)
+    model.load_state_dict(sd)
+    model.to(dev)
+    tse = "L_enroll" in c
+    noisy = det_wave(301, 32, 64000)
+    enroll = det_wave(302, 32, 64000) if tse else None
+    out = model.inference(noisy.to(dev), None if enroll is None else enroll.to(dev))
+    assert out.shape == (32, 64000)
+    assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0
+    for i in (0, 15, 16, 31):
+        single = model.inference(noisy[i:i + 1].to(dev), None if enroll is None else enroll[i:i + 1].to(dev))
+        assert torch.equal(single[0], out[i]), i
+    ref = O.inference(noisy[5:6], sd, cases.oracle_cfg(name), None if enroll is None else enroll[5:6])
+    assert rel_max(out[5:6].cpu().numpy(), ref.numpy()) < TOL
+
+
+def test_sixty_four_streams_match_single_streams(dev):
+    """BASELINE config 5 at its full size: 64 concurrent streams through the demo harness for two chunks; stream i of
+    the batched run equals the same audio / embedding run alone (tolerance: the short-row GEMM splits K the same way
+    for every frame, so this is exact), and one stream matches the oracle's harness."""
+    from puresound_amd.streaming.demo import DemoTseNet
+    c = cases.CASES["cfg5_demo"]
+    net = DemoTseNet().eval()
+    sd = det_state_dict(net)
+    net.load_state_dict(sd)
+    net.to(dev)
+    b, n_chunks = 64, 2
+    wav = det_wave(401, b, 320 * n_chunks)
+    emb = torch.rand(b, 192, generator=torch.Generator().manual_seed(402))
+    net.init_streams(b)
+    pre = None
+    for i in range(n_chunks):
+        pre = net.streaming_inference_chunk(wav[:, i * 320:(i + 1) * 320].to(dev), emb.to(dev), pre)
+    assert pre.shape == (b, 16 * (20 * n_chunks - 1) + 16)
+    assert torch.isfinite(pre).all()
+    for i in (0, 37, 63):
+        net.init_streams(1)
+        one = None
+        for j in range(n_chunks):
+            one = net.streaming_inference_chunk(wav[i:i + 1, j * 320:(j + 1) * 320].to(dev), emb[i:i + 1].to(dev), one)
+        assert torch.equal(one[0], pre[i]), i
+    st = DP.DemoStream(sd, cases.rnn_args(c), 1, 32, 16)
+    ref = None
+    for j in range(n_chunks):
+        ref = st.step_chunk(wav[37:38, j * 320:(j + 1) * 320], emb[37:38], ref)
+    assert rel_max(pre[37:38].cpu().numpy(), ref.numpy()) < TOL

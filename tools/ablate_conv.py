@@ -41,7 +41,8 @@ for name, (K, M, pro, res) in shapes.items():
         us = e0.elapsed_time(e1) / reps * 1e3
         res_line.append(f"{fname}={us:.0f}us")
     lib.ps_debug_flags(0)
-    for planes in (3, 1):
+    for planes, abl in ((3, 0), (3, 1), (3, 2), (3, 4), (1, 0)):
+        lib.ps_debug_flags(abl << 24)
         wb = hip.pack_wt_bf16(torch.randn(M, K, device=dev) * 0.05, planes)
         for _ in range(3):
             hip.conv1x1_bf16(x, T, wb, M, p, bias, None, r, want_stats=not res, out=y)
@@ -52,5 +53,6 @@ for name, (K, M, pro, res) in shapes.items():
             hip.conv1x1_bf16(x, T, wb, M, p, bias, None, r, want_stats=not res, out=y)
         e1.record()
         torch.cuda.synchronize()
-        res_line.append(f"bf16x{planes}={e0.elapsed_time(e1) / 10 * 1e3:.0f}us")
+        res_line.append(f"bf16x{planes}/abl{abl}={e0.elapsed_time(e1) / 10 * 1e3:.0f}us")
+    lib.ps_debug_flags(0)
     print(name, f"(peak {flop / 157.3e12 * 1e6:.0f}us)", "  ".join(res_line), flush=True)

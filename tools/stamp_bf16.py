@@ -1,0 +1,30 @@
+"""Phase buckets of ps_conv1x1_bf16_f32 per workgroup (s_memtime): compute / staging+load wait / barrier / epilogue."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from puresound_amd import hip, _abi
+dev = torch.device("cuda:0"); lib = _abi.lib()
+N, T = 32, 3999; ldt = _abi.padded_frames(T)
+shapes = {"in": (512, 256, False, False), "pw": (256, 256, True, False), "out": (256, 512, True, True)}
+for planes in (3, 1):
+    for name, (K, M, pro, res) in shapes.items():
+        x = torch.randn(N, K, ldt, device=dev); wb = hip.pack_wt_bf16(torch.randn(M, K, device=dev) * 0.05, planes)
+        y = torch.empty(N, M, ldt, device=dev); r = torch.randn(N, M, ldt, device=dev) if res else None
+        bias = torch.randn(M, device=dev)
+        g, b, sl = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1, torch.tensor([0.25], device=dev)
+        parts = lib.ps_dwconv_stats_parts(K, T)
+        st = torch.zeros(N, parts, 2, dtype=torch.float64, device=dev); st[:, 0, 1] = float(K * T)
+        p = hip.make_prologue(_abi.PS_NORM_GLOBAL, True, st, K * T, 1e-8, g, b, sl) if pro else None
+        nwg = N * ((M + 255) // 256) * ((T + 127) // 128)
+        buf = torch.zeros(nwg * 6, dtype=torch.int64, device=dev)
+        for _ in range(3):
+            hip.conv1x1_bf16(x, T, wb, M, p, bias, None, r, want_stats=not res, out=y)
+        lib.ps_debug_buffer(buf.data_ptr())
+        hip.conv1x1_bf16(x, T, wb, M, p, bias, None, r, want_stats=not res, out=y)
+        torch.cuda.synchronize(); lib.ps_debug_buffer(None)
+        s = buf.cpu().numpy().reshape(nwg, 6).astype(np.int64)
+        span = s[:, 5].max() - s[:, 0].min()
+        ks = (K + 15) // 16
+        print(f"bf16x{planes} {name}: span {span} cyc (100 MHz ticks? see ratio) WGs {nwg}; per K-step med: compute {np.median(s[:,1])/ks:.0f} "
+              f"stage+wait {np.median(s[:,2])/ks:.0f} barrier {np.median(s[:,3])/ks:.0f}; epilogue med {np.median(s[:,4]):.0f}; "
+              f"WG lifetime med {np.median(s[:,5]-s[:,0]):.0f}")
