@@ -41,7 +41,7 @@ struct BfArgs {
   const float* res;
   double* ostats;
   ps_prologue pro;
-  int K, M, T, ldt, ksteps, tiles_t, tiles_m;
+  int K, M, T, ldt, ksteps, tiles_t, tiles_m, N;
   unsigned long long* stamps;  // ps_debug_buffer(): 6 x u64 per workgroup (s_memtime buckets), diagnostics only
   int ablate;  // profiling only (ps_debug_flags bits 24..26): 1 = no MFMA, 2 = no epilogue, 4 = no activation split
 };
@@ -321,10 +321,384 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
   }
 }
 
+// ---- wave-specialised persistent variant ---------------------------------------------------------------------------
+// Measured on the kernel above (tools/stamp_bf16.py): the two co-resident workgroups fall into phase -- both stream
+// MFMAs, then both stage -- so a K-step costs compute (3047 cycles, two waves sharing a matrix pipe) PLUS staging
+// (1563) PLUS barrier (624) instead of their maximum.  Here ONE 512-thread workgroup per CU splits the roles for good:
+// waves 0-3 ("consumers") only read fragments, issue MFMAs and drain finished tiles; waves 4-7 ("producers") only load,
+// transform, split and write LDS, two K-steps ahead through a 3-slot ring, with their own deep register queues (they
+// hold no accumulators).  The workgroup is persistent over a contiguous run of tiles, so the producers keep
+// streaming into the next tile while the consumers drain the previous one.
+constexpr int WS_MAXU = 8;  // utterances one workgroup's tile run may touch (prologue scalars kept in LDS)
+
+struct WsTile {
+  int n, mt, tt;
+};
+
+__device__ __forceinline__ WsTile ws_tile(int idx, int tiles_t, int tiles_m) {
+  WsTile t;
+  t.tt = idx % tiles_t;
+  const int r = idx / tiles_t;
+  t.mt = r % tiles_m;
+  t.n = r / tiles_m;
+  return t;
+}
+
+template <int PLANES, bool TR, bool STATS, bool RES>
+__global__ __launch_bounds__(512, 1) void conv1x1_bf16_ws_kernel(BfArgs a) {
+  using L = BfLds<PLANES>;
+  constexpr int NSLOT = 3;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * L::SLOT + 2 * 512 * 4 + WS_MAXU * 2 * 4];
+  float* tab = reinterpret_cast<float*>(smem + NSLOT * L::SLOT);  // gamma[512] | beta[512]
+  float* scal = tab + 1024;                                       // [WS_MAXU][2]: mean, rstd of utterance n_lo + u
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool consumer = wave < 4;  // wave-uniform
+
+  const int ntiles = a.tiles_t * a.tiles_m * a.N;
+  const int G = gridDim.x;
+  const int lo = (int)((long long)blockIdx.x * ntiles / G), hi = (int)((long long)(blockIdx.x + 1) * ntiles / G);
+  if (lo >= hi) return;
+  const int total = (hi - lo) * a.ksteps;
+  const int n_lo = ws_tile(lo, a.tiles_t, a.tiles_m).n;
+
+  const float slope = (TR && a.pro.prelu) ? a.pro.slope[0] : 1.f;
+  if constexpr (TR) {
+    const bool has_norm = a.pro.norm != PS_NORM_NONE;
+    for (int k = tid; k < 512; k += 512) {
+      tab[k] = (has_norm && k < a.K) ? a.pro.gamma[k] : (k < a.K ? 1.f : 0.f);
+      tab[512 + k] = (has_norm && k < a.K) ? a.pro.beta[k] : 0.f;
+    }
+    const int n_hi = ws_tile(hi - 1, a.tiles_t, a.tiles_m).n;
+    // every wave reduces the producer's partial statistics itself (no cross-wave step); wave u % 8 stores
+    for (int u = 0; u <= n_hi - n_lo; ++u) {
+      float mean = 0.f, rstd = 1.f;
+      if (a.pro.norm == PS_NORM_GLOBAL) {
+        double sa = 0.0, sq = 0.0;
+        const double* src = a.pro.stats + (size_t)(n_lo + u) * a.pro.parts * 2;
+        for (int i = lane; i < a.pro.parts; i += 64) {
+          sa += src[2 * i];
+          sq += src[2 * i + 1];
+        }
+        sa = wave_sum(sa);
+        sq = wave_sum(sq);
+        const double m = sa / a.pro.count;
+        double var = sq / a.pro.count - m * m;
+        var = var > 0.0 ? var : 0.0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)a.pro.eps));
+      }
+      if (wave == (u & 7) && lane == 0) {
+        scal[2 * u] = mean;
+        scal[2 * u + 1] = rstd;
+      }
+    }
+  }
+  __syncthreads();
+
+  if (!consumer) {
+    // =============================== producers =====================================================================
+    const int ptid = tid - 256;
+    constexpr int A_PIECES = 2 * PLANES;
+    constexpr int AD = 2, BD = 3;  // K-steps of weights / activations in flight
+    const int bt = ptid & 127, bh = ptid >> 7;
+    const int xb_voff = (8 * bh * a.ldt + bt) * 4;
+    u32x4v areg[AD][A_PIECES];
+    float breg[BD][8];
+    // load side: global step -> (tile, ks); steps past the end re-read the last one
+    auto issue_a = [&](int g, auto q_c) {
+      constexpr int q = decltype(q_c)::value;
+      const int gc = g < total ? g : total - 1;
+      const WsTile t = ws_tile(lo + gc / a.ksteps, a.tiles_t, a.tiles_m);
+      const int ks = gc % a.ksteps;
+      const u32x4v* src = reinterpret_cast<const u32x4v*>(a.wt) + ((size_t)t.mt * a.ksteps + ks) * (L::A_BYTES / 16);
+#pragma unroll
+      for (int i = 0; i < A_PIECES; ++i) areg[q][i] = src[ptid + 256 * i];
+    };
+    auto issue_b = [&](int g, auto q_c) {
+      constexpr int q = decltype(q_c)::value;
+      const int gc = g < total ? g : total - 1;
+      const WsTile t = ws_tile(lo + gc / a.ksteps, a.tiles_t, a.tiles_m);
+      const int ks = gc % a.ksteps;
+      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(a.x) + (size_t)t.n * a.K * a.ldt, 0, a.K * a.ldt * 4, 0x00020000);
+      const int soff = (ks * XB_K * a.ldt + t.tt * XB_T) * 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        breg[q][j] =
+            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, xb_voff, soff + j * a.ldt * 4, 0));
+    };
+    auto stage = [&](int g) {  // write step g (queue heads) into its ring slot
+      unsigned char* sa = smem + (g % NSLOT) * L::SLOT;
+#pragma unroll
+      for (int i = 0; i < A_PIECES; ++i) reinterpret_cast<u32x4v*>(sa)[ptid + 256 * i] = areg[AD - 1][i];
+      float v[8];
+      const int ks = g % a.ksteps;
+      float mean = 0.f, rstd = 1.f;
+      if constexpr (TR) {
+        const int u = ws_tile(lo + g / a.ksteps, a.tiles_t, a.tiles_m).n - n_lo;
+        mean = scal[2 * u];
+        rstd = scal[2 * u + 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = breg[BD - 1][j];
+        if constexpr (TR) {
+          const int k = ks * XB_K + 8 * bh + j;
+          if (a.pro.pre_relu) x = fmaxf(x, 0.f);
+          const float sc = tab[k] * rstd;
+          x = x * sc + (tab[512 + k] - mean * sc);
+          if (a.pro.prelu) x = prelu(x, slope);
+          if (a.pro.post_tanh) x = tanhf(x);
+          if (k >= a.K) x = 0.f;
+        }
+        v[j] = x;
+      }
+      unsigned char* sb = sa + L::A_BYTES;
+#pragma unroll
+      for (int p = 0; p < PLANES; ++p) {
+        bf16x8 piece;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const bf16x2 h = __builtin_convertvector(f32x2v{v[j], v[j + 1]}, bf16x2);
+          piece[j] = h[0];
+          piece[j + 1] = h[1];
+          if (p + 1 < PLANES) {
+            const f32x2v back = __builtin_convertvector(h, f32x2v);
+            v[j] -= back[0];
+            v[j + 1] -= back[1];
+          }
+        }
+        *reinterpret_cast<bf16x8*>(sb + ((p * XB_T + bt) * XB_K + 8 * bh) * 2) = piece;
+      }
+    };
+    using i0 = std::integral_constant<int, 0>;
+    using i1 = std::integral_constant<int, 1>;
+    using i2 = std::integral_constant<int, 2>;
+    // fill the queues: heads (index AD-1 / BD-1) = step 0
+    issue_a(0, i1{});
+    issue_a(1, i0{});
+    issue_b(0, i2{});
+    issue_b(1, i1{});
+    issue_b(2, i0{});
+    unsigned long long p_stage = 0, p_bar = 0, p_prev = 0;
+    if (a.stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(p_prev)::"memory");
+    for (int i = 0; i < total + 2; ++i) {
+      if (i < total) {
+        stage(i);
+        // advance the queues, refill the tails
+#pragma unroll
+        for (int q = 0; q < A_PIECES; ++q) areg[1][q] = areg[0][q];
+        issue_a(i + 2, i0{});
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          breg[2][j] = breg[1][j];
+          breg[1][j] = breg[0][j];
+        }
+        issue_b(i + 3, i0{});
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (a.stamps) {
+        unsigned long long now;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+        p_stage += now - p_prev;
+        p_prev = now;
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (a.stamps) {
+        unsigned long long now;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+        p_bar += now - p_prev;
+        p_prev = now;
+      }
+    }
+    if (a.stamps && tid == 256) {
+      unsigned long long* d = a.stamps + (size_t)blockIdx.x * 6;
+      d[2] = p_stage;
+      d[3] = p_bar;
+    }
+    return;
+  }
+
+  // ================================= consumers ======================================================================
+  const int wm = wave >> 1, wt = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  f32x16 acc[4][2];
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = zero16;
+
+  auto compute = [&](int slot) {
+    const unsigned char* sa = smem + slot * L::SLOT;
+    const unsigned char* sb = sa + L::A_BYTES;
+    bf16x8 bf[PLANES][2];
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+        bf[p][ti] = *reinterpret_cast<const bf16x8*>(sb + ((p * XB_T + wt * 64 + ti * 32 + lr) * XB_K + 8 * lh) * 2);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      bf16x8 af[PLANES];
+#pragma unroll
+      for (int p = 0; p < PLANES; ++p)
+        af[p] = *reinterpret_cast<const bf16x8*>(sa + ((p * XB_M + wm * 128 + mi * 32 + lr) * XB_K + 8 * lh) * 2);
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
+        if constexpr (PLANES == 3) {
+          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][ti], acc[mi][ti], 0, 0, 0);
+          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0][ti], acc[mi][ti], 0, 0, 0);
+          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2][ti], acc[mi][ti], 0, 0, 0);
+          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0][ti], acc[mi][ti], 0, 0, 0);
+          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1][ti], acc[mi][ti], 0, 0, 0);
+        }
+        acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0][ti], acc[mi][ti], 0, 0, 0);
+      }
+    }
+  };
+
+  auto drain = [&](const WsTile& t) {
+    const int m0 = t.mt * XB_M, t0 = t.tt * XB_T, n = t.n;
+    float fsum = 0.f, fsq = 0.f;
+    const int slab = a.M * a.ldt * 4;
+    const __amdgpu_buffer_rsrc_t yr =
+        __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)n * a.M * a.ldt, 0, slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(RES ? a.res : a.y) + (size_t)n * a.M * a.ldt, 0, slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.bias ? a.bias : a.x), 0, a.bias ? a.M * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bnr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.bias_n ? a.bias_n + (size_t)n * a.M : a.x), 0, a.bias_n ? a.M * 4 : 0, 0x00020000);
+    const int lane_off = (4 * lh * a.ldt + lr) * 4;
+    const int tile_off = ((m0 + wm * 128) * a.ldt + t0 + wt * 64) * 4;
+    float cm[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) cm[ti] = (t0 + wt * 64 + ti * 32 + lr < a.T) ? 1.f : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      float bsum[16], rv[2][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rc = mi * 32 + (r & 3) + 8 * (r >> 2);
+        const int moff = (m0 + wm * 128 + rc + 4 * lh) * 4;
+        bsum[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, moff, 0, 0)) +
+                  __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bnr, moff, 0, 0));
+        if constexpr (RES) {
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti)
+            rv[ti][r] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, tile_off + rc * a.ldt * 4 + ti * 128, 0));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rc = mi * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+          float v = acc[mi][ti][r] + bsum[r];
+          if constexpr (STATS) {
+            const float vm = v * cm[ti];
+            fsum += vm;
+            fsq += vm * vm;
+          }
+          if constexpr (RES) v += rv[ti][r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, lane_off,
+                                                tile_off + rc * a.ldt * 4 + ti * 128, 0);
+        }
+      }
+    }
+    if constexpr (STATS) {
+      const double s = wave_sum((double)fsum), q = wave_sum((double)fsq);
+      if (lane == 0) {
+        const int parts = a.tiles_m * a.tiles_t * 4;
+        const int part = (t.mt * a.tiles_t + t.tt) * 4 + wave;
+        double* dst = a.ostats + ((size_t)n * parts + part) * 2;
+        dst[0] = s;
+        dst[1] = q;
+      }
+    }
+  };
+
+  int cks = 0, ctile = lo;
+  unsigned long long c_comp = 0, c_bar = 0, c_drain = 0, c_prev = 0;
+  if (a.stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_prev)::"memory");
+#define WS_STAMP(bucket)                                                          \
+  if (a.stamps) {                                                                 \
+    unsigned long long now;                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory"); \
+    bucket += now - c_prev;                                                       \
+    c_prev = now;                                                                 \
+  }
+  for (int i = 0; i < total + 2; ++i) {
+    if (i >= 2) {
+      compute((i - 2) % NSLOT);
+      WS_STAMP(c_comp)
+      if (++cks == a.ksteps) {
+        drain(ws_tile(ctile, a.tiles_t, a.tiles_m));
+        WS_STAMP(c_drain)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = zero16;
+        cks = 0;
+        ++ctile;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    WS_STAMP(c_bar)
+  }
+  if (a.stamps && tid == 0) {
+    unsigned long long* d = a.stamps + (size_t)blockIdx.x * 6;
+    d[0] = c_comp;
+    d[1] = c_bar;
+    d[4] = c_drain;
+    d[5] = (unsigned long long)total;
+  }
+}
+
+static int bf16_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
 template <int PLANES>
 static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
-  dim3 grid(a.tiles_t, a.tiles_m, N);
   const bool stats = a.ostats != nullptr, res = a.res != nullptr;
+  // The wave-specialised persistent kernel is NOT the default yet: its producers need 3100-4200 cycles per K-step
+  // (integer divisions of the tile walk, un-pipelined table reads, queue moves) against 2000 for the consumers, and
+  // its drains are un-overlapped, so it is 25-40 % slower than the simple kernel (tools/stamp_bf16.py).  ps_debug_flags
+  // bit 27 selects it (tests run both); it also needs >= one tile per CU and a bounded utterance span per workgroup.
+  const long long ntiles = (long long)a.tiles_t * a.tiles_m * N;
+  const int G = (int)(ntiles < bf16_cus() ? ntiles : bf16_cus());
+  const long long per_wg = (ntiles + G - 1) / G, per_utt = (long long)a.tiles_t * a.tiles_m;
+  const bool ws = (g_debug_flags & (1 << 27)) && ntiles >= bf16_cus() && (per_wg + per_utt - 1) / per_utt + 1 <= WS_MAXU;
+  if (ws) {
+#define PS_WS(TRV, STV, RSV) \
+  hipLaunchKernelGGL((conv1x1_bf16_ws_kernel<PLANES, TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)
+    if (tr) {
+      if (stats) PS_WS(true, true, false);
+      else if (res) PS_WS(true, false, true);
+      else PS_WS(true, false, false);
+    } else {
+      if (stats) PS_WS(false, true, false);
+      else if (res) PS_WS(false, false, true);
+      else PS_WS(false, false, false);
+    }
+#undef PS_WS
+    return;
+  }
+  dim3 grid(a.tiles_t, a.tiles_m, N);
 #define PS_BF(TRV, STV, RSV) \
   hipLaunchKernelGGL((conv1x1_bf16_kernel<PLANES, TRV, STV, RSV>), grid, dim3(256), 0, stream, a)
   if (tr) {
@@ -404,6 +778,7 @@ extern "C" int ps_conv1x1_bf16_f32(const float* x, const void* wt_planes, float*
   a.ksteps = (K + XB_K - 1) / XB_K;
   a.tiles_t = (T + XB_T - 1) / XB_T;
   a.tiles_m = (M + XB_M - 1) / XB_M;
+  a.N = N;
   a.ablate = (g_debug_flags >> 24) & 15;
   a.stamps = (unsigned long long*)g_debug_buffer;
   {

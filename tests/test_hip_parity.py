@@ -729,7 +729,10 @@ def test_fused_streaming_step_kernels(H, dev):
 @pytest.mark.parametrize("planes,tol", [(3, 2e-6), (1, 2e-2)])
 @pytest.mark.parametrize("n,k,m,t,mode", [(2, 24, 12, 77, "plain"), (2, 256, 256, 500, "norm_stats"),
                                           (1, 256, 512, 300, "norm_res"), (2, 512, 256, 129, "stats"),
-                                          (1, 40, 300, 128, "affine")])
+                                          (1, 40, 300, 128, "affine"),
+                                          # >= 256 tiles: the wave-specialised persistent kernel, runs across utterances
+                                          (9, 64, 256, 3800, "norm_stats"), (5, 48, 512, 3700, "norm_res"),
+                                          (9, 40, 200, 3800, "plain")])
 def test_conv1x1_bf16_planes(H, dev, planes, tol, n, k, m, t, mode):
     from puresound_amd import _abi
     x = _rand((n, k, t), 121) + 0.2
@@ -748,17 +751,23 @@ def test_conv1x1_bf16_planes(H, dev, planes, tol, n, k, m, t, mode):
     ref = torch.matmul(w.double(), a) + b.double().reshape(1, -1, 1)
     res = _rand((n, m, t), 126) if mode == "norm_res" else None
     want = mode in ("norm_stats", "stats")
-    y, st = H.conv1x1_bf16(H.pad_rows(x.to(dev)), t, H.pack_wt_bf16(w.to(dev), planes), m, pro, b.to(dev), None,
-                           None if res is None else H.pad_rows(res.to(dev)), want_stats=want)
-    torch.cuda.synchronize()
     if res is not None:
         ref = ref + res.double()
-    assert rel_max(y[..., :t].cpu().double().numpy(), ref.numpy()) < tol
-    if want:
-        s = st.sum(1).cpu().numpy()
-        got = y[..., :t].cpu().double()
-        np.testing.assert_allclose(s[:, 0], got.sum((1, 2)).numpy(), rtol=1e-6, atol=1e-3)
-        np.testing.assert_allclose(s[:, 1], (got ** 2).sum((1, 2)).numpy(), rtol=1e-6)
+    # flag bit 27 = the wave-specialised persistent variant (taken only when there is at least one tile per CU)
+    for flags in (0, 1 << 27):
+        old = _abi.lib().ps_debug_flags(flags)
+        try:
+            y, st = H.conv1x1_bf16(H.pad_rows(x.to(dev)), t, H.pack_wt_bf16(w.to(dev), planes), m, pro, b.to(dev), None,
+                                   None if res is None else H.pad_rows(res.to(dev)), want_stats=want)
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
+        assert rel_max(y[..., :t].cpu().double().numpy(), ref.numpy()) < tol, flags
+        if want:
+            s = st.sum(1).cpu().numpy()
+            got = y[..., :t].cpu().double()
+            np.testing.assert_allclose(s[:, 0], got.sum((1, 2)).numpy(), rtol=1e-6, atol=1e-3)
+            np.testing.assert_allclose(s[:, 1], (got ** 2).sum((1, 2)).numpy(), rtol=1e-6)
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", TOL), ("bf16", 3e-2)])

@@ -23,6 +23,13 @@ for planes in (3, 1):
         hip.conv1x1_bf16(x, T, wb, M, p, bias, None, r, want_stats=not res, out=y)
         torch.cuda.synchronize(); lib.ps_debug_buffer(None)
         s = buf.cpu().numpy().reshape(nwg, 6).astype(np.int64)
+        if lib.ps_debug_flags(-1) & (1 << 27):  # wave-specialised kernel: one record per CU-resident workgroup
+            s = s[:256]
+            tot = np.maximum(s[:, 5], 1)
+            print(f"bf16x{planes} {name} [ws]: ticks/WG {int(np.median(tot))}; per tick med: consumer compute {np.median(s[:,0]/tot):.0f} "
+                  f"consumer barrier-wait {np.median(s[:,1]/tot):.0f} | producer stage {np.median(s[:,2]/tot):.0f} producer "
+                  f"barrier-wait {np.median(s[:,3]/tot):.0f}; drain total/WG {np.median(s[:,4]):.0f}")
+            continue
         span = s[:, 5].max() - s[:, 0].min()
         ks = (K + 15) // 16
         print(f"bf16x{planes} {name}: span {span} cyc (100 MHz ticks? see ratio) WGs {nwg}; per K-step med: compute {np.median(s[:,1])/ks:.0f} "
