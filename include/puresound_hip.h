@@ -54,7 +54,7 @@ const char* ps_last_error(void);
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
  * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product", "segment_overlap",
- * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "conv1x1_bf16",
+ * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "conv1x1_bf16", "unfold2d", "activation", "add",
  * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
@@ -202,6 +202,29 @@ int ps_unfold_taps_f32(const float* x, float* y, int N, int K, int T, int ldt, i
                        const float* scale, const float* shift, const float* embed, int E, void* stream);
 int ps_gated_product_f32(const float* left, const float* right, float* y, int N, int H, int T, int ldt,
                          const ps_prologue* pro_left, const ps_prologue* pro_right, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2-D convolutional maskers (Unet / UnetTcn / DPCRN: unet.py:13-557, dpcrn.py:11-213).  A 4-D activation
+ * [N][CH][F][T] is stored as [N][CH*F] rows of ld frames; Conv2d / ConvTranspose2d run as ps_conv1x1_f32 GEMMs
+ * (M = Cout, K = Cin*kf*kt, "frames" = (f, t) flattened = Fout*ld) over the unfolded taps.
+ *
+ * ps_unfold2d_f32: y[n][(ci*kf + jf)*kt + jt][fo*ld + t] = x[n][ci][fi][ti], 0 outside the input or for t >= T.
+ *   transposed = 0 (nn.ZeroPad2d + nn.Conv2d, unet.py:112-128):  fi = fo*stride_f + jf*dil_f - pad_f,
+ *                                                               ti = t + jt*dil_t - pad_t
+ *   transposed = 1 (nn.ConvTranspose2d + the time trim, unet.py:139-165,252-256):
+ *                  fi = (fo + pad_f - jf*dil_f) / stride_f when divisible,  ti = t + pad_t - jt*dil_t
+ *                  (pad_t = the trim shift: transpose_t_size-1 with transpose_delay, else 0)
+ *   The input channels are the C1 channels of x1 followed by the C2 channels of x2 (the decoder's
+ *   torch.cat([x, skip], 1), unet.py:250; C2 = 0: one tensor).
+ * ps_activation_f32: in place on rows of ld frames, kind 0 none, 1 relu, 2 prelu (one shared slope), 3 mish,
+ *   4 sigmoid, 5 tanh (lobe/activation.py); pad frames are cleared.
+ * ------------------------------------------------------------------------------------------- */
+int ps_unfold2d_f32(const float* x1, int C1, const float* x2, int C2, float* y, int N, int Fin, int T, int ld, int kf,
+                    int kt, int stride_f, int dil_f, int dil_t, int pad_f, int pad_t, int Fout, int transposed,
+                    void* stream);
+int ps_activation_f32(float* x, int kind, const float* slope, int64_t rows, int T, int ld, void* stream);
+/* y = a + b over `count` floats (the additive skip connections of Unet(skip_conv=True), unet.py:249); y may alias a or b */
+int ps_add_f32(const float* a, const float* b, float* y, int64_t count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Recurrent maskers (DPRNN dprnn.py:111-191, SkiM skim.py:198-229,45-114,410-469, StreamingSkiM

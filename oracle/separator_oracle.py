@@ -406,7 +406,14 @@ def inference(noisy: torch.Tensor, sd: SD, cfg: dict, enroll: Optional[torch.Ten
         mask = conv_tasnet(feats, sd, "masker.", cfg["masker"], dvec, taps)
     else:
         from . import dualpath_oracle as DP                          # recurrent maskers live in their own file
-        mask = {"dprnn": DP.dprnn, "skim": DP.skim}[kind](feats, sd, "masker.", cfg["masker"], dvec)
+        if kind in ("dprnn", "skim"):
+            mask = {"dprnn": DP.dprnn, "skim": DP.skim}[kind](feats, sd, "masker.", cfg["masker"], dvec)
+        else:
+            from . import unet_oracle as UO                           # 2-D convolutional maskers
+            if kind == "unet_tcn":
+                mask = UO.unet_tcn(feats, sd, "masker.", cfg["masker"], dvec)
+            else:
+                mask = {"unet": UO.unet, "dpcrn": UO.dpcrn}[kind](feats, sd, "masker.", cfg["masker"])
     mask = get_mask(mask, cfg.get("mask_constraint", "linear"))
     enh = apply_tf_masks(feats, mask, cfg.get("mask_type", "real"), cfg.get("f_type", "real"))
     wav = decode_waveform(enh, sd, cfg["encoder"])

@@ -365,6 +365,41 @@ def overlap_average(prev: torch.Tensor, cur: torch.Tensor, overlap: int) -> torc
     return out
 
 
+ACT_KINDS = {"none": 0, "relu": 1, "prelu": 2, "mish": 3, "sigmoid": 4, "tanh": 5}
+
+
+def unfold2d(x1: torch.Tensor, x2: Optional[torch.Tensor], t: int, f_out: int, kf: int, kt: int, stride_f: int,
+             dil_f: int, dil_t: int, pad_f: int, pad_t: int, transposed: bool) -> torch.Tensor:
+    """x1 [N,C1,F,ld] (+ x2 [N,C2,F,ld]) -> tap rows [N, (C1+C2)*kf*kt, f_out*ld] for the Conv2d / ConvTranspose2d GEMM."""
+    require_device(x1, "unfold2d")
+    n, c1, f_in, ld = x1.shape
+    c2 = 0 if x2 is None else x2.shape[1]
+    if x2 is not None and (x2.shape[0], x2.shape[2], x2.shape[3]) != (n, f_in, ld):
+        raise RuntimeError("unfold2d: the two sources must agree in N, F and ld")
+    y = torch.empty(n, (c1 + c2) * kf * kt, f_out * ld, dtype=torch.float32, device=x1.device)
+    check(lib().ps_unfold2d_f32(ptr(x1), c1, ptr(x2), c2, ptr(y), n, f_in, t, ld, kf, kt, stride_f, dil_f, dil_t, pad_f,
+                                pad_t, f_out, int(transposed), stream_ptr(x1.device)), "ps_unfold2d_f32")
+    return y
+
+
+def activation_(x: torch.Tensor, kind: str, slope: Optional[torch.Tensor], t: int) -> torch.Tensor:
+    """in place on [..., ld] rows."""
+    require_device(x, "activation_")
+    ld = x.shape[-1]
+    check(lib().ps_activation_f32(ptr(x), ACT_KINDS[kind], ptr(slope), x.numel() // ld, t, ld, stream_ptr(x.device)),
+          "ps_activation_f32")
+    return x
+
+
+def add_(dst: torch.Tensor, other: torch.Tensor) -> torch.Tensor:
+    """dst += other (same shape, contiguous)."""
+    require_device(dst, "add_")
+    if dst.shape != other.shape or not dst.is_contiguous() or not other.is_contiguous():
+        raise RuntimeError("add_: contiguous tensors of one shape")
+    check(lib().ps_add_f32(ptr(dst), ptr(other), ptr(dst), dst.numel(), stream_ptr(dst.device)), "ps_add_f32")
+    return dst
+
+
 def lstm_cell(gates: torch.Tensor, c: torch.Tensor, h: torch.Tensor, hidden: int, dirs: int, t: int) -> None:
     """One cell update per (unit, frame): gates padded [N,D*4H,ld] (complete pre-activations), c in place, h out
     (both [N,D*H,ld'] rows, possibly views into larger row blocks)."""

@@ -8,6 +8,8 @@ from .lobe.encoder import ConvEncDec, FreeEncDec
 from .lobe.pooling import AttentiveStatisticsPooling
 from .lobe.trivial import FiLM, Gate
 from .skim import MemLSTM, SegLSTM, SkiM
+from .unet import Unet, UnetTcn
+from .dpcrn import DPCRN, DPRNNblock2D
 
 # the class namespace the parity tests hand to tests/golden/cases.build()
 class _Namespace(SimpleNamespace):
@@ -20,4 +22,5 @@ class _Namespace(SimpleNamespace):
 
 NS = _Namespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                      ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
-                     AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM, MemLSTM=MemLSTM, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate)
+                     AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM, MemLSTM=MemLSTM, Unet=Unet, UnetTcn=UnetTcn,
+                DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate)

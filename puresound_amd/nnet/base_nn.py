@@ -16,6 +16,7 @@ from .._abi import TcnBlock
 from .conv_tasnet import TCN, ConvTasNet
 from .dprnn import DPRNN
 from .skim import SkiM
+from .unet import Unet
 from .lobe.encoder import ConvEncDec, FreeEncDec
 from .lobe.pooling import AttentiveStatisticsPooling
 
@@ -157,10 +158,10 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
                 raise NotImplementedError("HIP inference path with an STFT encoder: (complex, complex) masks")
         elif not isinstance(self.encoder, FreeEncDec) or pairing != "real":
             raise NotImplementedError("HIP inference path: FreeEncDec encoder with (real, real) masks")
-        if not isinstance(self.masker, (ConvTasNet, DPRNN, SkiM)):
-            raise NotImplementedError(f"HIP inference path: ConvTasNet / DPRNN / SkiM masker "
+        if not isinstance(self.masker, (ConvTasNet, DPRNN, SkiM, Unet)):
+            raise NotImplementedError(f"HIP inference path: ConvTasNet / DPRNN / SkiM / Unet-family masker "
                                       f"(got {type(self.masker).__name__})")
-        recurrent = not isinstance(self.masker, ConvTasNet)
+        recurrent = isinstance(self.masker, (DPRNN, SkiM))
         if recurrent and stft:
             raise NotImplementedError("HIP inference path: recurrent maskers run behind the FreeEncDec encoder")
         if self.embedding_free_tse and not isinstance(self.masker, DPRNN):

@@ -50,6 +50,17 @@ CASES = {
                                                embedding_free_tse=True)),
                            wrap=dict(mask_constraint="ReLU", embedding_free_tse=True), B=2, L=4000, L_enroll=3000,
                            seed=1234),
+    # the real egs/ns model: ns_dpcrn_v0_causal verbatim (egs/ns/model.py:40-82), 1 380 043 parameters
+    "ns_dpcrn_short": dict(kind="wrap", enc=dict(kind="stft", n_fft=512, hop=128, drop_first_bin=True),
+                           masker=dict(cls="DPCRN", args=(), oracle="dpcrn",
+                                       kw=dict(input_type="RI", input_dim=512, activation_type="PReLU", norm_type="bN2d",
+                                               dropout=0.1, channels=(1, 32, 32, 32, 64, 128), transpose_t_size=2,
+                                               transpose_delay=False, skip_conv=False, kernel_t=(2, 2, 2, 2, 2),
+                                               kernel_f=(5, 3, 3, 3, 3), stride_t=(1, 1, 1, 1, 1),
+                                               stride_f=(2, 2, 1, 1, 1), dilation_t=(1, 1, 1, 1, 1),
+                                               dilation_f=(1, 1, 1, 1, 1), delay=(0, 0, 0, 0, 0), rnn_hidden=128)),
+                           wrap=dict(mask_constraint="linear", f_type="Complex", mask_type="Complex",
+                                     drop_first_bin=True), B=2, L=4000, seed=1234),
     # ---- reduced wrapper cases: odd sizes, ragged tails, sigmoid/linear constraints -----------
     "tiny_free": dict(kind="wrap", enc=dict(kind="free", win=16, hop=8, C=24),
                       masker=masker_args(24, 0, False, [0, 0, 0], tcn_kernel=3, tcn_dim=12, repeat_tcn=2,
@@ -142,6 +153,32 @@ CASES = {
                       kw=dict(n_blocks=4, seg_size=150, seg_overlap=False, causal=True, embed_dim=192,
                               embed_norm=True, block_with_embed=[1, 1, 1, 1], embed_fusion="FiLM"),
                       frames=307, seed=42, harness=dict(win=32, hop=16, C=128, chunks=3, chunk=320)),
+    # ---- 2-D convolutional maskers: Unet, UnetTcn (normal / gated + FiLM), DPCRN
+    "unet_small": dict(kind="unet", cls="Unet", oracle="unet",
+                       kw=dict(input_type="RI", input_dim=32, channels=(1, 4, 6), kernel_t=(2, 3), kernel_f=(3, 5),
+                               stride_t=(1, 1), stride_f=(2, 2), dilation_t=(1, 1), dilation_f=(1, 1), delay=(0, 1),
+                               transpose_t_size=2, dropout=0.0), B=2, T=19, seed=51),
+    "unet_real_skipconv": dict(kind="unet", cls="Unet", oracle="unet",
+                               kw=dict(input_type="Real", input_dim=20, activation_type="ReLU", channels=(1, 3, 5),
+                                       kernel_t=(1, 2), kernel_f=(5, 3), stride_t=(1, 1), stride_f=(4, 1),
+                                       dilation_t=(1, 1), dilation_f=(1, 1), delay=(0, 0), transpose_t_size=3,
+                                       skip_conv=True, multi_output=2, dropout=0.0), B=2, T=17, seed=52),
+    "unettcn_small": dict(kind="unet", cls="UnetTcn", oracle="unet_tcn",
+                          kw=dict(embed_dim=6, embed_norm=True, input_type="RI", input_dim=64, channels=(1, 4, 6),
+                                  kernel_t=(2, 2), kernel_f=(5, 3), stride_t=(1, 1), stride_f=(2, 2), dilation_t=(1, 1),
+                                  dilation_f=(1, 1), delay=(0, 0), tcn_dim=8, per_tcn_stack=2, repeat_tcn=2,
+                                  tcn_with_embed=[1, 0], dropout=0.0), B=2, T=23, seed=53, embed=6),
+    "unettcn_gated_film": dict(kind="unet", cls="UnetTcn", oracle="unet_tcn",
+                               kw=dict(embed_dim=6, embed_norm=True, input_type="RI", input_dim=64, channels=(1, 4, 6),
+                                       transpose_delay=True, kernel_t=(2, 2), kernel_f=(5, 5), stride_t=(1, 1),
+                                       stride_f=(2, 2), dilation_t=(1, 1), dilation_f=(1, 1), delay=(0, 0),
+                                       tcn_layer="gated", tcn_use_film=True, tcn_dim=8, per_tcn_stack=2, repeat_tcn=1,
+                                       tcn_with_embed=[1, 0], dropout=0.0), B=2, T=21, seed=54, embed=6),
+    "dpcrn_small": dict(kind="unet", cls="DPCRN", oracle="dpcrn",
+                        kw=dict(input_type="RI", input_dim=32, channels=(1, 4, 6, 8), transpose_delay=True,
+                                kernel_t=(2, 2, 2), kernel_f=(5, 3, 3), stride_t=(1, 1, 1), stride_f=(2, 2, 1),
+                                dilation_t=(1, 1, 1), dilation_f=(1, 1, 1), delay=(0, 0, 0), rnn_hidden=8, dropout=0.0),
+                        B=2, T=18, seed=55),
     "enc_free": dict(kind="encdec", enc=dict(kind="free", win=32, hop=16, C=20), B=3, L=500, seed=16),
     "enc_free_relu_ragged": dict(kind="encdec", enc=dict(kind="free", win=20, hop=6, C=9, relu=True),
                                  B=2, L=211, seed=17),
@@ -150,7 +187,8 @@ CASES = {
 }
 
 # parameter counts the reference documents / the survey measured (known answers)
-PARAM_COUNTS = {"cfg2_short": 7977032, "cfg1_short": 8207432, "cfg3_short": 10108119, "cfg4_tse_short": 723585}
+PARAM_COUNTS = {"cfg2_short": 7977032, "cfg1_short": 8207432, "cfg3_short": 10108119, "cfg4_tse_short": 723585,
+                "ns_dpcrn_short": 1380043}
 
 
 def build_encoder(ns, enc):
@@ -191,9 +229,31 @@ def build(ns, name):
         return build_encoder(ns, c["enc"])
     if c["kind"] == "rnn":
         return getattr(ns, c["cls"])(*c["args"], **c["kw"])
+    if c["kind"] == "unet":
+        return getattr(ns, c["cls"])(**c["kw"])
     if c["kind"] == "stream":
         return ns.StreamingSkiM(*c["args"], **c["kw"])
     raise KeyError(c["kind"])
+
+
+def unet_args(spec):
+    """The oracle's description of a Unet / UnetTcn / DPCRN constructor call (defaults of unet.py:35-53, 307-340,
+    dpcrn.py:85-104)."""
+    a = dict(input_type="RI", input_dim=512, activation_type="PReLU", norm_type="bN2d", dropout=0.05,
+             transpose_t_size=2, transpose_delay=False, skip_conv=False, multi_output=1, embed_dim=0, embed_norm=False,
+             tcn_layer="normal", tcn_kernel=3, tcn_dim=256, tcn_dilated_basic=2, per_tcn_stack=5, repeat_tcn=4,
+             tcn_with_embed=[1, 0, 0, 0, 0], tcn_use_film=False, tcn_norm="gLN", dconv_norm="gGN", causal=False,
+             spectral_compress=False)
+    if spec["cls"] == "DPCRN":
+        a.update(channels=(1, 32, 32, 32, 64, 128), kernel_t=(2, 2, 2, 2, 2), stride_t=(1, 1, 1, 1, 1),
+                 dilation_t=(1, 1, 1, 1, 1), kernel_f=(5, 3, 3, 3, 3), stride_f=(2, 2, 1, 1, 1),
+                 dilation_f=(1, 1, 1, 1, 1), delay=(0, 0, 0, 0, 0))
+    else:
+        a.update(channels=(1, 1, 8, 8, 16, 16), kernel_t=(5, 1, 9, 1, 1), stride_t=(1, 1, 1, 1, 1),
+                 dilation_t=(1, 1, 1, 1, 1), kernel_f=(1, 5, 1, 5, 1), stride_f=(1, 4, 1, 4, 1),
+                 dilation_f=(1, 1, 1, 1, 1), delay=(0, 0, 1, 0, 0))
+    a.update(spec["kw"])
+    return a
 
 
 def rnn_args(spec):
@@ -209,7 +269,9 @@ def oracle_cfg(name):
     """The oracle's description of a wrapper case."""
     c = CASES[name]
     enc = dict(c["enc"])
-    if "cls" in c["masker"]:
+    if c["masker"].get("cls") in ("Unet", "UnetTcn", "DPCRN"):
+        cfg = dict(encoder=enc, masker=unet_args(c["masker"]), masker_kind=c["masker"]["oracle"])
+    elif "cls" in c["masker"]:
         cfg = dict(encoder=enc, masker=rnn_args(c["masker"]), masker_kind=c["masker"]["cls"].lower())
     else:
         cfg = dict(encoder=enc, masker=full_masker_args(c["masker"]))

@@ -36,6 +36,8 @@ from puresound.nnet.lobe.pooling import AttentiveStatisticsPooling  # noqa: E402
 from puresound.nnet.dprnn import DPRNN  # noqa: E402
 from puresound.nnet.skim import SkiM  # noqa: E402
 from puresound.streaming.skim_inference import StreamingSkiM  # noqa: E402
+from puresound.nnet.unet import Unet, UnetTcn  # noqa: E402
+from puresound.nnet.dpcrn import DPCRN  # noqa: E402
 
 import cases  # noqa: E402
 from detweights import det_state_dict, det_wave  # noqa: E402
@@ -43,7 +45,7 @@ from detweights import det_state_dict, det_wave  # noqa: E402
 REF = cases.namespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                       ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                       AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM,
-                      StreamingSkiM=StreamingSkiM)
+                      StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN)
 
 
 def sub(x: torch.Tensor, cs: int = 7, ts: int = 5) -> np.ndarray:
@@ -78,7 +80,9 @@ def run_wrap(name, c):
     pre = model._get_waveform(enh)
     out["wav_preclamp"] = pre.numpy()
     small = c["L"] <= 4000
-    if small and "cls" in c["masker"]:
+    if small and c["masker"].get("cls") in ("Unet", "UnetTcn", "DPCRN"):
+        out["mask_sub"] = sub(mask)
+    elif small and "cls" in c["masker"]:
         out["feats_sub"] = sub(feats)
         out["mask_sub"] = sub(mask)
     elif small:
@@ -146,6 +150,23 @@ def run_rnn(name, c):
 
 
 @torch.no_grad()
+def run_unet(name, c):
+    """Unet / UnetTcn / DPCRN at module level: x [B, input_dim, T] (+ embedding)."""
+    model = cases.build(REF, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    x = _uniform(c["seed"], (c["B"], c["kw"]["input_dim"], c["T"]))
+    out = {"x": x.numpy()}
+    if "embed" in c:
+        e = _uniform(c["seed"] + 100, (c["B"], c["embed"]))
+        out["embed"] = e.numpy()
+        y = model(x.clone(), e.clone())
+    else:
+        y = model(x.clone())
+    out["y"] = y.numpy()
+    return out
+
+
+@torch.no_grad()
 def run_stream(name, c):
     """StreamingSkiM: offline forward, step_chunk over whole segments, step_frame over every frame; for the demo
     preset also the harness of egs/tse/demo/utils.py (DemoTseNet.streaming_inference_chunk) on three chunks."""
@@ -208,7 +229,7 @@ def main():
     dump_state_dict_keys()
     for name, c in cases.CASES.items():
         fn = {"wrap": run_wrap, "masker": run_masker, "encdec": run_encdec, "rnn": run_rnn,
-              "stream": run_stream}[c["kind"]]
+              "stream": run_stream, "unet": run_unet}[c["kind"]]
         if only and name not in only:
             continue
         out = fn(name, c)

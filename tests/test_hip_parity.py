@@ -848,3 +848,73 @@ def test_sixty_four_streams_match_single_streams(dev):
     for j in range(n_chunks):
         ref = st.step_chunk(wav[37:38, j * 320:(j + 1) * 320], emb[37:38], ref)
     assert rel_max(pre[37:38].cpu().numpy(), ref.numpy()) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# 2-D convolutional maskers: Unet, UnetTcn, DPCRN, the ns_dpcrn_v0_causal preset
+# ------------------------------------------------------------------------------------------------
+from oracle import unet_oracle as UO  # noqa: E402
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_unfold2d_kernel(H, dev, transposed):
+    import torch.nn.functional as F
+    n, c1, c2, f, t = 2, 3, 2, 11, 37
+    x1, x2 = _rand((n, c1, f, t), 131), _rand((n, c2, f, t), 132)
+    x = torch.cat([x1, x2], 1)
+    kf, kt, sf, df, dt = 3, 2, 2, 1, 1
+    pad = lambda v: H.pad_rows(v.reshape(n, -1, t).to(dev)).view(n, v.shape[1], f, -1)  # noqa: E731
+    if not transposed:
+        w = _rand((4, c1 + c2, kf, kt), 133)
+        ref = F.conv2d(F.pad(x, (kt - 1, 0, kf // 2, kf // 2)), w, None, stride=(sf, 1))
+        f_out = ref.shape[2]
+        taps = H.unfold2d(pad(x1), pad(x2), t, f_out, kf, kt, sf, df, dt, kf // 2, kt - 1, False)
+        w2 = w.reshape(4, -1)
+    else:
+        w = _rand((c1 + c2, 4, kf, kt), 133)
+        op = sf - kf + 2 * (kf // 2)
+        ref = F.conv_transpose2d(x, w, None, stride=(sf, 1), padding=(kf // 2, 0), output_padding=(op, 0))[..., (kt - 1):]
+        f_out = ref.shape[2]
+        taps = H.unfold2d(pad(x1), pad(x2), t, f_out, kf, kt, sf, df, dt, kf // 2, kt - 1, True)
+        w2 = w.permute(1, 0, 2, 3).reshape(4, -1)
+    ld = taps.shape[-1] // f_out
+    got = torch.einsum("mk,nkx->nmx", w2, taps.cpu()).view(n, 4, f_out, ld)[..., :t]
+    assert rel_max(got.numpy(), ref.numpy()) < 1e-6
+
+
+UNET_CASES = [n for n, c in cases.CASES.items() if c["kind"] == "unet"]
+
+
+@pytest.mark.parametrize("name", UNET_CASES)
+def test_unet_family_matches_reference_golden(PA, dev, golden_dir, name):
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    x = torch.tensor(g["x"]).to(dev)
+    y = model(x, torch.tensor(g["embed"]).to(dev)) if "embed" in g else model(x)
+    assert y.shape == g["y"].shape
+    assert rel_max(y.cpu().numpy(), g["y"]) < TOL
+
+
+def test_ns_dpcrn_preset_matches_reference_golden(PA, dev, golden_dir):
+    """egs/ns/model.py:40-82 (ns_dpcrn_v0_causal) through the wrapper: conv-STFT, DPCRN, complex mask, iSTFT."""
+    name = "ns_dpcrn_short"
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name).eval()
+    sd = det_state_dict(model)
+    model.load_state_dict(sd)
+    model.to(dev)
+    assert model.overall_parameters == cases.PARAM_COUNTS[name]
+    noisy = det_wave(c["seed"], c["B"], c["L"])
+    wav = model.inference(noisy.to(dev))
+    assert wav.shape == g["wav"].shape
+    sl = slice(16, wav.shape[1] - 16)
+    assert rel_max(wav.cpu().numpy()[:, sl], g["wav"][:, sl]) < TOL
+    # a longer, ragged batch against the oracle
+    n3 = det_wave(77, 3, 9000 + 37)
+    ref = O.inference(n3, sd, cases.oracle_cfg(name))
+    out = model.inference(n3.to(dev))
+    sl = slice(16, ref.shape[1] - 16)
+    assert rel_max(out.cpu().numpy()[:, sl], ref.numpy()[:, sl]) < TOL
