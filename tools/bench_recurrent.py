@@ -52,6 +52,40 @@ def cfg4(args):
     print(json.dumps(line))
 
 
+def dpcrn(args):
+    """The real egs/ns model (ns_dpcrn_v0_causal: conv-STFT 512/128 + DPCRN + complex mask + iSTFT), 32 x 4 s."""
+    dev = "cuda:0"
+    model = cases.build(PA.NS, "ns_dpcrn_short").eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    g = torch.Generator().manual_seed(1234)
+    noisy = ((torch.rand(args.batch, 64000, generator=g) * 2 - 1) * 0.5).to(dev)
+    for _ in range(args.warmup):
+        model.inference(noisy)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.inference(noisy)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    line = {"config": "ns_dpcrn_v0_causal (STFT 512/128 + DPCRN(1,32,32,32,64,128; H=128)) fp32", "batch": args.batch,
+            "ms_per_forward": ms, "samples_per_s": args.batch * 64000 / ms * 1e3}
+    if args.profile:
+        import ctypes as C
+        lib = _abi.lib()
+        lib.ps_profile_enable(1)
+        model.inference(noisy)
+        torch.cuda.synchronize()
+        fam = {}
+        for k in ("conv1x1", "unfold2d", "activation", "lstm", "proj_layernorm", "frame", "istft_ola", "complex_mask"):
+            ms_k, cnt = C.c_double(), C.c_int()
+            lib.ps_profile_read(k.encode(), C.byref(ms_k), C.byref(cnt))
+            fam[k] = [round(ms_k.value, 4), cnt.value]
+        lib.ps_profile_enable(0)
+        line["kernel_ms_per_forward"] = fam
+    print(json.dumps(line))
+
+
 def cfg5(args):
     from puresound_amd.streaming.demo import DemoTseNet
     dev = "cuda:0"
@@ -98,3 +132,5 @@ if __name__ == "__main__":
         cfg4(a)
     if "cfg5" in a.which:
         cfg5(a)
+    if "dpcrn" in a.which:
+        dpcrn(a)
