@@ -54,7 +54,7 @@ const char* ps_last_error(void);
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
  * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product", "segment_overlap",
- * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "conv1x1_bf16", "unfold2d", "activation", "add",
+ * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "conv1x1_bf16", "unfold2d", "activation", "add", "magnitude", "real_mask",
  * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
@@ -202,6 +202,14 @@ int ps_unfold_taps_f32(const float* x, float* y, int N, int K, int T, int ldt, i
                        const float* scale, const float* shift, const float* embed, int E, void* stream);
 int ps_gated_product_f32(const float* left, const float* right, float* y, int N, int H, int T, int ldt,
                          const ps_prologue* pro_left, const ps_prologue* pro_right, void* stream);
+
+/* apply_tf_masks(real, real) as a kernel of its own (base_nn.py:52-54): out = feats * act(mask) over `rows` rows of ldt
+ * frames -- for encoders whose decoder does not fuse the product (the STFT front end with a real mask). */
+int ps_real_mask_f32(const float* feats, const float* mask, float* out, int64_t rows, int ldt, int mask_act, void* stream);
+
+/* Magnitude lobe of the speaker branch (lobe/trivial.py:21-59) on the [re rows; im rows] layout [N][2*half][ldt]:
+ * y[n][h][t] = sqrt(re^2 + im^2 + 1e-8) of bin h + drop_first (log1p of it when asked), y is [N][half-drop_first][ldt]. */
+int ps_magnitude_f32(const float* x, float* y, int N, int half, int drop_first, int log1p, int T, int ldt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 2-D convolutional maskers (Unet / UnetTcn / DPCRN: unet.py:13-557, dpcrn.py:11-213).  A 4-D activation

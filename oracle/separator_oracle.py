@@ -376,15 +376,32 @@ def decode_waveform(enh: torch.Tensor, sd: SD, enc: dict, p: str = "encoder.") -
     return istft_decode(enh, sd, p + "encoder.", enc["hop"])
 
 
+def magnitude(x: torch.Tensor, drop_first: bool = True, log1p: bool = False) -> torch.Tensor:
+    """Magnitude lobe (lobe/trivial.py:21-59) on [N, 2H, T] channel halves."""
+    re, im = torch.chunk(x, 2, dim=1)
+    if drop_first:
+        re, im = re[:, 1:], im[:, 1:]
+    mag = torch.sqrt(re ** 2 + im ** 2 + 1e-8)
+    return torch.log1p(mag) if log1p else mag
+
+
 def speaker_embedding(enroll_feats: torch.Tensor, sd: SD, spk: dict, p: str = "speaker_net.") -> torch.Tensor:
-    """Speaker net of td_tse_conv_tasnet_v0 (egs/tse/model.py:118-135; base_nn.py:697-705):
-    n_tcn TCN blocks -> attentive stats pooling -> Conv1d(2C->E,1,bias=False) -> squeeze(-1)."""
+    """Speaker nets of the TSE presets (egs/tse/model.py:118-135, 228-238; base_nn.py:697-705): optional Magnitude,
+    n_tcn TCN or GatedTCN blocks, attentive stats pooling, Conv1d(2C->E,1,bias=False), squeeze(-1)."""
     x = enroll_feats
+    off = 0
+    if spk.get("magnitude", False):
+        x = magnitude(x, drop_first=False)
+        off = 1                                   # the parameter-free lobe still occupies ModuleList index 0
     n = spk["n_tcn"]
     for i in range(n):
-        x = tcn_block(x, sd, f"{p}{i}.", spk.get("kernel", 3), 2 ** i, False, "gLN", "gGN")
-    x = attentive_stats_pooling(x, sd, f"{p}{n}.")
-    x = conv1x1(x, sd[f"{p}{n + 1}.weight"])
+        bp = f"{p}{i + off}."
+        if spk.get("block", "tcn") == "gated":
+            x = gated_tcn_block(x, sd, bp, spk.get("kernel", 3), 2 ** i, False, "gLN", False, None)
+        else:
+            x = tcn_block(x, sd, bp, spk.get("kernel", 3), 2 ** i, False, "gLN", "gGN")
+    x = attentive_stats_pooling(x, sd, f"{p}{n + off}.")
+    x = conv1x1(x, sd[f"{p}{n + off + 1}.weight"])
     return x.squeeze(-1)
 
 

@@ -49,6 +49,21 @@ __global__ __launch_bounds__(256) void complex_mask_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(out + im) = yi;
 }
 
+// Real mask on real features (apply_tf_masks real/real, base_nn.py:52-54) for encoders whose decoder is not fused with
+// the mask product (the STFT front end of the tse_unet_tcn presets): y = x * act(m), rows of ldt frames.
+__global__ __launch_bounds__(256) void real_mask_kernel(const float* __restrict__ feats, const float* __restrict__ mask,
+                                                        float* __restrict__ out, int ldt, int mask_act) {
+  const size_t row = blockIdx.y;
+  const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t >= ldt) return;
+  const f32x4 x = *reinterpret_cast<const f32x4*>(feats + row * ldt + t);
+  const f32x4 m = *reinterpret_cast<const f32x4*>(mask + row * ldt + t);
+  f32x4 y;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) y[e] = x[e] * act(m[e], mask_act);
+  *reinterpret_cast<f32x4*>(out + row * ldt + t) = y;
+}
+
 // Overlap-add of synthesis frames (ConvSTFT.inverse, lobe/encoder.py:432-454): every frame is multiplied by the
 // window and divided by n_fft, overlapping samples are summed, then divided by the overlap-added squared window
 // wherever that exceeds 1e-10 (the reference does this with a boolean-mask index, i.e. a host sync; here the
@@ -116,6 +131,23 @@ extern "C" int ps_complex_mask_f32(const float* feats, const float* mask, float*
   return launched("ps_complex_mask_f32");
 }
 
+extern "C" int ps_real_mask_f32(const float* feats, const float* mask, float* out, int64_t rows, int ldt, int mask_act,
+                                void* stream) {
+  if (!feats || !mask || !out || rows <= 0 || rows > 65535 * 32768LL || ldt <= 0 || ldt % 4 || mask_act < PS_ACT_LINEAR ||
+      mask_act > PS_ACT_SIGMOID || ((uintptr_t)feats & 15) || ((uintptr_t)mask & 15) || ((uintptr_t)out & 15)) {
+    set_error("ps_real_mask_f32: bad argument (rows=%lld ldt=%d mask_act=%d)", (long long)rows, ldt, mask_act);
+    return PS_E_INVALID;
+  }
+  LaunchTimer timer("real_mask", (hipStream_t)stream);
+  const int64_t chunk = 65535;
+  for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+    const int64_t nr = rows - r0 < chunk ? rows - r0 : chunk;
+    hipLaunchKernelGGL(real_mask_kernel, dim3((ldt / 4 + 255) / 256, (unsigned)nr), dim3(256), 0, (hipStream_t)stream,
+                       feats + r0 * ldt, mask + r0 * ldt, out + r0 * ldt, ldt, mask_act);
+  }
+  return launched("ps_real_mask_f32");
+}
+
 extern "C" int ps_istft_ola_f32(const float* frames, const float* window, float* out, int N, int n_fft, int hop,
                                 int T, int ldt, int out_mode, void* stream) {
   if (!frames || !window || !out || N <= 0 || n_fft <= 0 || hop <= 0 || T <= 0 || ldt < T ||
@@ -129,3 +161,42 @@ extern "C" int ps_istft_ola_f32(const float* frames, const float* window, float*
                      window, out, n_fft, hop, T, ldt, out_mode);
   return launched("ps_istft_ola_f32");
 }
+
+// Magnitude lobe (lobe/trivial.py:21-59) on the [re rows; im rows] channel layout: y[h] = sqrt(re[h+d]^2 + im[h+d]^2 + 1e-8)
+// (d = 1 drops the first bin), optionally log1p.
+namespace ps {
+__global__ __launch_bounds__(256) void magnitude_kernel(const float* __restrict__ x, float* __restrict__ y, int half,
+                                                        int drop, int T, int ldt, int log1p_) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int h = blockIdx.y, n = blockIdx.z;
+  if (t >= T) return;
+  const int hout = half - drop;
+  const float re = x[((size_t)n * 2 * half + h + drop) * ldt + t];
+  const float im = x[((size_t)n * 2 * half + half + h + drop) * ldt + t];
+  float m = sqrtf(re * re + im * im + 1e-8f);
+  if (log1p_) m = log1pf(m);
+  y[((size_t)n * hout + h) * ldt + t] = m;
+}
+}  // namespace ps
+
+extern "C" int ps_magnitude_f32(const float* x, float* y, int N, int half, int drop_first, int log1p, int T, int ldt,
+                                void* stream) {
+  using namespace ps;
+  if (!x || !y || N <= 0 || half <= 0 || T <= 0 || ldt < T || (drop_first != 0 && drop_first != 1) ||
+      half - drop_first <= 0 || half > 65535 || N > 65535) {
+    set_error("ps_magnitude_f32: bad argument (N=%d half=%d T=%d)", N, half, T);
+    return PS_E_INVALID;
+  }
+  {
+    LaunchTimer timer("magnitude", (hipStream_t)stream);
+    hipLaunchKernelGGL(magnitude_kernel, dim3((T + 255) / 256, half - drop_first, N), dim3(256), 0, (hipStream_t)stream, x,
+                       y, half, drop_first, T, ldt, log1p);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("ps_magnitude_f32: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+

@@ -391,6 +391,29 @@ def activation_(x: torch.Tensor, kind: str, slope: Optional[torch.Tensor], t: in
     return x
 
 
+def real_mask(feats: torch.Tensor, mask: torch.Tensor, mask_act: str = "linear") -> torch.Tensor:
+    """feats * act(mask) on padded rows."""
+    require_device(feats, "real_mask")
+    if mask.shape != feats.shape:
+        raise RuntimeError("real_mask: feats and mask must have one shape")
+    out = torch.empty_like(feats)
+    ldt = feats.shape[-1]
+    check(lib().ps_real_mask_f32(ptr(feats), ptr(mask), ptr(out), feats.numel() // ldt, ldt, _abi.PS_ACT[mask_act],
+                                 stream_ptr(feats.device)), "ps_real_mask_f32")
+    return out
+
+
+def magnitude(x: torch.Tensor, t: int, drop_first: bool, log1p: bool) -> torch.Tensor:
+    """[re rows; im rows] padded [N,2H,ldt] -> |.| padded [N,H-drop,ldt]."""
+    require_device(x, "magnitude")
+    n, c2, ldt = x.shape
+    half = c2 // 2
+    y = torch.zeros(n, half - int(drop_first), ldt, dtype=torch.float32, device=x.device)
+    check(lib().ps_magnitude_f32(ptr(x), ptr(y), n, half, int(drop_first), int(log1p), t, ldt, stream_ptr(x.device)),
+          "ps_magnitude_f32")
+    return y
+
+
 def add_(dst: torch.Tensor, other: torch.Tensor) -> torch.Tensor:
     """dst += other (same shape, contiguous)."""
     require_device(dst, "add_")

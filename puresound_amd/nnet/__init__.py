@@ -6,7 +6,7 @@ from .conv_tasnet import TCN, ConvTasNet, GatedTCN
 from .dprnn import DPRNN
 from .lobe.encoder import ConvEncDec, FreeEncDec
 from .lobe.pooling import AttentiveStatisticsPooling
-from .lobe.trivial import FiLM, Gate
+from .lobe.trivial import FiLM, Gate, Magnitude
 from .skim import MemLSTM, SegLSTM, SkiM
 from .unet import Unet, UnetTcn
 from .dpcrn import DPCRN, DPRNNblock2D
@@ -23,4 +23,4 @@ class _Namespace(SimpleNamespace):
 NS = _Namespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                      ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                      AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM, MemLSTM=MemLSTM, Unet=Unet, UnetTcn=UnetTcn,
-                DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate)
+                DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, Magnitude=Magnitude, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate)

@@ -13,7 +13,8 @@ import torch.nn as nn
 
 from .. import hip
 from .._abi import TcnBlock
-from .conv_tasnet import TCN, ConvTasNet
+from .conv_tasnet import TCN, ConvTasNet, GatedTCN
+from .lobe.trivial import Magnitude
 from .dprnn import DPRNN
 from .skim import SkiM
 from .unet import Unet
@@ -154,8 +155,8 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             raise NameError("Non support type.")  # base_nn.py:421-422
         stft = isinstance(self.encoder, ConvEncDec)
         if stft:
-            if pairing != "complex":
-                raise NotImplementedError("HIP inference path with an STFT encoder: (complex, complex) masks")
+            if pairing not in ("complex", "real"):
+                raise NotImplementedError("HIP inference path with an STFT encoder: (complex, complex) or (real, real)")
         elif not isinstance(self.encoder, FreeEncDec) or pairing != "real":
             raise NotImplementedError("HIP inference path: FreeEncDec encoder with (real, real) masks")
         if not isinstance(self.masker, (ConvTasNet, DPRNN, SkiM, Unet)):
@@ -168,8 +169,8 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             raise NotImplementedError("embedding_free_tse needs a DPRNN masker (dprnn.py:120-125)")
         if enroll is not None:
             hip.require_device(enroll, "SoTaskWrapModule.inference")
-            if stft or self.encoder_spk is not None or (self.speaker_net is None and not self.embedding_free_tse):
-                raise NotImplementedError("HIP speaker branch: shared FreeEncDec encoder + speaker_net")
+            if self.encoder_spk is not None or (self.speaker_net is None and not self.embedding_free_tse):
+                raise NotImplementedError("HIP speaker branch: shared encoder + speaker_net")
         # the dual-path maskers pad the frame axis to whole segments: make the encoder leave room for it
         need = self.masker.padded_frames_needed if recurrent else None
 
@@ -178,9 +179,10 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             # (:56-61) -> _get_waveform (:380-395, zero DC re-inserted = DC columns left out of the synthesis
             # weight) -> ConvSTFT.inverse -> output constraint
             enc = self.encoder.encoder
+            dvec = None if enroll is None else self._speaker_embedding(enroll.contiguous())
             feats, t = enc.encode_padded(noisy.contiguous(), self.drop_first_bin)
-            mask = self.masker.forward_padded(feats, t)
-            enh = hip.complex_mask(feats, mask, mask_act)
+            mask = self.masker.forward_padded(feats, t, dvec)
+            enh = hip.complex_mask(feats, mask, mask_act) if pairing == "complex" else hip.real_mask(feats, mask, mask_act)
             return enc.decode_padded(enh, t, self.drop_first_bin, out_mode)
 
         def run(part: torch.Tensor, lane: int, out: Optional[torch.Tensor],
@@ -228,40 +230,65 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         return out
 
     # -- speaker branch (base_nn.py:697-705, 724-738) ---------------------------------------------------
-    def _speaker_layers(self):
-        """Split speaker_net into (leading plain TCN blocks, pooling, trailing 1x1 conv) -- the layout of every
-        Conv-TasNet TSE preset (egs/tse/model.py:118-135).  Anything else has no HIP path yet."""
+    def _speaker_embedding_from_feats(self, x: torch.Tensor, t: int) -> torch.Tensor:
+        """speaker_net layer by layer on padded enrolment features (base_nn.py:697-705): Magnitude, TCN (consecutive
+        plain blocks go through the fused driver together), GatedTCN, AttentiveStatisticsPooling, then the k=1
+        projection conv(s) on the pooled vector -> dvec [N, E]."""
         layers = list(self.speaker_net) if isinstance(self.speaker_net, (nn.ModuleList, nn.Sequential)) else None
         if layers is None:
             raise NotImplementedError("HIP speaker branch: speaker_net must be a ModuleList / Sequential")
-        tcns = []
-        while layers and isinstance(layers[0], TCN):
-            if layers[0].emb_dim != 0:
-                raise NotImplementedError("HIP speaker branch: TCN blocks with their own embedding input")
-            tcns.append(layers.pop(0))
-        if len(layers) != 2 or not isinstance(layers[0], AttentiveStatisticsPooling) or \
-                not isinstance(layers[1], nn.Conv1d) or layers[1].kernel_size != (1,) or layers[1].bias is not None:
-            raise NotImplementedError("HIP speaker branch: TCN* -> AttentiveStatisticsPooling -> Conv1d(k=1, no bias)")
-        return tcns, layers[0], layers[1]
+        pooled = None
+        i = 0
+        while i < len(layers):
+            lay = layers[i]
+            if pooled is not None:
+                if not (isinstance(lay, nn.Conv1d) and lay.kernel_size == (1,) and lay.bias is None):
+                    raise NotImplementedError("HIP speaker branch: after the pooling only Conv1d(k=1, bias=False)")
+                pooled = hip.embed_bias(pooled, lay.weight.detach()[:, :, 0].float().contiguous(), False)
+                i += 1
+            elif isinstance(lay, Magnitude):
+                x = lay.forward_padded(x, t)
+                i += 1
+            elif isinstance(lay, TCN):
+                run = []
+                while i < len(layers) and isinstance(layers[i], TCN):
+                    if layers[i].emb_dim != 0:
+                        raise NotImplementedError("HIP speaker branch: TCN blocks with their own embedding input")
+                    run.append(layers[i])
+                    i += 1
+                plans = [m.plan(x.device) for m in run]
+                if all(p["fused"] for p in plans):
+                    blocks = (TcnBlock * len(plans))(*[p["block"] for p in plans])
+                    x = hip.conv_tasnet(blocks, len(plans), x, t, run[0].in_channels, run[0].hid_channels, None, False)
+                else:
+                    for m in run:
+                        x = m.forward_padded_staged(x, t, None)
+            elif isinstance(lay, GatedTCN):
+                x = lay.forward_padded(x, t, None)
+                i += 1
+            elif isinstance(lay, AttentiveStatisticsPooling):
+                pooled = lay.forward_padded(x, t)                                # [N, 2C]
+                i += 1
+            else:
+                raise NotImplementedError(f"HIP speaker branch: no kernel path for {type(lay).__name__}")
+        if pooled is None:
+            raise NotImplementedError("HIP speaker branch: speaker_net must end in pooling + projection")
+        return pooled
 
     def _speaker_embedding(self, enroll: torch.Tensor, lane: int = 0) -> torch.Tensor:
-        """enroll [N,L'] -> dvec [N,E]."""
-        tcns, pool, proj = self._speaker_layers()
-        x, t = self.encoder.encode_padded(enroll)
-        if tcns:
-            plans = [m.plan(x.device) for m in tcns]
-            blocks = (TcnBlock * len(plans))(*[p["block"] for p in plans])
-            x = hip.conv_tasnet(blocks, len(plans), x, t, tcns[0].in_channels, tcns[0].hid_channels, None, False)
-        pooled = pool.forward_padded(x, t)                                       # [N, 2C]
-        w = proj.weight.detach()[:, :, 0].float().contiguous()                   # [E, 2C]
-        return hip.embed_bias(pooled, w, False)                                  # Conv1d(2C -> E, 1, bias=False)
+        """enroll [N,L'] -> dvec [N,E] (shared encoder)."""
+        if isinstance(self.encoder, ConvEncDec):
+            x, t = self.encoder.encoder.encode_padded(enroll, self.drop_first_bin)
+        else:
+            x, t = self.encoder.encode_padded(enroll)
+        return self._speaker_embedding_from_feats(x, t)
 
     @torch.no_grad()
     def inference_tse_embedding(self, enroll: Optional[torch.Tensor] = None) -> torch.Tensor:
         """enroll [N,L'] -> [N,E,1], as the reference returns it (base_nn.py:724-738: not squeezed)."""
         hip.require_device(enroll, "SoTaskWrapModule.inference_tse_embedding")
-        if self.encoder_spk is not None or not isinstance(self.encoder, FreeEncDec):
-            raise NotImplementedError("HIP speaker branch: shared FreeEncDec encoder")
+        if self.encoder_spk is not None:
+            raise NotImplementedError("HIP speaker branch: shared encoder")
         return self._speaker_embedding(enroll.contiguous()).unsqueeze(2)
 
     def _verbose(self):

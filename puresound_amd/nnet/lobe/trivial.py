@@ -14,6 +14,30 @@ from .._plans import PlanCache, _f32, layernorm_plan
 from .norm import ChanLN
 
 
+class Magnitude(nn.Module):
+    """STFT [re; im] -> magnitude (lobe/trivial.py:21-59).  3-D input [N, 2H, T] (channel halves) only: that is what
+    the wrapper hands the speaker net."""
+
+    def __init__(self, drop_first: bool = True, log1p: bool = False) -> None:
+        super().__init__()
+        self.drop_first = drop_first
+        self.log1p = log1p
+
+    def forward_padded(self, x: torch.Tensor, t: int) -> torch.Tensor:
+        if x.shape[1] % 2:
+            raise TypeError
+        return hip.magnitude(x, t, self.drop_first, self.log1p)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        hip.require_device(x, "Magnitude.forward")
+        if x.dim() != 3:
+            if x.dim() == 4:
+                raise NotImplementedError("Magnitude on HIP: [N, 2H, T] input (the [N, H, T, 2] form is not built)")
+            raise TypeError
+        t = x.shape[-1]
+        return hip.unpad_rows(self.forward_padded(hip.pad_rows(x), t), t)
+
+
 class _PerFrameCondition:
     """Streaming: the frames of the row are concurrent streams, each with its own embedding, so the embedding
     columns of the conditioning conv become a per-frame additive term [1, M, ldB] instead of a per-utterance bias.

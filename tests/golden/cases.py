@@ -61,6 +61,27 @@ CASES = {
                                                dilation_f=(1, 1, 1, 1, 1), delay=(0, 0, 0, 0, 0), rnn_hidden=128)),
                            wrap=dict(mask_constraint="linear", f_type="Complex", mask_type="Complex",
                                      drop_first_bin=True), B=2, L=4000, seed=1234),
+    # two more TSE presets verbatim: tse_unet_tcn_v0_causal (egs/tse/model.py:246-306: STFT + UnetTcn(bN2d, gated bN1d
+    # TCN, causal) + speaker net Magnitude -> 5 x GatedTCN(gLN) -> ASP -> 1x1) and tse_skim_v0_causal (:418-463)
+    "tse_unet_tcn_causal_short": dict(
+        kind="wrap", enc=dict(kind="stft", n_fft=512, hop=128, drop_first_bin=True),
+        masker=dict(cls="UnetTcn", args=(), oracle="unet_tcn",
+                    kw=dict(embed_dim=192, embed_norm=True, input_type="RI", input_dim=512, activation_type="PReLU",
+                            norm_type="bN2d", channels=(1, 32, 64, 128, 128, 128, 128), transpose_t_size=2,
+                            transpose_delay=True, skip_conv=False, kernel_t=(2,) * 6, kernel_f=(5,) * 6,
+                            stride_t=(1,) * 6, stride_f=(2,) * 6, dilation_t=(1,) * 6, dilation_f=(1,) * 6,
+                            delay=(0,) * 6, tcn_layer="gated", tcn_kernel=3, tcn_dim=256, tcn_dilated_basic=2,
+                            per_tcn_stack=5, repeat_tcn=3, tcn_with_embed=[1, 0, 0, 0, 0], tcn_norm="bN1d",
+                            dconv_norm="bN1d", causal=True)),
+        speaker_net=dict(n_tcn=5, C=256, H=128, att=128, E=192, block="gated", magnitude=True),
+        wrap=dict(mask_constraint="linear", drop_first_bin=True), B=2, L=4000, L_enroll=3000, seed=1234),
+    "tse_skim_causal_short": dict(
+        kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
+        masker=dict(cls="SkiM", args=(128, 256, 128),
+                    kw=dict(n_blocks=4, seg_size=150, seg_overlap=False, causal=True, embed_dim=192, embed_norm=True,
+                            block_with_embed=[1, 1, 1, 1], embed_fusion="FiLM")),
+        speaker_net=dict(n_tcn=5, C=128, H=256, att=128, E=192),
+        wrap=dict(mask_constraint="ReLU"), B=2, L=4000, L_enroll=3000, seed=1234),
     # ---- reduced wrapper cases: odd sizes, ragged tails, sigmoid/linear constraints -----------
     "tiny_free": dict(kind="wrap", enc=dict(kind="free", win=16, hop=8, C=24),
                       masker=masker_args(24, 0, False, [0, 0, 0], tcn_kernel=3, tcn_dim=12, repeat_tcn=2,
@@ -186,9 +207,11 @@ CASES = {
                      B=2, L=400, seed=18),
 }
 
-# parameter counts the reference documents / the survey measured (known answers)
+# parameter counts measured on the reference itself by make_golden.py (its docstrings quote 13 372 725 for
+# tse_unet_tcn_v0_causal and 6 375 442 for tse_skim_v0_causal; the models it builds have the numbers below)
 PARAM_COUNTS = {"cfg2_short": 7977032, "cfg1_short": 8207432, "cfg3_short": 10108119, "cfg4_tse_short": 723585,
-                "ns_dpcrn_short": 1380043}
+                "ns_dpcrn_short": 1380043, "tse_unet_tcn_causal_short": 13324533,
+                "tse_skim_causal_short": 6375440}
 
 
 def build_encoder(ns, enc):
@@ -208,6 +231,11 @@ def build_masker(ns, m):
 
 def build_speaker_net(ns, s):
     import torch.nn as nn
+    if s.get("block") == "gated":
+        return nn.ModuleList(
+            ([ns.Magnitude(drop_first=False)] if s.get("magnitude") else [])
+            + [ns.GatedTCN(s["C"], s["H"], 3, dilation=2 ** i, causal=False, tcn_norm="gLN") for i in range(s["n_tcn"])]
+            + [ns.AttentiveStatisticsPooling(s["C"], s["att"]), nn.Conv1d(s["C"] * 2, s["E"], 1, bias=False)])
     return nn.ModuleList(
         [ns.TCN(s["C"], s["H"], 3, dilation=2 ** i, causal=False, tcn_norm="gLN", dconv_norm="gGN")
          for i in range(s["n_tcn"])]
@@ -277,7 +305,7 @@ def oracle_cfg(name):
         cfg = dict(encoder=enc, masker=full_masker_args(c["masker"]))
     cfg.update({k: v for k, v in c["wrap"].items() if k not in ("drop_first_bin", "embedding_free_tse")})
     if "speaker_net" in c:
-        cfg["speaker_net"] = dict(n_tcn=c["speaker_net"]["n_tcn"])
+        cfg["speaker_net"] = {k: v for k, v in c["speaker_net"].items() if k in ("n_tcn", "block", "magnitude")}
     return cfg
 
 

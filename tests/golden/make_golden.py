@@ -38,6 +38,7 @@ from puresound.nnet.skim import SkiM  # noqa: E402
 from puresound.streaming.skim_inference import StreamingSkiM  # noqa: E402
 from puresound.nnet.unet import Unet, UnetTcn  # noqa: E402
 from puresound.nnet.dpcrn import DPCRN  # noqa: E402
+from puresound.nnet.lobe.trivial import Magnitude  # noqa: E402
 
 import cases  # noqa: E402
 from detweights import det_state_dict, det_wave  # noqa: E402
@@ -45,7 +46,8 @@ from detweights import det_state_dict, det_wave  # noqa: E402
 REF = cases.namespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                       ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                       AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM,
-                      StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN)
+                      StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN,
+                      Magnitude=Magnitude)
 
 
 def sub(x: torch.Tensor, cs: int = 7, ts: int = 5) -> np.ndarray:

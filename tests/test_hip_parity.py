@@ -918,3 +918,26 @@ def test_ns_dpcrn_preset_matches_reference_golden(PA, dev, golden_dir):
     out = model.inference(n3.to(dev))
     sl = slice(16, ref.shape[1] - 16)
     assert rel_max(out.cpu().numpy()[:, sl], ref.numpy()[:, sl]) < TOL
+
+
+@pytest.mark.parametrize("name", ["tse_unet_tcn_causal_short", "tse_skim_causal_short"])
+def test_more_tse_presets_match_reference_golden(PA, dev, golden_dir, name):
+    """egs/tse presets verbatim: tse_unet_tcn_v0_causal (STFT + UnetTcn with causal gated bN1d TCN + speaker net
+    Magnitude -> 5 x GatedTCN -> ASP -> 1x1, real mask on the STFT) and tse_skim_v0_causal (FreeEncDec + SkiM/FiLM +
+    TCN speaker net)."""
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name).eval()
+    sd = det_state_dict(model)
+    model.load_state_dict(sd)
+    model.to(dev)
+    assert model.overall_parameters == cases.PARAM_COUNTS[name] == int(g["n_params"])
+    noisy = det_wave(c["seed"], c["B"], c["L"])
+    enroll = det_wave(c["seed"] + 1, c["B"], c["L_enroll"])
+    dvec = model.inference_tse_embedding(enroll.to(dev))
+    assert rel_max(dvec[..., 0].cpu().numpy(), g["dvec"]) < TOL
+    wav = model.inference(noisy.to(dev), enroll.to(dev))
+    assert wav.shape == g["wav"].shape
+    edge = 16 if c["enc"]["kind"] == "stft" else 0
+    sl = slice(edge, wav.shape[1] - edge) if edge else slice(None)
+    assert rel_max(wav.cpu().numpy()[:, sl], g["wav"][:, sl]) < TOL
