@@ -54,7 +54,7 @@ const char* ps_last_error(void);
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
  * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product", "segment_overlap",
- * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "conv1x1_bf16", "unfold2d", "activation", "add", "magnitude", "real_mask",
+ * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "conv1x1_bf16", "unfold2d", "activation", "add", "magnitude", "real_mask", "norm_activation",
  * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
@@ -216,7 +216,9 @@ int ps_magnitude_f32(const float* x, float* y, int N, int half, int drop_first, 
  * [N][CH][F][T] is stored as [N][CH*F] rows of ld frames; Conv2d / ConvTranspose2d run as ps_conv1x1_f32 GEMMs
  * (M = Cout, K = Cin*kf*kt, "frames" = (f, t) flattened = Fout*ld) over the unfolded taps.
  *
- * ps_unfold2d_f32: y[n][(ci*kf + jf)*kt + jt][fo*ld + t] = x[n][ci][fi][ti], 0 outside the input or for t >= T.
+ * ps_unfold2d_f32: y[n][(ci*kf + jf)*kt + jt][fo*ld + t] = x[n][ci][fi][ti], 0 for ti outside [0, T_in), fi outside
+ *   [0, Fin) or t >= T (T_in = frames the input holds, T = frames to produce: T_in + dil_t*(kt-1) for an untrimmed
+ *   transposed convolution, whose gLN statistics the reference takes before trimming).
  *   transposed = 0 (nn.ZeroPad2d + nn.Conv2d, unet.py:112-128):  fi = fo*stride_f + jf*dil_f - pad_f,
  *                                                               ti = t + jt*dil_t - pad_t
  *   transposed = 1 (nn.ConvTranspose2d + the time trim, unet.py:139-165,252-256):
@@ -227,10 +229,17 @@ int ps_magnitude_f32(const float* x, float* y, int N, int half, int drop_first, 
  * ps_activation_f32: in place on rows of ld frames, kind 0 none, 1 relu, 2 prelu (one shared slope), 3 mish,
  *   4 sigmoid, 5 tanh (lobe/activation.py); pad frames are cleared.
  * ------------------------------------------------------------------------------------------- */
-int ps_unfold2d_f32(const float* x1, int C1, const float* x2, int C2, float* y, int N, int Fin, int T, int ld, int kf,
-                    int kt, int stride_f, int dil_f, int dil_t, int pad_f, int pad_t, int Fout, int transposed,
+int ps_unfold2d_f32(const float* x1, int C1, const float* x2, int C2, float* y, int N, int Fin, int T_in, int T, int ld,
+                    int kf, int kt, int stride_f, int dil_f, int dil_t, int pad_f, int pad_t, int Fout, int transposed,
                     void* stream);
 int ps_activation_f32(float* x, int kind, const float* slope, int64_t rows, int T, int ld, void* stream);
+/* gLN over [CH, F, T] (GlobLN on a 4-D map, lobe/norm.py:20-34) followed by an activation, in place on [N][rows_per_utt]
+ * rows of ld frames (row r belongs to channel r / rows_per_channel).  pro = PS_NORM_GLOBAL with the producing GEMM's
+ * partial statistics, count = the number of VALID elements per utterance; corr_sum / corr_sq = what the pad columns
+ * contributed to those statistics (zero taps there: the GEMM output is its bias, so sum_c bias[c] * F * (ld - T) and the
+ * same with bias^2). */
+int ps_norm_activation_f32(float* x, const ps_prologue* pro, double corr_sum, double corr_sq, int rows_per_channel,
+                           int kind, const float* slope, int N, int rows_per_utt, int T, int ld, void* stream);
 /* y = a + b over `count` floats (the additive skip connections of Unet(skip_conv=True), unet.py:249); y may alias a or b */
 int ps_add_f32(const float* a, const float* b, float* y, int64_t count, void* stream);
 

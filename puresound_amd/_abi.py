@@ -79,10 +79,12 @@ SIGNATURES = {
     "ps_proj_layernorm_f32": (C.c_int, [_vp] * 5 + [C.c_float, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp] + [C.c_int] * 5
                               + [_vp]),
     "ps_overlap_average_f32": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
-    "ps_unfold2d_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp] + [C.c_int] * 13 + [_vp]),
+    "ps_unfold2d_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp] + [C.c_int] * 14 + [_vp]),
     "ps_activation_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "ps_magnitude_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_real_mask_f32": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
+    "ps_norm_activation_f32": (C.c_int, [_vp, C.POINTER(Prologue), C.c_double, C.c_double, C.c_int, C.c_int, _vp]
+                               + [C.c_int] * 4 + [_vp]),
     "ps_add_f32": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "ps_lstm_cell_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_chan_layernorm_f32": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),

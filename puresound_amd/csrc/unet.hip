@@ -17,7 +17,7 @@ struct Unfold2dArgs {
   const float* x1;
   const float* x2;
   float* y;
-  int C1, C2, Fin, T, ld, kf, kt, sf, df, dt, pf, pt, Fout, transposed;
+  int C1, C2, Fin, T, Tin, ld, kf, kt, sf, df, dt, pf, pt, Fout, transposed;
 };
 
 __global__ __launch_bounds__(256) void unfold2d_kernel(Unfold2dArgs a) {
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void unfold2d_kernel(Unfold2dArgs a) {
       fi = num / a.sf;
       ti = t + a.pt - jt * a.dt;  // pt carries the trim shift here
     }
-    if (ok && fi >= 0 && fi < a.Fin && ti >= 0 && ti < a.T) {
+    if (ok && fi >= 0 && fi < a.Fin && ti >= 0 && ti < a.Tin) {
       const float* src = ci < a.C1 ? a.x1 + ((size_t)n * a.C1 + ci) * a.Fin * a.ld
                                    : a.x2 + ((size_t)n * a.C2 + (ci - a.C1)) * a.Fin * a.ld;
       v = src[(size_t)fi * a.ld + ti];
@@ -73,6 +73,56 @@ __global__ __launch_bounds__(256) void activation_kernel(float* __restrict__ x, 
   *reinterpret_cast<f32x4*>(x + row * ld + t) = v;
 }
 
+// gLN over [CH, F, T] (GlobLN on a 4-D map, lobe/norm.py:20-34) + activation, in place.  The statistics come from the
+// producing GEMM's partial slabs, which also cover the pad columns of every frequency row; there the taps are zero and
+// the GEMM output is exactly its bias, so the caller passes that contribution (corr_sum, corr_sq) to be taken out.
+struct NormActArgs {
+  float* x;
+  ps_prologue pro;
+  double corr_sum, corr_sq;
+  const float* slope;
+  int rows_per_channel, kind, rows_per_utt, T, ld;
+};
+
+__global__ __launch_bounds__(256) void norm_activation_kernel(NormActArgs a) {
+  __shared__ double red[8];
+  const int n = blockIdx.z, row = blockIdx.y;
+  double sa = 0.0, sq = 0.0;
+  const double* src = a.pro.stats + (size_t)n * a.pro.parts * 2;
+  for (int i = threadIdx.x; i < a.pro.parts; i += 256) {
+    sa += src[2 * i];
+    sq += src[2 * i + 1];
+  }
+  block_sum2(sa, sq, red);
+  sa -= a.corr_sum;
+  sq -= a.corr_sq;
+  const double mean = sa / a.pro.count;
+  double var = sq / a.pro.count - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)a.pro.eps));
+  const int ch = row / a.rows_per_channel;
+  const float sc = a.pro.gamma[ch] * rstd, sh = a.pro.beta[ch] - (float)mean * sc;
+  const float s = a.slope ? a.slope[0] : 0.f;
+  const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t >= a.ld) return;
+  float* p = a.x + ((size_t)n * a.rows_per_utt + row) * a.ld + t;
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float u = v[e] * sc + sh;
+    switch (a.kind) {
+      case 1: u = fmaxf(u, 0.f); break;
+      case 2: u = u >= 0.f ? u : s * u; break;
+      case 3: u = u * tanhf(u > 20.f ? u : log1pf(expf(u))); break;
+      case 4: u = 1.f / (1.f + expf(-u)); break;
+      case 5: u = tanhf(u); break;
+      default: break;
+    }
+    v[e] = (t + e < a.T) ? u : 0.f;
+  }
+  *reinterpret_cast<f32x4*>(p) = v;
+}
+
 __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                        float* __restrict__ y, size_t n4) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -93,10 +143,10 @@ static int unet_status(const char* who) {
 
 using namespace ps;
 
-extern "C" int ps_unfold2d_f32(const float* x1, int C1, const float* x2, int C2, float* y, int N, int Fin, int T,
-                               int ld, int kf, int kt, int stride_f, int dil_f, int dil_t, int pad_f, int pad_t, int Fout,
+extern "C" int ps_unfold2d_f32(const float* x1, int C1, const float* x2, int C2, float* y, int N, int Fin, int T_in,
+                               int T, int ld, int kf, int kt, int stride_f, int dil_f, int dil_t, int pad_f, int pad_t, int Fout,
                                int transposed, void* stream) {
-  if (!x1 || !y || N <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && !x2) || Fin <= 0 || Fout <= 0 || T <= 0 || ld < T ||
+  if (!x1 || !y || N <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && !x2) || Fin <= 0 || Fout <= 0 || T <= 0 || T_in <= 0 || ld < T || ld < T_in ||
       kf <= 0 || kt <= 0 || stride_f <= 0 || dil_f <= 0 || dil_t <= 0 || Fout > 65535) {
     set_error("ps_unfold2d_f32: bad argument (N=%d C=%d+%d F=%d->%d T=%d k=%dx%d)", N, C1, C2, Fin, Fout, T, kf, kt);
     return PS_E_INVALID;
@@ -106,7 +156,7 @@ extern "C" int ps_unfold2d_f32(const float* x1, int C1, const float* x2, int C2,
     set_error("ps_unfold2d_f32: N * Cin * kf * kt = %lld exceeds the grid limit 65535", z);
     return PS_E_UNSUPPORTED;
   }
-  Unfold2dArgs a{x1, x2, y, C1, C2, Fin, T, ld, kf, kt, stride_f, dil_f, dil_t, pad_f, pad_t, Fout, transposed};
+  Unfold2dArgs a{x1, x2, y, C1, C2, Fin, T, T_in, ld, kf, kt, stride_f, dil_f, dil_t, pad_f, pad_t, Fout, transposed};
   {
     LaunchTimer timer("unfold2d", (hipStream_t)stream);
     hipLaunchKernelGGL(unfold2d_kernel, dim3((ld + 255) / 256, Fout, (unsigned)z), dim3(256), 0, (hipStream_t)stream, a);
@@ -141,4 +191,22 @@ extern "C" int ps_add_f32(const float* a, const float* b, float* y, int64_t coun
   LaunchTimer timer("add", (hipStream_t)stream);
   hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, n4);
   return unet_status("ps_add_f32");
+}
+
+extern "C" int ps_norm_activation_f32(float* x, const ps_prologue* pro, double corr_sum, double corr_sq,
+                                      int rows_per_channel, int kind, const float* slope, int N, int rows_per_utt, int T,
+                                      int ld, void* stream) {
+  if (!x || !pro || pro->norm != PS_NORM_GLOBAL || !pro->stats || pro->parts <= 0 || pro->count <= 0 || !pro->gamma ||
+      !pro->beta || N <= 0 || N > 65535 || rows_per_utt <= 0 || rows_per_utt > 65535 || rows_per_channel <= 0 ||
+      T <= 0 || ld < T || ld % 4 || ((uintptr_t)x & 15) || kind < 0 || kind > 5 || (kind == 2 && !slope)) {
+    set_error("ps_norm_activation_f32: bad argument (N=%d rows=%d T=%d ld=%d kind=%d)", N, rows_per_utt, T, ld, kind);
+    return PS_E_INVALID;
+  }
+  NormActArgs a{x, *pro, corr_sum, corr_sq, slope, rows_per_channel, kind, rows_per_utt, T, ld};
+  {
+    LaunchTimer timer("norm_activation", (hipStream_t)stream);
+    hipLaunchKernelGGL(norm_activation_kernel, dim3((ld / 4 + 255) / 256, rows_per_utt, N), dim3(256), 0,
+                       (hipStream_t)stream, a);
+  }
+  return unet_status("ps_norm_activation_f32");
 }

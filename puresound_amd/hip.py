@@ -369,7 +369,7 @@ ACT_KINDS = {"none": 0, "relu": 1, "prelu": 2, "mish": 3, "sigmoid": 4, "tanh": 
 
 
 def unfold2d(x1: torch.Tensor, x2: Optional[torch.Tensor], t: int, f_out: int, kf: int, kt: int, stride_f: int,
-             dil_f: int, dil_t: int, pad_f: int, pad_t: int, transposed: bool) -> torch.Tensor:
+             dil_f: int, dil_t: int, pad_f: int, pad_t: int, transposed: bool, t_in: Optional[int] = None) -> torch.Tensor:
     """x1 [N,C1,F,ld] (+ x2 [N,C2,F,ld]) -> tap rows [N, (C1+C2)*kf*kt, f_out*ld] for the Conv2d / ConvTranspose2d GEMM."""
     require_device(x1, "unfold2d")
     n, c1, f_in, ld = x1.shape
@@ -377,7 +377,7 @@ def unfold2d(x1: torch.Tensor, x2: Optional[torch.Tensor], t: int, f_out: int, k
     if x2 is not None and (x2.shape[0], x2.shape[2], x2.shape[3]) != (n, f_in, ld):
         raise RuntimeError("unfold2d: the two sources must agree in N, F and ld")
     y = torch.empty(n, (c1 + c2) * kf * kt, f_out * ld, dtype=torch.float32, device=x1.device)
-    check(lib().ps_unfold2d_f32(ptr(x1), c1, ptr(x2), c2, ptr(y), n, f_in, t, ld, kf, kt, stride_f, dil_f, dil_t, pad_f,
+    check(lib().ps_unfold2d_f32(ptr(x1), c1, ptr(x2), c2, ptr(y), n, f_in, t if t_in is None else t_in, t, ld, kf, kt, stride_f, dil_f, dil_t, pad_f,
                                 pad_t, f_out, int(transposed), stream_ptr(x1.device)), "ps_unfold2d_f32")
     return y
 
@@ -389,6 +389,16 @@ def activation_(x: torch.Tensor, kind: str, slope: Optional[torch.Tensor], t: in
     check(lib().ps_activation_f32(ptr(x), ACT_KINDS[kind], ptr(slope), x.numel() // ld, t, ld, stream_ptr(x.device)),
           "ps_activation_f32")
     return x
+
+
+def norm_activation_(x4: torch.Tensor, t: int, pro: Prologue, corr_sum: float, corr_sq: float, kind: str,
+                     slope: Optional[torch.Tensor]) -> torch.Tensor:
+    """gLN over [CH, F, T] + activation, in place on [N, CH, F, ld]."""
+    require_device(x4, "norm_activation_")
+    n, ch, f, ld = x4.shape
+    check(lib().ps_norm_activation_f32(ptr(x4), C.byref(pro), float(corr_sum), float(corr_sq), f, ACT_KINDS[kind],
+                                       ptr(slope), n, ch * f, t, ld, stream_ptr(x4.device)), "ps_norm_activation_f32")
+    return x4
 
 
 def real_mask(feats: torch.Tensor, mask: torch.Tensor, mask_act: str = "linear") -> torch.Tensor:

@@ -15,7 +15,8 @@ from .. import hip
 from ._plans import PlanCache, _f32
 from .conv_tasnet import TCN, GatedTCN, TcnBlock
 from .lobe.activation import activation_kind, get_activation
-from .lobe.norm import get_norm
+from .._abi import PS_NORM_GLOBAL
+from .lobe.norm import GlobLN, get_norm
 
 
 class Unet(PlanCache, nn.Module):
@@ -94,8 +95,8 @@ class Unet(PlanCache, nn.Module):
     @staticmethod
     def _fold(norm: Optional[nn.Module], w2: torch.Tensor, b: torch.Tensor):
         """eval BatchNorm2d after a conv is an affine map of its output: fold it into the GEMM weight / bias."""
-        if norm is None:
-            return w2, b
+        if norm is None or isinstance(norm, GlobLN):
+            return w2, b     # gLN needs the statistics of the conv output: applied by ps_norm_activation_f32
         if not isinstance(norm, nn.BatchNorm2d):
             raise NotImplementedError(f"U-Net convolution norm {type(norm).__name__}: only bN2d is on the HIP path")
         if norm.training:
@@ -103,6 +104,15 @@ class Unet(PlanCache, nn.Module):
         scale = norm.weight.detach().float() / torch.sqrt(norm.running_var.detach().float() + norm.eps)
         shift = norm.bias.detach().float() - norm.running_mean.detach().float() * scale
         return w2 * scale.to(w2.device).reshape(-1, 1), b * scale.to(b.device) + shift.to(b.device)
+
+    @staticmethod
+    def _gln(norm: Optional[nn.Module], bias: torch.Tensor, device) -> dict:
+        """gLN parameters + the bias moments that take the pad columns out of the GEMM's statistics (one host read
+        at plan time)."""
+        if not isinstance(norm, GlobLN):
+            return {}
+        return dict(gln=(_f32(norm.gamma, device), _f32(norm.beta, device), float(norm.eps)),
+                    bias_sum=float(bias.double().sum().item()), bias_sq=float((bias.double() ** 2).sum().item()))
 
     def _act(self, mod: Optional[nn.Module], device):
         if mod is None:
@@ -123,14 +133,16 @@ class Unet(PlanCache, nn.Module):
             w2, b = self._fold(seq[2], _f32(conv.weight, device).reshape(conv.out_channels, -1),
                                _f32(conv.bias, device))
             kind, slope = self._act(seq[3], device)
-            down.append(dict(wt=hip.pack_wt(w2), bias=b.contiguous(), M=conv.out_channels, act=kind, slope=slope))
+            down.append(dict(wt=hip.pack_wt(w2), bias=b.contiguous(), M=conv.out_channels, act=kind, slope=slope,
+                             **self._gln(seq[2], b, device)))
         for j, seq in enumerate(self.cnn_up):
             conv = seq[0]
             w = _f32(conv.weight, device)                                      # [Cin, Cout, kf, kt]
             w2 = w.permute(1, 0, 2, 3).reshape(w.shape[1], -1)
             w2, b = self._fold(seq[1] if len(seq) > 1 else None, w2, _f32(conv.bias, device))
             kind, slope = self._act(seq[2] if len(seq) > 2 else None, device)
-            up.append(dict(wt=hip.pack_wt(w2.contiguous()), bias=b.contiguous(), M=w.shape[1], act=kind, slope=slope))
+            up.append(dict(wt=hip.pack_wt(w2.contiguous()), bias=b.contiguous(), M=w.shape[1], act=kind, slope=slope,
+                           **self._gln(seq[1] if len(seq) > 1 else None, b, device)))
         if self.skip_conv:
             for seq in self.skip_cnn:
                 kind, slope = self._act(seq[1], device)
@@ -141,10 +153,16 @@ class Unet(PlanCache, nn.Module):
     # -- pieces -------------------------------------------------------------------------------------------------
     def _gemm_act(self, taps: torch.Tensor, lay: dict, f_out: int, ld: int, t: int, res=None) -> torch.Tensor:
         n = taps.shape[0]
-        y, _ = hip.conv1x1(taps, f_out * ld, lay["wt"], lay["M"], None, lay["bias"], res=res,
-                           out=torch.empty(n, lay["M"], f_out * ld, dtype=torch.float32, device=taps.device))
+        gln = lay.get("gln")
+        y, stats = hip.conv1x1(taps, f_out * ld, lay["wt"], lay["M"], None, lay["bias"], res=res,
+                               want_stats=gln is not None,
+                               out=torch.empty(n, lay["M"], f_out * ld, dtype=torch.float32, device=taps.device))
         y = y.view(n, lay["M"], f_out, ld)
-        return hip.activation_(y, lay["act"], lay["slope"], t)
+        if gln is None:
+            return hip.activation_(y, lay["act"], lay["slope"], t)
+        pro = hip.make_prologue(PS_NORM_GLOBAL, False, stats, float(lay["M"] * f_out * t), gln[2], gln[0], gln[1], None)
+        pad = float(f_out * (ld - t))
+        return hip.norm_activation_(y, t, pro, lay["bias_sum"] * pad, lay["bias_sq"] * pad, lay["act"], lay["slope"])
 
     def _down(self, x4: torch.Tensor, t: int, p: dict) -> List[torch.Tensor]:
         """[N, CH0, F, ld] -> skip list (input first), unet.py:235-246."""
@@ -183,15 +201,31 @@ class Unet(PlanCache, nn.Module):
             pf = kf // 2
             op = sf - kf + 2 * pf
             f_out = (f_in - 1) * sf - 2 * pf + df * (kf - 1) + op + 1
-            shift = (self.t_kernel - 1) * dt if transpose_delay else 0
-            taps = hip.unfold2d(x, x2, t, f_out, kf, self.t_kernel, sf, df, dt, pf, shift, True)
-            x = self._gemm_act(taps, lay, f_out, ld, t)
+            ext = (self.t_kernel - 1) * dt                       # frames the transposed convolution adds
+            if "gln" in lay and ext > 0:
+                # the reference normalises the UNtrimmed output (unet.py:252-256 trims after the layer): produce all
+                # T + ext frames, normalise over them, then drop the trimmed ones
+                if t + ext > ld:
+                    raise NotImplementedError("U-Net on HIP: gLN decoder needs rows with room for the untrimmed frames")
+                taps = hip.unfold2d(x, x2, t + ext, f_out, kf, self.t_kernel, sf, df, dt, pf, 0, True, t_in=t)
+                x = self._gemm_act(taps, lay, f_out, ld, t + ext)
+                if transpose_delay:   # keep frames [ext, ext + T): a 1x1 "convolution" with a negative time pad
+                    x = hip.unfold2d(x, None, t, f_out, 1, 1, 1, 1, 1, 0, -ext, False, t_in=t + ext).view(
+                        n, lay["M"], f_out, ld)
+            else:
+                shift = ext if transpose_delay else 0
+                taps = hip.unfold2d(x, x2, t, f_out, kf, self.t_kernel, sf, df, dt, pf, shift, True)
+                x = self._gemm_act(taps, lay, f_out, ld, t)
         return x
+
+    def frames_needed(self, t: int) -> int:
+        """Row length the decoder needs: gLN layers hold their untrimmed T + transpose_t_size - 1 frames."""
+        return t + (self.t_kernel - 1) * max(dt for _, dt in self.dilation)
 
     def _split_in(self, x: torch.Tensor):
         """[N, C, T] compact -> ([N, CH0, F, ld], T)."""
         t = x.shape[-1]
-        xp = hip.pad_rows(x if x.dim() == 3 else x.reshape(x.shape[0], -1, t))
+        xp = hip.pad_rows(x if x.dim() == 3 else x.reshape(x.shape[0], -1, t), self.frames_needed(t))
         n, c, ld = xp.shape
         ch0 = 2 if self.input_type.lower() == "ri" else 1
         return xp.view(n, ch0, c // ch0, ld), t

@@ -75,6 +75,18 @@ CASES = {
                             dconv_norm="bN1d", causal=True)),
         speaker_net=dict(n_tcn=5, C=256, H=128, att=128, E=192, block="gated", magnitude=True),
         wrap=dict(mask_constraint="linear", drop_first_bin=True), B=2, L=4000, L_enroll=3000, seed=1234),
+    "tse_unet_tcn_short": dict(   # tse_unet_tcn_v0 (egs/tse/model.py:184-244): gLN as the 2-D convolution norm, non-causal
+        kind="wrap", enc=dict(kind="stft", n_fft=512, hop=128, drop_first_bin=True),
+        masker=dict(cls="UnetTcn", args=(), oracle="unet_tcn",
+                    kw=dict(embed_dim=192, embed_norm=True, input_type="RI", input_dim=512, activation_type="PReLU",
+                            norm_type="gLN", channels=(1, 32, 64, 128, 128, 128, 128), transpose_t_size=2,
+                            transpose_delay=True, skip_conv=False, kernel_t=(2,) * 6, kernel_f=(5,) * 6,
+                            stride_t=(1,) * 6, stride_f=(2,) * 6, dilation_t=(1,) * 6, dilation_f=(1,) * 6,
+                            delay=(0,) * 6, tcn_layer="gated", tcn_kernel=3, tcn_dim=256, tcn_dilated_basic=2,
+                            per_tcn_stack=5, repeat_tcn=3, tcn_with_embed=[1, 0, 0, 0, 0], tcn_norm="gLN",
+                            dconv_norm="gGN", causal=False)),
+        speaker_net=dict(n_tcn=5, C=256, H=128, att=128, E=192, block="gated", magnitude=True),
+        wrap=dict(mask_constraint="linear", drop_first_bin=True), B=2, L=4000, L_enroll=3000, seed=1234),
     "tse_skim_causal_short": dict(
         kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
         masker=dict(cls="SkiM", args=(128, 256, 128),
@@ -195,6 +207,12 @@ CASES = {
                                        stride_f=(2, 2), dilation_t=(1, 1), dilation_f=(1, 1), delay=(0, 0),
                                        tcn_layer="gated", tcn_use_film=True, tcn_dim=8, per_tcn_stack=2, repeat_tcn=1,
                                        tcn_with_embed=[1, 0], dropout=0.0), B=2, T=21, seed=54, embed=6),
+    "unettcn_gln2d": dict(kind="unet", cls="UnetTcn", oracle="unet_tcn",
+                          kw=dict(embed_dim=6, embed_norm=True, input_type="RI", input_dim=64, norm_type="gLN",
+                                  channels=(1, 4, 6), transpose_delay=True, kernel_t=(2, 2), kernel_f=(5, 5),
+                                  stride_t=(1, 1), stride_f=(2, 2), dilation_t=(1, 1), dilation_f=(1, 1), delay=(0, 0),
+                                  tcn_layer="gated", tcn_dim=8, per_tcn_stack=2, repeat_tcn=1, tcn_with_embed=[1, 0],
+                                  tcn_norm="gLN", dropout=0.0), B=2, T=21, seed=56, embed=6),
     "dpcrn_small": dict(kind="unet", cls="DPCRN", oracle="dpcrn",
                         kw=dict(input_type="RI", input_dim=32, channels=(1, 4, 6, 8), transpose_delay=True,
                                 kernel_t=(2, 2, 2), kernel_f=(5, 3, 3), stride_t=(1, 1, 1), stride_f=(2, 2, 1),

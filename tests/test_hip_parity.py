@@ -920,7 +920,7 @@ def test_ns_dpcrn_preset_matches_reference_golden(PA, dev, golden_dir):
     assert rel_max(out.cpu().numpy()[:, sl], ref.numpy()[:, sl]) < TOL
 
 
-@pytest.mark.parametrize("name", ["tse_unet_tcn_causal_short", "tse_skim_causal_short"])
+@pytest.mark.parametrize("name", ["tse_unet_tcn_causal_short", "tse_unet_tcn_short", "tse_skim_causal_short"])
 def test_more_tse_presets_match_reference_golden(PA, dev, golden_dir, name):
     """egs/tse presets verbatim: tse_unet_tcn_v0_causal (STFT + UnetTcn with causal gated bN1d TCN + speaker net
     Magnitude -> 5 x GatedTCN -> ASP -> 1x1, real mask on the STFT) and tse_skim_v0_causal (FreeEncDec + SkiM/FiLM +
@@ -931,7 +931,9 @@ def test_more_tse_presets_match_reference_golden(PA, dev, golden_dir, name):
     sd = det_state_dict(model)
     model.load_state_dict(sd)
     model.to(dev)
-    assert model.overall_parameters == cases.PARAM_COUNTS[name] == int(g["n_params"])
+    assert model.overall_parameters == int(g["n_params"])
+    if name in cases.PARAM_COUNTS:
+        assert model.overall_parameters == cases.PARAM_COUNTS[name]
     noisy = det_wave(c["seed"], c["B"], c["L"])
     enroll = det_wave(c["seed"] + 1, c["B"], c["L_enroll"])
     dvec = model.inference_tse_embedding(enroll.to(dev))
