@@ -208,8 +208,10 @@ int ps_gated_product_f32(const float* left, const float* right, float* y, int N,
 int ps_real_mask_f32(const float* feats, const float* mask, float* out, int64_t rows, int ldt, int mask_act, void* stream);
 
 /* Magnitude lobe of the speaker branch (lobe/trivial.py:21-59) on the [re rows; im rows] layout [N][2*half][ldt]:
- * y[n][h][t] = sqrt(re^2 + im^2 + 1e-8) of bin h + drop_first (log1p of it when asked), y is [N][half-drop_first][ldt]. */
-int ps_magnitude_f32(const float* x, float* y, int N, int half, int drop_first, int log1p, int T, int ldt, void* stream);
+ * y[n][h][t] = sqrt(re^2 + im^2 + 1e-8) of bin h + drop_first (kind 0; kind 1: log1p of it; kind 2: the power re^2 + im^2;
+ * kind 3: power + 1e-8 -- ConvMelSpectrogram's "Magnitude" input to the mel projection, lobe/encoder.py:529-536);
+ * y is [N][half-drop_first][ldt]. */
+int ps_magnitude_f32(const float* x, float* y, int N, int half, int drop_first, int kind, int T, int ldt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 2-D convolutional maskers (Unet / UnetTcn / DPCRN: unet.py:13-557, dpcrn.py:11-213).  A 4-D activation

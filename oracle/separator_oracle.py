@@ -202,6 +202,16 @@ def istft_decode(spec: torch.Tensor, sd: SD, p: str, hop: int) -> torch.Tensor:
     return out
 
 
+def fbank_encode(wav: torch.Tensor, sd: SD, p: str, hop: int, trainable: bool) -> torch.Tensor:
+    """FbankEnc / ConvMelSpectrogram.forward, output_format "Magnitude" (lobe/encoder.py:529-536): power spectrum of
+    the conv-STFT (+1e-8 when trainable) projected on the mel filterbank -> [N, n_mels, T]."""
+    spec = stft_encode(wav, sd[p + "wsin"], sd[p + "wcos"], hop)        # [N, F, T, 2]
+    power = spec[..., 0] ** 2 + spec[..., 1] ** 2
+    if trainable:
+        power = power + 1e-8
+    return torch.matmul(power.transpose(1, 2), sd[p + "filterbank"].to(wav.dtype)).transpose(1, 2)
+
+
 def create_fourier_tables(n_fft: int):
     """create_fourier_kernels(freq_scale="no") (lobe/stft.py:91-96,100): float64 sin/cos -> fp32."""
     s = torch.arange(n_fft, dtype=torch.float64)
@@ -416,7 +426,11 @@ def inference(noisy: torch.Tensor, sd: SD, cfg: dict, enroll: Optional[torch.Ten
     dvec = None
     kind = cfg.get("masker_kind", "convtasnet")
     if enroll is not None:
-        dvec = encode_features(enroll, sd, cfg["encoder"])
+        if "encoder_spk" in cfg:                                     # FbankEnc enrolment encoder (base_nn.py:361-375)
+            dvec = fbank_encode(enroll, sd, "encoder_spk.encoder.", cfg["encoder_spk"]["hop"],
+                                cfg["encoder_spk"]["trainable"])
+        else:
+            dvec = encode_features(enroll, sd, cfg["encoder"])
         if not cfg["masker"].get("embedding_free_tse", False):      # base_nn.py:697-707
             dvec = speaker_embedding(dvec, sd, cfg["speaker_net"])
     if kind == "convtasnet":

@@ -173,8 +173,11 @@ __global__ __launch_bounds__(256) void magnitude_kernel(const float* __restrict_
   const int hout = half - drop;
   const float re = x[((size_t)n * 2 * half + h + drop) * ldt + t];
   const float im = x[((size_t)n * 2 * half + half + h + drop) * ldt + t];
-  float m = sqrtf(re * re + im * im + 1e-8f);
-  if (log1p_) m = log1pf(m);
+  // kind 0: sqrt(|.|^2 + 1e-8); 1: log1p of it; 2: |.|^2 (power); 3: |.|^2 + 1e-8 (ConvMelSpectrogram, encoder.py:532)
+  float m = re * re + im * im;
+  if (log1p_ <= 1) m = sqrtf(m + 1e-8f);
+  if (log1p_ == 1) m = log1pf(m);
+  if (log1p_ == 3) m += 1e-8f;
   y[((size_t)n * hout + h) * ldt + t] = m;
 }
 }  // namespace ps
@@ -183,7 +186,7 @@ extern "C" int ps_magnitude_f32(const float* x, float* y, int N, int half, int d
                                 void* stream) {
   using namespace ps;
   if (!x || !y || N <= 0 || half <= 0 || T <= 0 || ldt < T || (drop_first != 0 && drop_first != 1) ||
-      half - drop_first <= 0 || half > 65535 || N > 65535) {
+      half - drop_first <= 0 || half > 65535 || N > 65535 || log1p < 0 || log1p > 3) {
     set_error("ps_magnitude_f32: bad argument (N=%d half=%d T=%d)", N, half, T);
     return PS_E_INVALID;
   }

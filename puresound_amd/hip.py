@@ -413,13 +413,15 @@ def real_mask(feats: torch.Tensor, mask: torch.Tensor, mask_act: str = "linear")
     return out
 
 
-def magnitude(x: torch.Tensor, t: int, drop_first: bool, log1p: bool) -> torch.Tensor:
-    """[re rows; im rows] padded [N,2H,ldt] -> |.| padded [N,H-drop,ldt]."""
+def magnitude(x: torch.Tensor, t: int, drop_first: bool, log1p: bool, kind: Optional[str] = None) -> torch.Tensor:
+    """[re rows; im rows] padded [N,2H,ldt] -> |.| (or log1p|.|, or the power with kind="power"/"power_eps")
+    padded [N,H-drop,ldt]."""
     require_device(x, "magnitude")
     n, c2, ldt = x.shape
     half = c2 // 2
     y = torch.zeros(n, half - int(drop_first), ldt, dtype=torch.float32, device=x.device)
-    check(lib().ps_magnitude_f32(ptr(x), ptr(y), n, half, int(drop_first), int(log1p), t, ldt, stream_ptr(x.device)),
+    k = {"power": 2, "power_eps": 3}[kind] if kind else int(log1p)
+    check(lib().ps_magnitude_f32(ptr(x), ptr(y), n, half, int(drop_first), k, t, ldt, stream_ptr(x.device)),
           "ps_magnitude_f32")
     return y
 

@@ -4,7 +4,7 @@ from types import SimpleNamespace
 from .base_nn import SoTaskWrapModule
 from .conv_tasnet import TCN, ConvTasNet, GatedTCN
 from .dprnn import DPRNN
-from .lobe.encoder import ConvEncDec, FreeEncDec
+from .lobe.encoder import ConvEncDec, FbankEnc, FreeEncDec
 from .lobe.pooling import AttentiveStatisticsPooling
 from .lobe.trivial import FiLM, Gate, Magnitude
 from .skim import MemLSTM, SegLSTM, SkiM
@@ -23,4 +23,4 @@ class _Namespace(SimpleNamespace):
 NS = _Namespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                      ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                      AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM, MemLSTM=MemLSTM, Unet=Unet, UnetTcn=UnetTcn,
-                DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, Magnitude=Magnitude, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate)
+                DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, Magnitude=Magnitude, FbankEnc=FbankEnc, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate)

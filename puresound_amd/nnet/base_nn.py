@@ -18,7 +18,7 @@ from .lobe.trivial import Magnitude
 from .dprnn import DPRNN
 from .skim import SkiM
 from .unet import Unet
-from .lobe.encoder import ConvEncDec, FreeEncDec
+from .lobe.encoder import ConvEncDec, FbankEnc, FreeEncDec
 from .lobe.pooling import AttentiveStatisticsPooling
 
 _MASK_ACTS = ("linear", "relu", "sigmoid")
@@ -169,8 +169,8 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             raise NotImplementedError("embedding_free_tse needs a DPRNN masker (dprnn.py:120-125)")
         if enroll is not None:
             hip.require_device(enroll, "SoTaskWrapModule.inference")
-            if self.encoder_spk is not None or (self.speaker_net is None and not self.embedding_free_tse):
-                raise NotImplementedError("HIP speaker branch: shared encoder + speaker_net")
+            if self.speaker_net is None and not self.embedding_free_tse:
+                raise NotImplementedError("HIP speaker branch: an enrolment needs a speaker_net (or embedding_free_tse)")
         # the dual-path maskers pad the frame axis to whole segments: make the encoder leave room for it
         need = self.masker.padded_frames_needed if recurrent else None
 
@@ -276,19 +276,21 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         return pooled
 
     def _speaker_embedding(self, enroll: torch.Tensor, lane: int = 0) -> torch.Tensor:
-        """enroll [N,L'] -> dvec [N,E] (shared encoder)."""
-        if isinstance(self.encoder, ConvEncDec):
-            x, t = self.encoder.encoder.encode_padded(enroll, self.drop_first_bin)
+        """enroll [N,L'] -> dvec [N,E]; the enrolment goes through encoder_spk when there is one, else through the
+        shared encoder (base_nn.py:347-375)."""
+        enc = self.encoder_spk if self.encoder_spk is not None else self.encoder
+        if isinstance(enc, ConvEncDec):
+            x, t = enc.encoder.encode_padded(enroll, self.drop_first_bin)
+        elif isinstance(enc, (FreeEncDec, FbankEnc)):
+            x, t = enc.encode_padded(enroll)
         else:
-            x, t = self.encoder.encode_padded(enroll)
+            raise NotImplementedError(f"HIP speaker branch: no kernel path for a {type(enc).__name__} enrolment encoder")
         return self._speaker_embedding_from_feats(x, t)
 
     @torch.no_grad()
     def inference_tse_embedding(self, enroll: Optional[torch.Tensor] = None) -> torch.Tensor:
         """enroll [N,L'] -> [N,E,1], as the reference returns it (base_nn.py:724-738: not squeezed)."""
         hip.require_device(enroll, "SoTaskWrapModule.inference_tse_embedding")
-        if self.encoder_spk is not None:
-            raise NotImplementedError("HIP speaker branch: shared encoder")
         return self._speaker_embedding(enroll.contiguous()).unsqueeze(2)
 
     def _verbose(self):

@@ -214,3 +214,119 @@ class ConvEncDec(nn.Module):
     def inverse(self, x: torch.Tensor) -> torch.Tensor:
         gen = self.encoder.inverse(x)
         return gen.squeeze(1) if gen.dim() == 3 else gen
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Mel front end of the speaker branch (encoder.py:186-272, 459-598; stft.py:129-293)
+# ------------------------------------------------------------------------------------------------------------
+def _hz_to_mel(f):
+    """Slaney mel scale: linear (200/3 Hz per mel) below 1 kHz, logarithmic (27 steps per factor 6.4) above."""
+    import numpy as np
+    f = np.asarray(f, dtype=np.float64)
+    lin = f / (200.0 / 3)
+    brk_mel, step = 1000.0 / (200.0 / 3), np.log(6.4) / 27.0
+    return np.where(f >= 1000.0, brk_mel + np.log(np.maximum(f, 1e-30) / 1000.0) / step, lin)
+
+
+def _mel_to_hz(m):
+    import numpy as np
+    m = np.asarray(m, dtype=np.float64)
+    brk_mel, step = 1000.0 / (200.0 / 3), np.log(6.4) / 27.0
+    return np.where(m >= brk_mel, 1000.0 * np.exp(step * (m - brk_mel)), (200.0 / 3) * m)
+
+
+def mel_filterbank(sr: int, n_fft: int, n_banks: int = 128, fmin: float = 0.0, fmax: Optional[float] = None,
+                   norm: int = 1) -> torch.Tensor:
+    """[n_banks, n_fft//2+1] triangular Slaney-normalised mel weights (same construction as stft.py:237-293)."""
+    import numpy as np
+    if fmax is None:
+        fmax = float(sr / 2)
+    bins = np.linspace(0, float(sr) / 2, int(1 + n_fft // 2), endpoint=True)
+    edges = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_banks + 2))
+    width = np.diff(edges)
+    ramps = np.subtract.outer(edges, bins)
+    w = np.zeros((n_banks, bins.shape[0]), dtype=np.float32)
+    for i in range(n_banks):
+        w[i] = np.maximum(0, np.minimum(-ramps[i] / width[i], ramps[i + 2] / width[i + 1]))
+    if norm == 1:
+        w *= (2.0 / (edges[2:n_banks + 2] - edges[:n_banks]))[:, None]
+    if not np.all((edges[:-2] == 0) | (w.max(axis=1) > 0)):
+        raise ValueError("Empty filters detected in mel frequency basis.")
+    return torch.from_numpy(w)
+
+
+class ConvMelSpectrogram(ConvSTFT):
+    """Mel spectrogram on the conv-STFT (encoder.py:459-598): analysis GEMM, power / magnitude of the bins
+    (ps_magnitude_f32), mel projection GEMM.  The inverse (pseudo-inverse mel + iSTFT) is not on the HIP path."""
+
+    def __init__(self, window_mask: torch.Tensor, n_fft: int = 512, win_length: int = 512,
+                 freq_bins: Optional[int] = None, hop_length: Optional[int] = None, freq_scale: str = "no",
+                 iSTFT: bool = True, fmin: int = 50, fmax: int = 6000, sr: int = 16000, trainable: bool = False,
+                 output_format: str = "MagPhase", n_banks: int = 80):
+        super().__init__(window_mask, n_fft, win_length, freq_bins, hop_length, freq_scale, iSTFT, fmin, fmax, sr,
+                         trainable, output_format)
+        mel_fb = mel_filterbank(sr=16000, n_fft=n_fft, n_banks=n_banks).permute(1, 0)     # [bins, n_mels]
+        inv_mel_fb = torch.pinverse(mel_fb)
+        if trainable:
+            self.register_parameter("filterbank", nn.Parameter(mel_fb, requires_grad=True))
+            self.register_parameter("inv_filterbank", nn.Parameter(inv_mel_fb, requires_grad=True))
+        else:
+            self.register_buffer("filterbank", mel_fb)
+            self.register_buffer("inv_filterbank", inv_mel_fb)
+
+    def encode_padded(self, x: torch.Tensor):
+        """[N, L] -> (mel features padded [N, n_mels, ldt], T)."""
+        fmt = self.output_format.lower()
+        if fmt not in ("magnitude", "magphase"):
+            raise NotImplementedError
+        if fmt == "magphase":
+            raise NotImplementedError("ConvMelSpectrogram on HIP: the 'Magnitude' output (mel of the power spectrum)")
+        spec, t = ConvSTFT.encode_padded(self, x, False)                                    # [re bins ; im bins]
+        bins = spec.shape[1] // 2
+        power = hip.magnitude(spec, t, False, False, kind="power_eps" if self.trainable else "power")
+        key = (self.filterbank.data_ptr(), self.filterbank._version)
+        if getattr(self, "_mel_plan", None) is None or self._mel_plan[0] != key:
+            self._mel_plan = (key, hip.pack_wt(self.filterbank.detach().float().t().contiguous()))
+        n_mels = self.filterbank.shape[1]
+        y, _ = hip.conv1x1(power, t, self._mel_plan[1], n_mels,
+                           out=torch.empty(x.shape[0], n_mels, spec.shape[-1], dtype=torch.float32, device=x.device))
+        assert bins == self.filterbank.shape[0]
+        return y, t
+
+    def forward(self, x: torch.Tensor):
+        """x [N, 1, L] -> mel [N, n_mels, T] (output_format 'Magnitude', encoder.py:529-536)."""
+        hip.require_device(x, "ConvMelSpectrogram.forward")
+        y, t = self.encode_padded(x[:, 0] if x.dim() == 3 else x)
+        return hip.unpad_rows(y, t)
+
+    def inverse(self, melspec, phase, refresh_win=True):
+        raise NotImplementedError("ConvMelSpectrogram.inverse (pseudo-inverse mel + iSTFT) is not on the HIP path")
+
+
+class FbankEnc(nn.Module):
+    """Mel front end (encoder.py:186-272); constructor order as the reference."""
+
+    def __init__(self, fft_length: int = 512, win_type: str = "hann", win_length: int = 512, freq_bins: int = None,
+                 hop_length: int = 128, freq_scale: str = "no", fmin: int = 0, fmax: int = 8000, sr: int = 16000,
+                 trainable: bool = True, output_format: str = "Magnitude", n_banks=80):
+        super().__init__()
+        self.n_fft, self.win_length, self.freq_bins, self.hop_length = fft_length, win_length, freq_bins, hop_length
+        self.freq_scale, self.iSTFT, self.fmin, self.fmax, self.sr = freq_scale, False, fmin, fmax, sr
+        self.trainable, self.output_format, self.n_banks = trainable, output_format, n_banks
+        if win_type.lower() != "hann":
+            raise NotImplementedError("window type not support")
+        self.window = torch.hann_window(self.win_length)
+        self.encoder = ConvMelSpectrogram(self.window, n_fft=self.n_fft, win_length=self.win_length,
+                                          freq_scale=self.freq_scale, iSTFT=self.iSTFT, sr=self.sr, fmin=self.fmin,
+                                          fmax=self.fmax, output_format=self.output_format, trainable=self.trainable,
+                                          hop_length=self.hop_length, n_banks=self.n_banks)
+
+    def encode_padded(self, x: torch.Tensor):
+        return self.encoder.encode_padded(x)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """[N, L] -> [N, n_banks, T]."""
+        return self.encoder(x.unsqueeze(1))
+
+    def inverse(self, magphase: torch.Tensor) -> torch.Tensor:
+        return self.encoder.inverse(magphase[..., 0], magphase[..., 1])

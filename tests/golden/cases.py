@@ -87,6 +87,16 @@ CASES = {
                             dconv_norm="gGN", causal=False)),
         speaker_net=dict(n_tcn=5, C=256, H=128, att=128, E=192, block="gated", magnitude=True),
         wrap=dict(mask_constraint="linear", drop_first_bin=True), B=2, L=4000, L_enroll=3000, seed=1234),
+    # tse_skim_v2_causal (egs/tse/model.py:509-558) WITHOUT its SpecAugment layer, which draws random masks even in
+    # eval mode (lobe/trivial.py:326-335) and so has no reproducible output: FbankEnc enrolment encoder + TCN speaker net
+    "tse_skim_fbank_short": dict(
+        kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
+        enc_spk=dict(kw=dict(trainable=False, output_format="Magnitude", n_banks=80)),
+        masker=dict(cls="SkiM", args=(128, 256, 128),
+                    kw=dict(n_blocks=4, seg_size=150, seg_overlap=False, causal=True, embed_dim=192, embed_norm=True,
+                            block_with_embed=[1, 1, 1, 1], embed_fusion="FiLM")),
+        speaker_net=dict(n_tcn=5, C=80, H=256, att=128, E=192),
+        wrap=dict(mask_constraint="ReLU"), B=2, L=4000, L_enroll=3000, seed=1234),
     "tse_skim_causal_short": dict(
         kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
         masker=dict(cls="SkiM", args=(128, 256, 128),
@@ -221,6 +231,10 @@ CASES = {
     "enc_free": dict(kind="encdec", enc=dict(kind="free", win=32, hop=16, C=20), B=3, L=500, seed=16),
     "enc_free_relu_ragged": dict(kind="encdec", enc=dict(kind="free", win=20, hop=6, C=9, relu=True),
                                  B=2, L=211, seed=17),
+    "enc_fbank": dict(kind="fbank", kw=dict(fft_length=64, win_length=64, hop_length=16, trainable=False,
+                                            output_format="Magnitude", n_banks=12), B=2, L=500, seed=19),
+    "enc_fbank_trainable": dict(kind="fbank", kw=dict(fft_length=128, win_length=128, hop_length=32, trainable=True,
+                                                      output_format="Magnitude", n_banks=20), B=2, L=700, seed=20),
     "enc_stft": dict(kind="encdec", enc=dict(kind="stft", n_fft=64, hop=16, drop_first_bin=False),
                      B=2, L=400, seed=18),
 }
@@ -267,6 +281,8 @@ def build(ns, name):
         kw = dict(c["wrap"])
         if "speaker_net" in c:
             kw["speaker_net"] = build_speaker_net(ns, c["speaker_net"])
+        if "enc_spk" in c:
+            kw["encoder_spk"] = ns.FbankEnc(**c["enc_spk"]["kw"])
         return ns.SoTaskWrapModule(encoder=build_encoder(ns, c["enc"]), masker=build_masker(ns, c["masker"]),
                                    verbose=False, **kw)
     if c["kind"] == "masker":
@@ -277,6 +293,8 @@ def build(ns, name):
         return getattr(ns, c["cls"])(*c["args"], **c["kw"])
     if c["kind"] == "unet":
         return getattr(ns, c["cls"])(**c["kw"])
+    if c["kind"] == "fbank":
+        return ns.FbankEnc(**c["kw"])
     if c["kind"] == "stream":
         return ns.StreamingSkiM(*c["args"], **c["kw"])
     raise KeyError(c["kind"])
@@ -322,6 +340,9 @@ def oracle_cfg(name):
     else:
         cfg = dict(encoder=enc, masker=full_masker_args(c["masker"]))
     cfg.update({k: v for k, v in c["wrap"].items() if k not in ("drop_first_bin", "embedding_free_tse")})
+    if "enc_spk" in c:
+        cfg["encoder_spk"] = dict(hop=c["enc_spk"]["kw"].get("hop_length", 128),
+                                  trainable=c["enc_spk"]["kw"].get("trainable", True))
     if "speaker_net" in c:
         cfg["speaker_net"] = {k: v for k, v in c["speaker_net"].items() if k in ("n_tcn", "block", "magnitude")}
     return cfg

@@ -31,7 +31,7 @@ if "torchaudio" not in sys.modules:
 
 from puresound.nnet.base_nn import SoTaskWrapModule  # noqa: E402
 from puresound.nnet.conv_tasnet import TCN, ConvTasNet, GatedTCN  # noqa: E402
-from puresound.nnet.lobe.encoder import ConvEncDec, FreeEncDec  # noqa: E402
+from puresound.nnet.lobe.encoder import ConvEncDec, FbankEnc, FreeEncDec  # noqa: E402
 from puresound.nnet.lobe.pooling import AttentiveStatisticsPooling  # noqa: E402
 from puresound.nnet.dprnn import DPRNN  # noqa: E402
 from puresound.nnet.skim import SkiM  # noqa: E402
@@ -47,7 +47,7 @@ REF = cases.namespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=Con
                       ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                       AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM,
                       StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN,
-                      Magnitude=Magnitude)
+                      Magnitude=Magnitude, FbankEnc=FbankEnc)
 
 
 def sub(x: torch.Tensor, cs: int = 7, ts: int = 5) -> np.ndarray:
@@ -68,6 +68,8 @@ def run_wrap(name, c):
     # step through the same reference methods to capture taps (base_nn.py:690-722)
     feats, enr = model._get_feature(noisy.clone(), None if enroll is None else enroll.clone())
     dvec = None
+    if enr is not None and model.encoder_spk is not None and hasattr(model.encoder_spk, "n_banks"):
+        pass  # _get_feature already ran the FbankEnc
     if enr is not None and model.embedding_free_tse:
         dvec = enr
     elif enr is not None:
@@ -125,6 +127,14 @@ def run_encdec(name, c):
     feats = model(wav.clone())
     rec = model.inverse(feats.clone())
     return {"feats": feats.numpy(), "rec": rec.numpy()}
+
+
+@torch.no_grad()
+def run_fbank(name, c):
+    model = cases.build(REF, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    wav = det_wave(c["seed"], c["B"], c["L"])
+    return {"feats": model(wav.clone()).numpy()}
 
 
 def _uniform(seed, shape, lo=-1.0, hi=1.0):
@@ -231,7 +241,7 @@ def main():
     dump_state_dict_keys()
     for name, c in cases.CASES.items():
         fn = {"wrap": run_wrap, "masker": run_masker, "encdec": run_encdec, "rnn": run_rnn,
-              "stream": run_stream, "unet": run_unet}[c["kind"]]
+              "stream": run_stream, "unet": run_unet, "fbank": run_fbank}[c["kind"]]
         if only and name not in only:
             continue
         out = fn(name, c)

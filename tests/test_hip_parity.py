@@ -920,7 +920,8 @@ def test_ns_dpcrn_preset_matches_reference_golden(PA, dev, golden_dir):
     assert rel_max(out.cpu().numpy()[:, sl], ref.numpy()[:, sl]) < TOL
 
 
-@pytest.mark.parametrize("name", ["tse_unet_tcn_causal_short", "tse_unet_tcn_short", "tse_skim_causal_short"])
+@pytest.mark.parametrize("name", ["tse_unet_tcn_causal_short", "tse_unet_tcn_short", "tse_skim_causal_short",
+                                  "tse_skim_fbank_short"])
 def test_more_tse_presets_match_reference_golden(PA, dev, golden_dir, name):
     """egs/tse presets verbatim: tse_unet_tcn_v0_causal (STFT + UnetTcn with causal gated bN1d TCN + speaker net
     Magnitude -> 5 x GatedTCN -> ASP -> 1x1, real mask on the STFT) and tse_skim_v0_causal (FreeEncDec + SkiM/FiLM +
@@ -943,3 +944,16 @@ def test_more_tse_presets_match_reference_golden(PA, dev, golden_dir, name):
     edge = 16 if c["enc"]["kind"] == "stft" else 0
     sl = slice(edge, wav.shape[1] - edge) if edge else slice(None)
     assert rel_max(wav.cpu().numpy()[:, sl], g["wav"][:, sl]) < TOL
+
+
+@pytest.mark.parametrize("name", [n for n, c in cases.CASES.items() if c["kind"] == "fbank"])
+def test_fbank_encoder_matches_reference_golden(PA, dev, golden_dir, name):
+    """FbankEnc / ConvMelSpectrogram: conv-STFT -> power -> mel projection."""
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    y = model(det_wave(c["seed"], c["B"], c["L"]).to(dev))
+    assert y.shape == g["feats"].shape
+    assert rel_max(y.cpu().numpy(), g["feats"]) < TOL

@@ -221,3 +221,14 @@ def test_unet_family_matches_reference(golden_dir, name):
         y = {"unet": UO.unet, "dpcrn": UO.dpcrn}[c["oracle"]](x, sd, "", args)
     assert y.shape == g["y"].shape
     assert rel_max(y.numpy(), g["y"]) < TOL
+
+
+@pytest.mark.parametrize("name", [n for n, c in cases.CASES.items() if c["kind"] == "fbank"])
+def test_fbank_encoder_matches_reference(golden_dir, name):
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    sd = _sd(name)
+    wav = det_wave(c["seed"], c["B"], c["L"])
+    y = O.fbank_encode(wav, sd, "encoder.", c["kw"]["hop_length"], c["kw"]["trainable"])
+    assert y.shape == g["feats"].shape
+    assert rel_max(y.numpy(), g["feats"]) < TOL
