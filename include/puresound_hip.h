@@ -54,7 +54,7 @@ const char* ps_last_error(void);
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
  * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product", "segment_overlap",
- * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "conv1x1_bf16", "unfold2d", "activation", "add", "magnitude", "real_mask", "norm_activation",
+ * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "conv1x1_bf16", "unfold2d", "activation", "add", "magnitude", "real_mask", "norm_activation", "self_attention", "add_position",
  * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
@@ -246,6 +246,19 @@ int ps_norm_activation_f32(float* x, const ps_prologue* pro, double corr_sum, do
 int ps_add_f32(const float* a, const float* b, float* y, int64_t count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Self-attention of the DPARN bottleneck (MhaSelfAttenLayer / nn.MultiheadAttention(bias=False), lobe/attention.py:38-232;
+ * dparn.py:55-80).  qkv [N][3E][ld] = in_proj_weight applied by ps_conv1x1_f32 (q rows | k rows | v rows, head h = rows
+ * h*dh..).  A sequence is (n, q), q < Q; its position p sits at frame q*q_stride + p*pos_stride (DPARN: q = frame t,
+ * positions = the F frequency rows, pos_stride = ld).  out [N][E][ld] = concat_h softmax(q k^T / sqrt(dh)) v; causal = 1
+ * restricts keys to positions <= the query's.  ps_add_position_f32 adds the sinusoidal table pe [L][E]
+ * (PositionalEncoding, lobe/attention.py:8-35) to every sequence.
+ * ------------------------------------------------------------------------------------------- */
+int ps_self_attention_f32(const float* qkv, float* out, int N, int E, int heads, int Q, int q_stride, int L,
+                          int pos_stride, int ld, int causal, void* stream);
+int ps_add_position_f32(const float* x, const float* pe, float* y, int N, int E, int Q, int q_stride, int L,
+                        int pos_stride, int ld, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Recurrent maskers (DPRNN dprnn.py:111-191, SkiM skim.py:198-229,45-114,410-469, StreamingSkiM
  * streaming/skim_inference.py:41-252).  They run on the same channel-major padded layout, so their Linear layers
  * (LSTM input projections, proj, FiLM convs, output_fc) are ps_conv1x1_f32 calls; what is left is below.
@@ -296,14 +309,15 @@ int ps_segment_overlap_f32(const float* src, float* dst, int64_t rows, int T_src
  *   c [N][H][ld_state] is updated in place, h' goes to h [N][H][ld_state], which must NOT alias the h rows of xh.
  * ps_proj_layernorm_f32: y = res + LN(W x + b; gamma, beta, eps) (skim.py:223-227), optionally also
  *   y2 = LN(y; gamma2, beta2, eps2) (the next block's FiLM input norm) and x_copy = x (hands h' back to the xh block).
- *   M <= 256. */
+ *   res_inside = 1 moves the residual inside the norm: y = LN(W x + b + res) (the post-norm transformer layer of
+ *   lobe/attention.py:211-226).  M <= 256. */
 int ps_film_conv_f32(const float* x, const float* wt_pairs, const float* res_pairs, float* y, int N, int C, int T,
                      int ldt, void* stream);
 int ps_lstm_gates_cell_f32(const float* xh, const float* wt_units, const float* bias_units, float* c, float* h, int N,
                            int K, int H, int T, int ldt, int ld_state, void* stream);
 int ps_proj_layernorm_f32(const float* x, const float* wt, const float* bias, const float* gamma, const float* beta,
                           float eps, const float* res, float* y, const float* gamma2, const float* beta2, float eps2,
-                          float* y2, float* x_copy, int N, int K, int M, int T, int ldt, void* stream);
+                          float* y2, float* x_copy, int res_inside, int N, int K, int M, int T, int ldt, void* stream);
 
 /* Streaming harness overlap-add (egs/tse/demo/utils.py:121-128): out[b][j] = (tail[b][j] + cur[b][j]) / 2 for
  * j < overlap (tail = the last `overlap` samples of the running output, row stride ld_tail), cur[b][j] otherwise. */

@@ -444,7 +444,7 @@ def inference(noisy: torch.Tensor, sd: SD, cfg: dict, enroll: Optional[torch.Ten
             if kind == "unet_tcn":
                 mask = UO.unet_tcn(feats, sd, "masker.", cfg["masker"], dvec)
             else:
-                mask = {"unet": UO.unet, "dpcrn": UO.dpcrn}[kind](feats, sd, "masker.", cfg["masker"])
+                mask = {"unet": UO.unet, "dpcrn": UO.dpcrn, "dparn": UO.dparn}[kind](feats, sd, "masker.", cfg["masker"])
     mask = get_mask(mask, cfg.get("mask_constraint", "linear"))
     enh = apply_tf_masks(feats, mask, cfg.get("mask_type", "real"), cfg.get("f_type", "real"))
     wav = decode_waveform(enh, sd, cfg["encoder"])

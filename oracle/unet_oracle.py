@@ -216,3 +216,74 @@ def dpcrn(x: torch.Tensor, sd: SD, p: str, args: dict) -> torch.Tensor:
     y = dprnn_block2d(skip[-1], sd, p + "dprnn_block1.")
     y = dprnn_block2d(y, sd, p + "dprnn_block2.")
     return unet_up(y, skip, sd, p, args)
+
+
+# ---------------------------------------------------------------------------
+# DPARN (dparn.py:12-247, lobe/attention.py:8-232)
+# ---------------------------------------------------------------------------
+def positional_table(length: int, d_model: int, dtype=torch.float32) -> torch.Tensor:
+    """PositionalEncoding.pe[:length, 0] (lobe/attention.py:17-24): sin on even, cos on odd feature indices."""
+    import math
+    pos = torch.arange(length, dtype=torch.float64).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float64) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(length, d_model, dtype=torch.float64)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.to(dtype)
+
+
+def multihead_attention(x: torch.Tensor, w_in: torch.Tensor, w_out: torch.Tensor, heads: int, causal: bool = False):
+    """nn.MultiheadAttention(E, heads, bias=False, batch_first=True) self-attention on x [B, L, E]
+    (lobe/attention.py:38-112): q,k,v = x W_in^T split in three, per head softmax(q k^T / sqrt(dh)) v, then W_out."""
+    b, l, e = x.shape
+    dh = e // heads
+    qkv = linear(x, w_in)
+    q, k, v = [t.reshape(b, l, heads, dh).transpose(1, 2) for t in qkv.split(e, dim=-1)]   # [B, h, L, dh]
+    s = torch.matmul(q, k.transpose(-1, -2)) / (dh ** 0.5)
+    if causal:
+        s = s + torch.triu(torch.full((l, l), float("-inf"), dtype=x.dtype), diagonal=1)
+    p = torch.softmax(s, dim=-1)
+    o = torch.matmul(p, v).transpose(1, 2).reshape(b, l, e)
+    return linear(o, w_out)
+
+
+def mha_self_atten_layer(x: torch.Tensor, sd: SD, p: str, heads: int, position_encoding: bool,
+                         causal: bool = False) -> torch.Tensor:
+    """MhaSelfAttenLayer.forward, improved=False (lobe/attention.py:180-232): x [B, C, L] -> [B, C, L]."""
+    y = x.transpose(1, 2)
+    src = y
+    if position_encoding:
+        # `pe` is a persistent buffer of the reference (it travels in checkpoints); its values are positional_table()
+        y = y + sd[p + "pos.pe"][:y.shape[1], 0].to(y.dtype).unsqueeze(0)
+    a = multihead_attention(y, sd[p + "self_atten.atten.in_proj_weight"], sd[p + "self_atten.atten.out_proj.weight"],
+                            heads, causal)
+    y = layer_norm(src + a, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+    ff = linear(torch.relu(linear(y, sd[p + "feedforward.0.weight"], sd[p + "feedforward.0.bias"])),
+                sd[p + "feedforward.3.weight"], sd[p + "feedforward.3.bias"])
+    return layer_norm(y + ff, sd[p + "norm2.weight"], sd[p + "norm2.bias"]).transpose(1, 2)
+
+
+def dparn_block2d(x: torch.Tensor, sd: SD, p: str, heads: int) -> torch.Tensor:
+    """DPARNblock2D.forward (dparn.py:55-108): two self-attention layers along frequency per frame, Linear,
+    LayerNorm, skip; then the unidirectional LSTM along time of the DPCRN block."""
+    n, ch, c, t = x.shape
+    y = x.transpose(1, -1).reshape(n * t, c, ch).permute(0, 2, 1)       # [N*T, CH, C]
+    y = mha_self_atten_layer(y, sd, p + "intra_atten1.", heads, True)
+    y = mha_self_atten_layer(y, sd, p + "intra_atten2.", heads, False)
+    y = linear(y.permute(0, 2, 1), sd[p + "intra_fc.weight"], sd[p + "intra_fc.bias"])
+    y = layer_norm(y, sd[p + "intra_norm.weight"], sd[p + "intra_norm.bias"])
+    x = x + y.reshape(n, t, c, ch).transpose(1, -1)
+    y = x.permute(0, 2, 3, 1).reshape(n * c, t, ch)
+    y = single_rnn(y.permute(0, 2, 1), sd, p + "inter_rnn.", False).permute(0, 2, 1)
+    y = layer_norm(y, sd[p + "inter_norm.weight"], sd[p + "inter_norm.bias"])
+    return x + y.permute(0, 2, 1).reshape(n, c, ch, t).permute(0, 2, 1, 3)
+
+
+def dparn(x: torch.Tensor, sd: SD, p: str, args: dict) -> torch.Tensor:
+    """DPARN.forward (dparn.py:170-226), spectral_compress=False."""
+    if args.get("spectral_compress", False):
+        raise NotImplementedError("spectral_compress")
+    skip = unet_down(x, sd, p, args)
+    y = dparn_block2d(skip[-1], sd, p + "dprnn_block1.", args["nhead"])
+    y = dparn_block2d(y, sd, p + "dprnn_block2.", args["nhead"])
+    return unet_up(y, skip, sd, p, args)

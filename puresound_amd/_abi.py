@@ -76,8 +76,10 @@ SIGNATURES = {
     "ps_segment_overlap_f32": (C.c_int, [_vp, _vp, C.c_int64] + [C.c_int] * 6 + [_vp]),
     "ps_film_conv_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
     "ps_lstm_gates_cell_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp] + [C.c_int] * 6 + [_vp]),
-    "ps_proj_layernorm_f32": (C.c_int, [_vp] * 5 + [C.c_float, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp] + [C.c_int] * 5
+    "ps_proj_layernorm_f32": (C.c_int, [_vp] * 5 + [C.c_float, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp] + [C.c_int] * 6
                               + [_vp]),
+    "ps_self_attention_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 9 + [_vp]),
+    "ps_add_position_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 7 + [_vp]),
     "ps_overlap_average_f32": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ps_unfold2d_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp] + [C.c_int] * 14 + [_vp]),
     "ps_activation_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int, _vp]),

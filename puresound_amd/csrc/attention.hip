@@ -1,0 +1,148 @@
+// Self-attention of the DPARN bottleneck (MhaSelfAttenLayer / nn.MultiheadAttention, lobe/attention.py:38-232 of
+// mcw519/PureSound) on the library's rows.  Q, K, V come from ONE ps_conv1x1_f32 over the in_proj weight as
+// [N][3E][ld'] rows (q rows, then k rows, then v rows; head h = rows h*dh .. h*dh+dh-1 of each third).  A sequence is the
+// same strided walk over the frame axis the LSTM kernel uses (frame = q*q_stride + pos*pos_stride): DPARN attends along
+// frequency for every frame, i.e. q = t, q_stride = 1, L = F positions, pos_stride = ld.
+//
+// One workgroup = one head of ATT_SQ consecutive sequences; thread (sequence, query position).  K and V of the head are
+// staged in LDS ([d][key][sequence]); a thread walks the keys in blocks with a running maximum / normaliser (online
+// softmax), so L is not bounded by registers.  Sequences are short here (L = 64, dh = 16) and the attention is < 1 % of
+// the block's FLOPs: the kernel is written for clarity, the GEMMs around it do the work.
+#include "ps_common.h"
+
+namespace ps {
+
+constexpr int ATT_SQ = 4;     // sequences per workgroup
+constexpr int ATT_MAXD = 64;  // head dimension
+constexpr int ATT_MAXL = 256; // positions (threads per sequence)
+
+struct AttArgs {
+  const float* qkv;
+  float* out;
+  int E, heads, Q, q_stride, L, pos_stride, ld, causal;
+  float scale;
+};
+
+__global__ __launch_bounds__(ATT_SQ * 64) void self_attention_kernel(AttArgs a) {
+  extern __shared__ float sm[];  // k[dh][L][SQ] | v[dh][L][SQ]
+  const int dh = a.E / a.heads;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int q0 = blockIdx.x * ATT_SQ;
+  const int lanes = blockDim.x / ATT_SQ;  // query positions handled per pass
+  float* ks = sm;
+  float* vs = sm + (size_t)dh * a.L * ATT_SQ;
+  const float* base = a.qkv + (size_t)n * 3 * a.E * a.ld;
+  // stage K and V of this head for the ATT_SQ sequences
+  for (int idx = threadIdx.x; idx < dh * a.L * ATT_SQ; idx += blockDim.x) {
+    const int s = idx % ATT_SQ, pos = (idx / ATT_SQ) % a.L, d = idx / (ATT_SQ * a.L);
+    const int q = q0 + s;
+    float kv = 0.f, vv = 0.f;
+    if (q < a.Q) {
+      const size_t fr = (size_t)q * a.q_stride + (size_t)pos * a.pos_stride;
+      kv = base[(size_t)(a.E + h * dh + d) * a.ld + fr];
+      vv = base[(size_t)(2 * a.E + h * dh + d) * a.ld + fr];
+    }
+    ks[idx] = kv;
+    vs[idx] = vv;
+  }
+  __syncthreads();
+  const int s = threadIdx.x % ATT_SQ;
+  const int q = q0 + s;
+  for (int i = threadIdx.x / ATT_SQ; i < a.L; i += lanes) {
+    if (q >= a.Q) continue;
+    const size_t fr = (size_t)q * a.q_stride + (size_t)i * a.pos_stride;
+    float qv[ATT_MAXD];
+#pragma unroll
+    for (int d = 0; d < ATT_MAXD; ++d) qv[d] = d < dh ? base[(size_t)(h * dh + d) * a.ld + fr] * a.scale : 0.f;
+    float m = -INFINITY, z = 0.f;
+    float o[ATT_MAXD];
+#pragma unroll
+    for (int d = 0; d < ATT_MAXD; ++d) o[d] = 0.f;
+    const int jend = a.causal ? i + 1 : a.L;
+    for (int j = 0; j < jend; ++j) {
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < ATT_MAXD; ++d)
+        if (d < dh) sc = fmaf(qv[d], ks[((size_t)d * a.L + j) * ATT_SQ + s], sc);
+      const float mn = fmaxf(m, sc);
+      const float corr = expf(m - mn), p = expf(sc - mn);
+      z = z * corr + p;
+#pragma unroll
+      for (int d = 0; d < ATT_MAXD; ++d)
+        if (d < dh) o[d] = o[d] * corr + p * vs[((size_t)d * a.L + j) * ATT_SQ + s];
+      m = mn;
+    }
+    const float rz = 1.f / z;
+    float* dst = a.out + (size_t)n * a.E * a.ld + fr;
+#pragma unroll
+    for (int d = 0; d < ATT_MAXD; ++d)
+      if (d < dh) dst[(size_t)(h * dh + d) * a.ld] = o[d] * rz;
+  }
+}
+
+// y[n][c][pos*pos_stride + q*q_stride] = x[...] + pe[pos][c]   (PositionalEncoding.forward, lobe/attention.py:27-35)
+__global__ __launch_bounds__(256) void add_position_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                           float* __restrict__ y, int E, int Q, int q_stride,
+                                                           int pos_stride, int ld) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int pos = blockIdx.y;
+  const int n = blockIdx.z / E, c = blockIdx.z % E;
+  if (q >= Q) return;
+  const size_t off = ((size_t)n * E + c) * ld + (size_t)pos * pos_stride + (size_t)q * q_stride;
+  y[off] = x[off] + pe[(size_t)pos * E + c];
+}
+
+}  // namespace ps
+
+using namespace ps;
+
+static int att_status(const char* who) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", who, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+extern "C" int ps_self_attention_f32(const float* qkv, float* out, int N, int E, int heads, int Q, int q_stride, int L,
+                                     int pos_stride, int ld, int causal, void* stream) {
+  if (!qkv || !out || N <= 0 || E <= 0 || heads <= 0 || E % heads || Q <= 0 || L <= 0 || q_stride < 0 ||
+      pos_stride < 0 || ld <= 0 || N > 65535 || heads > 65535) {
+    set_error("ps_self_attention_f32: bad argument (N=%d E=%d heads=%d Q=%d L=%d)", N, E, heads, Q, L);
+    return PS_E_INVALID;
+  }
+  const int dh = E / heads;
+  const size_t lds = (size_t)2 * dh * L * ATT_SQ * sizeof(float);
+  if (dh > ATT_MAXD || lds > 64 * 1024) {
+    set_error("ps_self_attention_f32: head_dim %d (max %d) or K/V stage of %zu bytes (max 64 KiB) not supported", dh,
+              ATT_MAXD, lds);
+    return PS_E_UNSUPPORTED;
+  }
+  if ((long long)(Q - 1) * q_stride + (long long)(L - 1) * pos_stride >= ld) {
+    set_error("ps_self_attention_f32: the last frame lies outside the row (ld=%d)", ld);
+    return PS_E_INVALID;
+  }
+  AttArgs a{qkv, out, E, heads, Q, q_stride, L, pos_stride, ld, causal, 1.f / sqrtf((float)dh)};
+  {
+    LaunchTimer timer("self_attention", (hipStream_t)stream);
+    hipLaunchKernelGGL(self_attention_kernel, dim3((Q + ATT_SQ - 1) / ATT_SQ, heads, N), dim3(ATT_SQ * 64), lds,
+                       (hipStream_t)stream, a);
+  }
+  return att_status("ps_self_attention_f32");
+}
+
+extern "C" int ps_add_position_f32(const float* x, const float* pe, float* y, int N, int E, int Q, int q_stride, int L,
+                                   int pos_stride, int ld, void* stream) {
+  if (!x || !pe || !y || N <= 0 || E <= 0 || Q <= 0 || L <= 0 || L > 65535 || (long long)N * E > 65535 ||
+      (long long)(Q - 1) * q_stride + (long long)(L - 1) * pos_stride >= ld) {
+    set_error("ps_add_position_f32: bad argument (N=%d E=%d Q=%d L=%d ld=%d)", N, E, Q, L, ld);
+    return PS_E_INVALID;
+  }
+  {
+    LaunchTimer timer("add_position", (hipStream_t)stream);
+    hipLaunchKernelGGL(add_position_kernel, dim3((Q + 255) / 256, L, N * E), dim3(256), 0, (hipStream_t)stream, x, pe, y,
+                       E, Q, q_stride, pos_stride, ld);
+  }
+  return att_status("ps_add_position_f32");
+}

@@ -186,6 +186,7 @@ struct ProjLnArgs {
   const float* beta2;
   float* y2;
   float* x_copy;  // optional: the input rows are also written here (same layout), frames [0, T)
+  int res_inside;  // 0: y = res + LN(W x + b)   1: y = LN(W x + b + res)  (post-norm transformer blocks)
   float eps, eps2;
   int K, Kp, M, T, ldt;
 };
@@ -238,7 +239,11 @@ __global__ __launch_bounds__(256) void proj_layernorm_kernel(ProjLnArgs a) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int m = j * 16 + 4 * (ln >> 4) + reg;
-      if (m < a.M) tile[m][ln & 15] = s[reg] + (a.bias ? a.bias[m] : 0.f);
+      if (m < a.M) {
+        float v = s[reg] + (a.bias ? a.bias[m] : 0.f);
+        if (a.res_inside && a.res && t0 + (ln & 15) < a.T) v += a.res[((size_t)n * a.M + m) * a.ldt + t0 + (ln & 15)];
+        tile[m][ln & 15] = v;
+      }
     }
   }
   __syncthreads();
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(256) void proj_layernorm_kernel(ProjLnArgs a) {
   for (int m = cp; m < a.M; m += 16) {
     float v = (tile[m][f] - mean) * rstd * a.gamma[m] + a.beta[m];
     const size_t off = ((size_t)n * a.M + m) * a.ldt + t;
-    if (a.res && t < a.T) v += a.res[off];
+    if (!a.res_inside && a.res && t < a.T) v += a.res[off];
     if (t < a.T) a.y[off] = v;
     tile[m][f] = v;
   }
@@ -403,8 +408,8 @@ extern "C" int ps_lstm_gates_cell_f32(const float* xh, const float* wt_units, co
 
 extern "C" int ps_proj_layernorm_f32(const float* x, const float* wt, const float* bias, const float* gamma,
                                      const float* beta, float eps, const float* res, float* y, const float* gamma2,
-                                     const float* beta2, float eps2, float* y2, float* x_copy, int N, int K, int M,
-                                     int T, int ldt, void* stream) {
+                                     const float* beta2, float eps2, float* y2, float* x_copy, int res_inside, int N,
+                                     int K, int M, int T, int ldt, void* stream) {
   if (!x || !wt || !gamma || !beta || !y || N <= 0 || K <= 0 || M <= 0 || T <= 0 || ldt < T || N > 65535 ||
       (y2 && (!gamma2 || !beta2))) {
     set_error("ps_proj_layernorm_f32: bad argument (N=%d K=%d M=%d T=%d)", N, K, M, T);
@@ -414,7 +419,7 @@ extern "C" int ps_proj_layernorm_f32(const float* x, const float* wt, const floa
     set_error("ps_proj_layernorm_f32: M=%d > %d output channels", M, PLN_MAXM);
     return PS_E_UNSUPPORTED;
   }
-  ProjLnArgs a{x, wt, bias, gamma, beta, res, y, gamma2, beta2, y2, x_copy, eps, eps2, K, (K + 15) / 16 * 16, M, T, ldt};
+  ProjLnArgs a{x, wt, bias, gamma, beta, res, y, gamma2, beta2, y2, x_copy, res_inside, eps, eps2, K, (K + 15) / 16 * 16, M, T, ldt};
   {
     LaunchTimer timer("proj_layernorm", (hipStream_t)stream);
     if (M <= 128)

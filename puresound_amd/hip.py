@@ -337,15 +337,15 @@ def lstm_gates_cell(xh: torch.Tensor, t: int, wt_units: torch.Tensor, bias_units
 
 def proj_layernorm(x: torch.Tensor, t: int, wt: torch.Tensor, bias: Optional[torch.Tensor], m: int,
                    gamma: torch.Tensor, beta: torch.Tensor, eps: float, res: Optional[torch.Tensor],
-                   norm2: Optional[tuple] = None, x_copy: Optional[torch.Tensor] = None):
-    """y = res + LN(W x + b) (+ y2 = LN2(y), + copy of x); returns (y, y2)."""
+                   norm2: Optional[tuple] = None, x_copy: Optional[torch.Tensor] = None, res_inside: bool = False):
+    """y = res + LN(W x + b), or LN(W x + b + res) with res_inside (+ y2 = LN2(y), + copy of x); returns (y, y2)."""
     require_device(x, "proj_layernorm")
     n, k, ldt = x.shape
     y = torch.empty(n, m, ldt, dtype=torch.float32, device=x.device)
     y2 = torch.empty_like(y) if norm2 is not None else None
     g2, b2, e2 = norm2 if norm2 is not None else (None, None, 0.0)
     check(lib().ps_proj_layernorm_f32(ptr(x), ptr(wt), ptr(bias), ptr(gamma), ptr(beta), float(eps), ptr(res), ptr(y),
-                                      ptr(g2), ptr(b2), float(e2), ptr(y2), ptr(x_copy), n, k, m, t, ldt,
+                                      ptr(g2), ptr(b2), float(e2), ptr(y2), ptr(x_copy), int(res_inside), n, k, m, t, ldt,
                                       stream_ptr(x.device)), "ps_proj_layernorm_f32")
     return y, y2
 
@@ -433,6 +433,29 @@ def add_(dst: torch.Tensor, other: torch.Tensor) -> torch.Tensor:
         raise RuntimeError("add_: contiguous tensors of one shape")
     check(lib().ps_add_f32(ptr(dst), ptr(other), ptr(dst), dst.numel(), stream_ptr(dst.device)), "ps_add_f32")
     return dst
+
+
+def self_attention(qkv: torch.Tensor, e: int, heads: int, q: int, q_stride: int, length: int, pos_stride: int,
+                   causal: bool = False) -> torch.Tensor:
+    """qkv padded [N,3E,ld] -> attention output [N,E,ld] (sequence (n,q): positions at q*q_stride + p*pos_stride)."""
+    require_device(qkv, "self_attention")
+    n, rows, ld = qkv.shape
+    if rows != 3 * e:
+        raise RuntimeError("self_attention: qkv must be [N, 3E, ld]")
+    out = torch.empty(n, e, ld, dtype=torch.float32, device=qkv.device)
+    check(lib().ps_self_attention_f32(ptr(qkv), ptr(out), n, e, heads, q, q_stride, length, pos_stride, ld, int(causal),
+                                      stream_ptr(qkv.device)), "ps_self_attention_f32")
+    return out
+
+
+def add_position(x: torch.Tensor, pe: torch.Tensor, q: int, q_stride: int, length: int, pos_stride: int) -> torch.Tensor:
+    """x padded [N,E,ld] + pe[pos][c] at every sequence position."""
+    require_device(x, "add_position")
+    n, e, ld = x.shape
+    y = x.clone()
+    check(lib().ps_add_position_f32(ptr(x), ptr(pe), ptr(y), n, e, q, q_stride, length, pos_stride, ld,
+                                    stream_ptr(x.device)), "ps_add_position_f32")
+    return y
 
 
 def lstm_cell(gates: torch.Tensor, c: torch.Tensor, h: torch.Tensor, hidden: int, dirs: int, t: int) -> None:

@@ -10,6 +10,8 @@ from .lobe.trivial import FiLM, Gate, Magnitude
 from .skim import MemLSTM, SegLSTM, SkiM
 from .unet import Unet, UnetTcn
 from .dpcrn import DPCRN, DPRNNblock2D
+from .dparn import DPARN, DPARNblock2D
+from .lobe.attention import MhaSelfAttenLayer
 
 # the class namespace the parity tests hand to tests/golden/cases.build()
 class _Namespace(SimpleNamespace):
@@ -23,4 +25,5 @@ class _Namespace(SimpleNamespace):
 NS = _Namespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                      ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                      AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM, MemLSTM=MemLSTM, Unet=Unet, UnetTcn=UnetTcn,
-                DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, Magnitude=Magnitude, FbankEnc=FbankEnc, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate)
+                DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, DPARN=DPARN, DPARNblock2D=DPARNblock2D,
+                MhaSelfAttenLayer=MhaSelfAttenLayer, Magnitude=Magnitude, FbankEnc=FbankEnc, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate)

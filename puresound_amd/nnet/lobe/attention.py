@@ -1,0 +1,123 @@
+"""Attention lobes (mirror of puresound/nnet/lobe/attention.py:8-232): parameter trees under the reference's keys and
+the HIP driver of the post-norm transformer layer used by DPARN (improved=False):
+
+    [x + pe] -> in_proj GEMM -> ps_self_attention_f32 -> out_proj + residual + LayerNorm (one kernel)
+             -> Linear + ReLU + Linear + residual (two GEMMs, the ReLU is the second one's prologue) -> LayerNorm
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ... import hip
+from .._plans import PlanCache, _f32, layernorm_plan, linear_plan
+
+
+class PositionalEncoding(nn.Module):
+    """lobe/attention.py:8-35; `pe` [max_len, 1, d_model] is a persistent buffer (it is in the checkpoints)."""
+
+    def __init__(self, d_model: int, dropout: float = 0.1, max_len: int = 5000):
+        super().__init__()
+        if d_model % 2 != 0:
+            raise ValueError(f"Cannot use sin/cos positional encoding with odd dim (got dim={d_model})")
+        self.dropout = nn.Dropout(p=dropout)
+        position = torch.arange(max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(max_len, 1, d_model)
+        pe[:, 0, 0::2] = torch.sin(position * div_term)
+        pe[:, 0, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError("PositionalEncoding is applied by ps_add_position_f32 inside MhaSelfAttenLayer")
+
+
+class MHA(nn.Module):
+    """lobe/attention.py:38-112: holds nn.MultiheadAttention(bias=False, batch_first=True)."""
+
+    def __init__(self, embed_dim: int, heads: int = 1):
+        super().__init__()
+        self.atten = nn.MultiheadAttention(embed_dim=embed_dim, num_heads=heads, dropout=0, batch_first=True,
+                                           bias=False)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("MHA runs inside MhaSelfAttenLayer on the HIP path")
+
+
+class MhaSelfAttenLayer(PlanCache, nn.Module):
+    """Transformer encoder block (lobe/attention.py:115-232)."""
+
+    def __init__(self, feats_dim: int, hidden_dim: int, nhead: int, dropout: float = 0.0, improved: bool = False,
+                 bidirectional: bool = False, position_encoding: bool = True):
+        super().__init__()
+        self.improved = improved
+        self.bidirectional = bidirectional
+        self.position_encoding = position_encoding
+        self.feats_dim, self.nhead = feats_dim, nhead
+        self.self_atten = MHA(feats_dim, heads=nhead)
+        self.self_atten_dropout = nn.Dropout(p=dropout)
+        self.norm1 = nn.LayerNorm(feats_dim)
+        if not improved:
+            if self.bidirectional:
+                print("Ignored bidirectional option since no LSTM here.")
+            if position_encoding:
+                self.pos = PositionalEncoding(d_model=feats_dim, dropout=dropout)
+            self.feedforward = nn.Sequential(nn.Linear(feats_dim, hidden_dim), nn.ReLU(), nn.Dropout(p=dropout),
+                                             nn.Linear(hidden_dim, feats_dim), nn.Dropout(p=dropout))
+        else:
+            if position_encoding:
+                print("Ignored position_encoding option here replaced by LSTM modeling.")
+            self.recurrent = nn.LSTM(feats_dim, hidden_dim, bidirectional=bidirectional, batch_first=True)
+            if bidirectional:
+                hidden_dim *= 2
+            self.feedforward = nn.Sequential(nn.ReLU(), nn.Dropout(p=dropout), nn.Linear(hidden_dim, feats_dim),
+                                             nn.Dropout(p=dropout))
+        self.norm2 = nn.LayerNorm(feats_dim)
+
+    def _build(self, device):
+        if self.improved:
+            raise NotImplementedError("MhaSelfAttenLayer(improved=True) (LSTM feed-forward) is not on the HIP path")
+        if self.training and (self.self_atten_dropout.p > 0 or self.feedforward[2].p > 0):
+            raise RuntimeError("MhaSelfAttenLayer: dropout is active; the HIP path is inference only -- call .eval()")
+        at = self.self_atten.atten
+        p = dict(w_in=hip.pack_wt(_f32(at.in_proj_weight, device)),
+                 out=dict(wt=hip.pack_wt(_f32(at.out_proj.weight, device)), M=self.feats_dim),
+                 norm1=layernorm_plan(self.norm1, device), ff1=linear_plan(self.feedforward[0], device),
+                 ff2=linear_plan(self.feedforward[3], device), norm2=layernorm_plan(self.norm2, device))
+        if self.position_encoding:
+            p["pe"] = _f32(self.pos.pe[:, 0, :], device)            # [max_len, E]
+        return p
+
+    def forward_padded(self, x: torch.Tensor, frames: int, q: int, q_stride: int, length: int, pos_stride: int,
+                       causal: bool = False) -> torch.Tensor:
+        """x padded [N, E, ld]: sequences (n, q) with `length` positions at q*q_stride + p*pos_stride."""
+        p = self._plan_get(x.device, self._build)
+        n, e, ld = x.shape
+        new = lambda rows: torch.empty(n, rows, ld, dtype=torch.float32, device=x.device)  # noqa: E731
+        src = x
+        if self.position_encoding:
+            if length > p["pe"].shape[0]:
+                raise RuntimeError("sequence longer than the positional table")
+            x = hip.add_position(x, p["pe"], q, q_stride, length, pos_stride)
+        qkv, _ = hip.conv1x1(x, frames, p["w_in"], 3 * e, out=new(3 * e))
+        att = hip.self_attention(qkv, e, self.nhead, q, q_stride, length, pos_stride, causal)
+        n1 = p["norm1"]
+        y, _ = hip.proj_layernorm(att, frames, p["out"]["wt"], None, e, n1["gamma"], n1["beta"], n1["eps"], src,
+                                  res_inside=True)
+        h, _ = hip.conv1x1(y, frames, p["ff1"]["wt"], p["ff1"]["M"], None, p["ff1"]["bias"], out=new(p["ff1"]["M"]))
+        n2 = p["norm2"]
+        pro = hip.make_prologue(0, False, None, 0.0, 0.0, None, None, None, pre_relu=True)
+        s, _ = hip.conv1x1(h, frames, p["ff2"]["wt"], e, pro, p["ff2"]["bias"], res=y, out=new(e))
+        return hip.chan_layernorm(s, frames, n2["gamma"], n2["beta"], n2["eps"])
+
+    def forward(self, x: torch.Tensor, causal: bool = False, context_range: Optional[int] = None,
+                return_atten_weight: bool = False):
+        """x [N, C, T] -> [N, C, T] (lobe/attention.py:180-232)."""
+        hip.require_device(x, "MhaSelfAttenLayer.forward")
+        if context_range is not None or return_atten_weight:
+            raise NotImplementedError("MhaSelfAttenLayer on HIP: context_range / return_atten_weight")
+        t = x.shape[-1]
+        xp = hip.pad_rows(x)
+        # every batch entry is one sequence over its t frames
+        return hip.unpad_rows(self.forward_padded(xp, t, 1, 0, t, 1, causal), t)

@@ -104,6 +104,18 @@ CASES = {
                             block_with_embed=[1, 1, 1, 1], embed_fusion="FiLM")),
         speaker_net=dict(n_tcn=5, C=128, H=256, att=128, E=192),
         wrap=dict(mask_constraint="ReLU"), B=2, L=4000, L_enroll=3000, seed=1234),
+    # ns_dparn_v0_causal verbatim (egs/ns/model.py:128-171)
+    "ns_dparn_short": dict(kind="wrap", enc=dict(kind="stft", n_fft=512, hop=128, drop_first_bin=True),
+                           masker=dict(cls="DPARN", args=(), oracle="dparn",
+                                       kw=dict(input_type="RI", input_dim=512, activation_type="PReLU", norm_type="bN2d",
+                                               dropout=0.1, channels=(1, 32, 32, 32, 64, 128), transpose_t_size=2,
+                                               transpose_delay=False, skip_conv=False, kernel_t=(2, 2, 2, 2, 2),
+                                               kernel_f=(5, 3, 3, 3, 3), stride_t=(1, 1, 1, 1, 1),
+                                               stride_f=(2, 2, 1, 1, 1), dilation_t=(1, 1, 1, 1, 1),
+                                               dilation_f=(1, 1, 1, 1, 1), delay=(0, 0, 0, 0, 0), rnn_hidden=128,
+                                               nhead=8)),
+                           wrap=dict(mask_constraint="linear", f_type="Complex", mask_type="Complex",
+                                     drop_first_bin=True), B=2, L=4000, seed=1234),
     # ---- reduced wrapper cases: odd sizes, ragged tails, sigmoid/linear constraints -----------
     "tiny_free": dict(kind="wrap", enc=dict(kind="free", win=16, hop=8, C=24),
                       masker=masker_args(24, 0, False, [0, 0, 0], tcn_kernel=3, tcn_dim=12, repeat_tcn=2,
@@ -228,6 +240,11 @@ CASES = {
                                 kernel_t=(2, 2, 2), kernel_f=(5, 3, 3), stride_t=(1, 1, 1), stride_f=(2, 2, 1),
                                 dilation_t=(1, 1, 1), dilation_f=(1, 1, 1), delay=(0, 0, 0), rnn_hidden=8, dropout=0.0),
                         B=2, T=18, seed=55),
+    "dparn_small": dict(kind="unet", cls="DPARN", oracle="dparn",
+                        kw=dict(input_type="RI", input_dim=32, channels=(1, 4, 6, 8), transpose_delay=False,
+                                kernel_t=(2, 2, 2), kernel_f=(5, 3, 3), stride_t=(1, 1, 1), stride_f=(2, 2, 1),
+                                dilation_t=(1, 1, 1), dilation_f=(1, 1, 1), delay=(0, 0, 0), rnn_hidden=12, nhead=2,
+                                dropout=0.0), B=2, T=18, seed=57),
     "enc_free": dict(kind="encdec", enc=dict(kind="free", win=32, hop=16, C=20), B=3, L=500, seed=16),
     "enc_free_relu_ragged": dict(kind="encdec", enc=dict(kind="free", win=20, hop=6, C=9, relu=True),
                                  B=2, L=211, seed=17),
@@ -308,7 +325,8 @@ def unet_args(spec):
              tcn_layer="normal", tcn_kernel=3, tcn_dim=256, tcn_dilated_basic=2, per_tcn_stack=5, repeat_tcn=4,
              tcn_with_embed=[1, 0, 0, 0, 0], tcn_use_film=False, tcn_norm="gLN", dconv_norm="gGN", causal=False,
              spectral_compress=False)
-    if spec["cls"] == "DPCRN":
+    if spec["cls"] in ("DPCRN", "DPARN"):
+        a["nhead"] = 1
         a.update(channels=(1, 32, 32, 32, 64, 128), kernel_t=(2, 2, 2, 2, 2), stride_t=(1, 1, 1, 1, 1),
                  dilation_t=(1, 1, 1, 1, 1), kernel_f=(5, 3, 3, 3, 3), stride_f=(2, 2, 1, 1, 1),
                  dilation_f=(1, 1, 1, 1, 1), delay=(0, 0, 0, 0, 0))
@@ -333,7 +351,7 @@ def oracle_cfg(name):
     """The oracle's description of a wrapper case."""
     c = CASES[name]
     enc = dict(c["enc"])
-    if c["masker"].get("cls") in ("Unet", "UnetTcn", "DPCRN"):
+    if c["masker"].get("cls") in ("Unet", "UnetTcn", "DPCRN", "DPARN"):
         cfg = dict(encoder=enc, masker=unet_args(c["masker"]), masker_kind=c["masker"]["oracle"])
     elif "cls" in c["masker"]:
         cfg = dict(encoder=enc, masker=rnn_args(c["masker"]), masker_kind=c["masker"]["cls"].lower())

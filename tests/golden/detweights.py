@@ -39,7 +39,7 @@ def det_tensor(name: str, ref: torch.Tensor) -> torch.Tensor:
 
 
 # buffers that are constants of the algorithm, never randomised
-_KEEP = ("kernel_sin_inv", "kernel_cos_inv", "window_mask")
+_KEEP = ("kernel_sin_inv", "kernel_cos_inv", "window_mask", "pe")
 
 
 def det_state_dict(model: torch.nn.Module, perturb_stft: float = 0.02) -> dict:

@@ -38,6 +38,7 @@ from puresound.nnet.skim import SkiM  # noqa: E402
 from puresound.streaming.skim_inference import StreamingSkiM  # noqa: E402
 from puresound.nnet.unet import Unet, UnetTcn  # noqa: E402
 from puresound.nnet.dpcrn import DPCRN  # noqa: E402
+from puresound.nnet.dparn import DPARN  # noqa: E402
 from puresound.nnet.lobe.trivial import Magnitude  # noqa: E402
 
 import cases  # noqa: E402
@@ -46,7 +47,7 @@ from detweights import det_state_dict, det_wave  # noqa: E402
 REF = cases.namespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                       ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                       AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM,
-                      StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN,
+                      StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN, DPARN=DPARN,
                       Magnitude=Magnitude, FbankEnc=FbankEnc)
 
 
@@ -84,7 +85,7 @@ def run_wrap(name, c):
     pre = model._get_waveform(enh)
     out["wav_preclamp"] = pre.numpy()
     small = c["L"] <= 4000
-    if small and c["masker"].get("cls") in ("Unet", "UnetTcn", "DPCRN"):
+    if small and c["masker"].get("cls") in ("Unet", "UnetTcn", "DPCRN", "DPARN"):
         out["mask_sub"] = sub(mask)
     elif small and "cls" in c["masker"]:
         out["feats_sub"] = sub(feats)

@@ -897,16 +897,17 @@ def test_unet_family_matches_reference_golden(PA, dev, golden_dir, name):
     assert rel_max(y.cpu().numpy(), g["y"]) < TOL
 
 
-def test_ns_dpcrn_preset_matches_reference_golden(PA, dev, golden_dir):
-    """egs/ns/model.py:40-82 (ns_dpcrn_v0_causal) through the wrapper: conv-STFT, DPCRN, complex mask, iSTFT."""
-    name = "ns_dpcrn_short"
+@pytest.mark.parametrize("name", ["ns_dpcrn_short", "ns_dparn_short"])
+def test_ns_dpcrn_preset_matches_reference_golden(PA, dev, golden_dir, name):
+    """egs/ns/model.py:40-171 (ns_dpcrn_v0_causal, ns_dparn_v0_causal) through the wrapper: conv-STFT, DPCRN / DPARN,
+    complex mask, iSTFT."""
     c = cases.CASES[name]
     g = _load(golden_dir, name)
     model = cases.build(PA.NS, name).eval()
     sd = det_state_dict(model)
     model.load_state_dict(sd)
     model.to(dev)
-    assert model.overall_parameters == cases.PARAM_COUNTS[name]
+    assert model.overall_parameters == int(g["n_params"])
     noisy = det_wave(c["seed"], c["B"], c["L"])
     wav = model.inference(noisy.to(dev))
     assert wav.shape == g["wav"].shape
@@ -957,3 +958,34 @@ def test_fbank_encoder_matches_reference_golden(PA, dev, golden_dir, name):
     y = model(det_wave(c["seed"], c["B"], c["L"]).to(dev))
     assert y.shape == g["feats"].shape
     assert rel_max(y.cpu().numpy(), g["feats"]) < TOL
+
+
+def test_self_attention_kernel(H, dev):
+    """ps_self_attention_f32 / ps_add_position_f32 against the oracle's multi-head attention, both sequence layouts
+    (positions contiguous in time; positions strided over frequency rows as in DPARN), with and without causal mask."""
+    n, e, heads, f, t = 2, 16, 4, 9, 13
+    x = _rand((n, e, f, t), 141)
+    w_in, w_out = _rand((3 * e, e), 142, -0.4, 0.4), _rand((e, e), 143, -0.4, 0.4)
+    xp = H.pad_rows(x.reshape(n, e * f, t).to(dev)).view(n, e, f, -1)
+    ld = xp.shape[-1]
+    rows = xp.view(n, e, f * ld)
+    frames = (f - 1) * ld + t
+    qkv, _ = H.conv1x1(rows, frames, H.pack_wt(w_in.to(dev)), 3 * e)
+    for causal in (False, True):
+        # DPARN layout: one sequence per frame t, positions = frequency rows
+        att = H.self_attention(qkv, e, heads, t, 1, f, ld, causal)
+        out, _ = H.conv1x1(att, frames, H.pack_wt(w_out.to(dev)), e)
+        got = out.view(n, e, f, ld)[..., :t].cpu()                                  # [N, E, F, T]
+        seq = x.permute(0, 3, 2, 1).reshape(n * t, f, e)                             # [N*T, F, E]
+        ref = UO.multihead_attention(seq, w_in, w_out, heads, causal).reshape(n, t, f, e).permute(0, 3, 2, 1)
+        assert rel_max(got.numpy(), ref.numpy()) < 2e-5, causal
+    # time layout: one sequence per (n, f) row... expressed as Q = f rows, positions = frames
+    att = H.self_attention(qkv, e, heads, f, ld, t, 1, False)
+    out, _ = H.conv1x1(att, frames, H.pack_wt(w_out.to(dev)), e)
+    got = out.view(n, e, f, ld)[..., :t].cpu()
+    seq = x.permute(0, 2, 3, 1).reshape(n * f, t, e)
+    ref = UO.multihead_attention(seq, w_in, w_out, heads, False).reshape(n, f, t, e).permute(0, 3, 1, 2)
+    assert rel_max(got.numpy(), ref.numpy()) < 2e-5
+    pe = UO.positional_table(f, e)
+    y = H.add_position(rows, pe.to(dev), t, 1, f, ld).view(n, e, f, ld)[..., :t].cpu()
+    assert torch.allclose(y, x + pe.t().reshape(1, e, f, 1), atol=1e-6)

@@ -218,7 +218,7 @@ def test_unet_family_matches_reference(golden_dir, name):
     if c["oracle"] == "unet_tcn":
         y = UO.unet_tcn(x, sd, "", args, torch.tensor(g["embed"]))
     else:
-        y = {"unet": UO.unet, "dpcrn": UO.dpcrn}[c["oracle"]](x, sd, "", args)
+        y = {"unet": UO.unet, "dpcrn": UO.dpcrn, "dparn": UO.dparn}[c["oracle"]](x, sd, "", args)
     assert y.shape == g["y"].shape
     assert rel_max(y.numpy(), g["y"]) < TOL
 
