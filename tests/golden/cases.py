@@ -97,6 +97,13 @@ CASES = {
                             block_with_embed=[1, 1, 1, 1], embed_fusion="FiLM")),
         speaker_net=dict(n_tcn=5, C=80, H=256, att=128, E=192),
         wrap=dict(mask_constraint="ReLU"), B=2, L=4000, L_enroll=3000, seed=1234),
+    "tse_skim_vad_short": dict(   # tse_skim_v0_causal_vad (egs/tse/model.py:560-606): sigmoid output, H = 64, 2 blocks
+        kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
+        masker=dict(cls="SkiM", args=(128, 64, 128),
+                    kw=dict(n_blocks=2, seg_size=150, seg_overlap=False, causal=True, embed_dim=192, embed_norm=True,
+                            block_with_embed=[1, 1], embed_fusion="FiLM")),
+        speaker_net=dict(n_tcn=5, C=128, H=256, att=128, E=192),
+        wrap=dict(mask_constraint="ReLU", output_constraint="Sigmoid"), B=2, L=4000, L_enroll=3000, seed=1234),
     "tse_skim_causal_short": dict(
         kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
         masker=dict(cls="SkiM", args=(128, 256, 128),
