@@ -1,23 +1,21 @@
-"""Activation lookup (mirror of puresound/nnet/lobe/activation.py): the names the recipes pass and the classes that
-hold their parameters; the arithmetic is ps_activation_f32."""
+"""Activation lookup for the U-Net family: which nn class a recipe's `activation_type` string names (so the parameter
+tree and state_dict keys match the reference's lobe/activation.py) and which ps_activation_f32 kind computes it."""
 import torch.nn as nn
 
-relu = nn.ReLU
-prelu = nn.PReLU
-mish = nn.Mish
-sigmoid = nn.Sigmoid
-tanh = nn.Tanh
+_TABLE = {"relu": nn.ReLU, "prelu": nn.PReLU, "mish": nn.Mish, "sigmoid": nn.Sigmoid, "tanh": nn.Tanh}
 
 
 def get_activation(name: str):
-    if name not in ["relu", "mish", "prelu", "sigmoid", "tanh"]:
-        raise NameError("Could not interpret activation identifier")
-    return globals()[name]
+    """Class for a lower-case activation name; anything else is a NameError, as in the reference."""
+    try:
+        return _TABLE[name]
+    except (KeyError, TypeError):
+        raise NameError("Could not interpret activation identifier") from None
 
 
 def activation_kind(mod: nn.Module) -> str:
-    for kind, cls in (("relu", nn.ReLU), ("prelu", nn.PReLU), ("mish", nn.Mish), ("sigmoid", nn.Sigmoid),
-                      ("tanh", nn.Tanh)):
+    """ps_activation_f32 kind of an instantiated activation module."""
+    for kind, cls in _TABLE.items():
         if isinstance(mod, cls):
             return kind
     raise NotImplementedError(type(mod).__name__)
