@@ -54,7 +54,7 @@ const char* ps_last_error(void);
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
  * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product", "segment_overlap",
- * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "conv1x1_bf16", "unfold2d", "activation", "add", "magnitude", "real_mask", "norm_activation", "self_attention", "add_position",
+ * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "conv1x1_bf16", "unfold2d", "conv2d", "activation", "add", "magnitude", "real_mask", "norm_activation", "self_attention", "add_position",
  * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
@@ -234,6 +234,14 @@ int ps_magnitude_f32(const float* x, float* y, int N, int half, int drop_first, 
 int ps_unfold2d_f32(const float* x1, int C1, const float* x2, int C2, float* y, int N, int Fin, int T_in, int T, int ld,
                     int kf, int kt, int stride_f, int dil_f, int dil_t, int pad_f, int pad_t, int Fout, int transposed,
                     void* stream);
+/* ps_conv2d_f32: the same convolution WITHOUT materialising the taps (implicit GEMM: the MFMA B operand is gathered from
+ * the input rows), bias and activation in the epilogue: y[n][m][fo][t] = act(bias[m] + sum_k W[m][k] * taps[k][fo][t]) with
+ * the tap definition, two-source channel concat and T_in / T convention of ps_unfold2d_f32; wt is the packed transposed
+ * weight of ps_conv1x1_f32 over K = (C1+C2)*kf*kt (eval BatchNorm2d folded in by the caller); act as ps_activation_f32.
+ * Pad frames of y are cleared.  K <= 4096 (PS_E_UNSUPPORTED beyond: use the unfold path). */
+int ps_conv2d_f32(const float* x1, int C1, const float* x2, int C2, const float* wt, const float* bias, float* y, int N,
+                  int M, int Fin, int T_in, int T, int ld, int kf, int kt, int stride_f, int dil_f, int dil_t, int pad_f,
+                  int pad_t, int Fout, int transposed, int act, const float* slope, void* stream);
 int ps_activation_f32(float* x, int kind, const float* slope, int64_t rows, int T, int ld, void* stream);
 /* gLN over [CH, F, T] (GlobLN on a 4-D map, lobe/norm.py:20-34) followed by an activation, in place on [N][rows_per_utt]
  * rows of ld frames (row r belongs to channel r / rows_per_channel).  pro = PS_NORM_GLOBAL with the producing GEMM's

@@ -82,6 +82,7 @@ SIGNATURES = {
     "ps_add_position_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 7 + [_vp]),
     "ps_overlap_average_f32": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ps_unfold2d_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp] + [C.c_int] * 14 + [_vp]),
+    "ps_conv2d_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 16 + [_vp, _vp]),
     "ps_activation_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "ps_magnitude_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_real_mask_f32": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),

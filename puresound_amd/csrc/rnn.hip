@@ -337,7 +337,13 @@ __global__ __launch_bounds__(H * 4) void lstm_m4_kernel(LstmK k) {
   const int j = lane & 3, ub = lane >> 2;
   const int unit = 16 * w + ub;
   const int d = blockIdx.z;
-  const int b = blockIdx.x * 4 + j;
+  // XCD-aware group order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), but
+  // neighbouring sequence groups share the 128-byte lines of the gate rows (4 sequences = 16 bytes of a line), so
+  // groups are renumbered to put neighbours on ONE XCD: id -> (id % 8) * ceil(G/8) + id / 8.
+  // (the grid is a multiple of 8 groups, so this is a bijection; groups past the last sequence are masked by `valid`)
+  const int per = gridDim.x >> 3;
+  const int grp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int b = grp * 4 + j;
   const bool valid = b < a.N * a.Q;
   const int n = valid ? b / a.Q : 0, q = valid ? b % a.Q : 0;
   const int G = 4 * H;
@@ -590,7 +596,13 @@ extern "C" int ps_lstm_f32(const ps_lstm_args* args, void* stream) {
   dim3 grid((a.Q + LS - 1) / LS, a.N, a.D);
   if ((a.H == 64 || a.H == 128) && !(g_debug_flags & 2)) {
     const long long seqs = (long long)a.N * a.Q;
-    const bool contig = a.step_stride == 1 && a.steps % 4 == 0 && a.q_stride % 4 == 0 && a.ldt % 4 == 0 &&
+    // 16-byte step groups: steps are consecutive frames starting on a 16-byte boundary.  A forward-only pass may end
+    // in a partial group: it reads / writes up to 3 frames past its last step, which must still lie inside the row
+    // (pad frames; they are never read as data).  Without the groups a long pass over consecutive frames re-fetches
+    // every 128-byte line of the gate pre-activations once per step (DPCRN's inter pass: 10.8 ms instead of ~3).
+    const int steps4 = (a.steps + 3) / 4 * 4;
+    const bool tail_ok = a.steps % 4 == 0 || (a.D == 1 && (long long)(a.Q - 1) * a.q_stride + steps4 <= a.ldt);
+    const bool contig = a.step_stride == 1 && tail_ok && a.q_stride % 4 == 0 && a.ldt % 4 == 0 &&
                         !((uintptr_t)a.gx & 15) && !((uintptr_t)a.hout & 15);
     // 16 sequences per workgroup when there are enough sequences to fill the chip that way (debug bit 2 / 3 force one)
     const bool wide = (g_debug_flags & 4) ? true : (g_debug_flags & 8) ? false : (a.H == 64 && contig && seqs >= 16 * 256);
@@ -604,7 +616,7 @@ extern "C" int ps_lstm_f32(const ps_lstm_args* args, void* stream) {
       else  // H = 128: the 16-byte group path does not fit the 256-VGPR budget of 8 waves
         hipLaunchKernelGGL((lstm_mfma_kernel<128, false>), mgrid, dim3(512), 0, (hipStream_t)stream, k);
     } else {
-      dim3 mgrid((unsigned)((seqs + 3) / 4), 1, a.D);
+      dim3 mgrid((unsigned)(((seqs + 3) / 4 + 7) / 8 * 8), 1, a.D);  // multiple of 8: see the XCD-aware group order
       if (a.H == 64 && contig)
         hipLaunchKernelGGL((lstm_m4_kernel<64, true>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
       else if (a.H == 64)

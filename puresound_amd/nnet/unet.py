@@ -19,6 +19,13 @@ from .._abi import PS_NORM_GLOBAL
 from .lobe.norm import GlobLN, get_norm
 
 
+import os
+
+# 1 (default): Conv2d / ConvTranspose2d as ps_conv2d_f32 (implicit GEMM, taps gathered in the kernel);
+# 0: ps_unfold2d_f32 + ps_conv1x1_f32 + ps_activation_f32 (the path gLN-normalised layers always take)
+IMPLICIT_CONV = os.environ.get("PS_IMPLICIT_CONV", "1") == "1"
+
+
 class Unet(PlanCache, nn.Module):
     """unet.py:13-296; constructor order as the reference (unet.py:35-53)."""
 
@@ -175,8 +182,12 @@ class Unet(PlanCache, nn.Module):
             f_in = x.shape[2]
             pf = kf // 2
             f_out = (f_in + 2 * pf - df * (kf - 1) - 1) // sf + 1
-            taps = hip.unfold2d(x, None, t, f_out, kf, kt, sf, df, dt, pf, kt - self.delay[i] - 1, False)
-            x = self._gemm_act(taps, lay, f_out, x.shape[3], t)
+            if "gln" not in lay and IMPLICIT_CONV and x.shape[1] * kf * kt <= 4096:
+                x = hip.conv2d(x, None, lay["wt"], lay["bias"], lay["M"], t, f_out, kf, kt, sf, df, dt, pf,
+                               kt - self.delay[i] - 1, False, lay["act"], lay["slope"])
+            else:
+                taps = hip.unfold2d(x, None, t, f_out, kf, kt, sf, df, dt, pf, kt - self.delay[i] - 1, False)
+                x = self._gemm_act(taps, lay, f_out, x.shape[3], t)
             skip.append(x)
         return skip
 
@@ -212,6 +223,9 @@ class Unet(PlanCache, nn.Module):
                 if transpose_delay:   # keep frames [ext, ext + T): a 1x1 "convolution" with a negative time pad
                     x = hip.unfold2d(x, None, t, f_out, 1, 1, 1, 1, 1, 0, -ext, False, t_in=t + ext).view(
                         n, lay["M"], f_out, ld)
+            elif IMPLICIT_CONV and (x.shape[1] + (0 if x2 is None else x2.shape[1])) * kf * self.t_kernel <= 4096:
+                x = hip.conv2d(x, x2, lay["wt"], lay["bias"], lay["M"], t, f_out, kf, self.t_kernel, sf, df, dt, pf,
+                               ext if transpose_delay else 0, True, lay["act"], lay["slope"])
             else:
                 shift = ext if transpose_delay else 0
                 taps = hip.unfold2d(x, x2, t, f_out, kf, self.t_kernel, sf, df, dt, pf, shift, True)

@@ -882,6 +882,31 @@ def test_unfold2d_kernel(H, dev, transposed):
     assert rel_max(got.numpy(), ref.numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("transposed,m", [(False, 4), (True, 40), (False, 100)])
+def test_conv2d_implicit_gemm_kernel(H, dev, transposed, m):
+    import torch.nn.functional as F
+    n, c1, c2, f, t = 2, 3, 2, 11, 150
+    x1, x2 = _rand((n, c1, f, t), 151), _rand((n, c2, f, t), 152)
+    x = torch.cat([x1, x2], 1)
+    kf, kt, sf = 3, 2, 2
+    b, slope = _rand((m,), 153), torch.tensor([0.2])
+    pad = lambda v: H.pad_rows(v.reshape(n, -1, t).to(dev)).view(n, v.shape[1], f, -1)  # noqa: E731
+    if not transposed:
+        w = _rand((m, c1 + c2, kf, kt), 154, -0.3, 0.3)
+        ref = F.conv2d(F.pad(x, (kt - 1, 0, kf // 2, kf // 2)), w, b, stride=(sf, 1))
+        w2, shift = w.reshape(m, -1), kt - 1
+    else:
+        w = _rand((c1 + c2, m, kf, kt), 154, -0.3, 0.3)
+        op = sf - kf + 2 * (kf // 2)
+        ref = F.conv_transpose2d(x, w, b, stride=(sf, 1), padding=(kf // 2, 0), output_padding=(op, 0))[..., (kt - 1):]
+        w2, shift = w.permute(1, 0, 2, 3).reshape(m, -1), kt - 1
+    ref = torch.where(ref >= 0, ref, 0.2 * ref)
+    y = H.conv2d(pad(x1), pad(x2), H.pack_wt(w2.contiguous().to(dev)), b.to(dev), m, t, ref.shape[2], kf, kt, sf, 1, 1,
+                 kf // 2, shift, transposed, "prelu", slope.to(dev))
+    assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 2e-5
+    assert float(y[..., t:].abs().max()) == 0.0
+
+
 UNET_CASES = [n for n, c in cases.CASES.items() if c["kind"] == "unet"]
 
 
@@ -989,3 +1014,29 @@ def test_self_attention_kernel(H, dev):
     pe = UO.positional_table(f, e)
     y = H.add_position(rows, pe.to(dev), t, 1, f, ld).view(n, e, f, ld)[..., :t].cpu()
     assert torch.allclose(y, x + pe.t().reshape(1, e, f, 1), atol=1e-6)
+
+
+@pytest.mark.parametrize("hid,t", [(64, 13), (128, 10), (64, 16)])
+def test_lstm_kernel_row_sequences_with_partial_step_group(H, dev, hid, t):
+    """DPCRN's inter pass: one sequence per frequency row (q_stride = ld), consecutive frames, a step count that is
+    not a multiple of the 16-byte step group."""
+    from puresound_amd import _abi
+    from puresound_amd.nnet._plans import lstm_plan
+    n, c, f = 2, 12, 5
+    m, sd = _lstm_sd(c, hid, False, 160)
+    x = _rand((n, c, f, t), 161)
+    ref, _ = DP.lstm(x.permute(0, 2, 3, 1).reshape(n * f, t, c), sd, "", False)
+    p = lstm_plan(m.to(dev), torch.device(dev))
+    xp = H.pad_rows(x.reshape(n, c * f, t).to(dev)).view(n, c, f, -1)
+    ld = xp.shape[-1]
+    frames = (f - 1) * ld + t
+    gx, _ = H.conv1x1(xp.view(n, c, f * ld), frames, p["wih"], p["rows"], None, p["bias"])
+    for flags in (0, 4, 8, 2):
+        old = _abi.lib().ps_debug_flags(flags)
+        try:
+            hout, _ = H.lstm(gx, p["whh_t"], hid, 1, f, ld, t, 1)
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
+        got = hout.view(n, hid, f, ld)[..., :t].cpu().permute(0, 2, 3, 1).reshape(n * f, t, hid)
+        assert rel_max(got.numpy(), ref.numpy()) < 2e-5, flags
