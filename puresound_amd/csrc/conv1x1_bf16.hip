@@ -321,56 +321,97 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
   }
 }
 
-// ---- wave-specialised persistent variant ---------------------------------------------------------------------------
+// ---- ping-pong persistent variant ------------------------------------------------------------------------------------
 // Measured on the kernel above (tools/stamp_bf16.py): the two co-resident workgroups fall into phase -- both stream
 // MFMAs, then both stage -- so a K-step costs compute (3047 cycles, two waves sharing a matrix pipe) PLUS staging
-// (1563) PLUS barrier (624) instead of their maximum.  Here ONE 512-thread workgroup per CU splits the roles for good:
-// waves 0-3 ("consumers") only read fragments, issue MFMAs and drain finished tiles; waves 4-7 ("producers") only load,
-// transform, split and write LDS, two K-steps ahead through a 3-slot ring, with their own deep register queues (they
-// hold no accumulators).  The workgroup is persistent over a contiguous run of tiles, so the producers keep
-// streaming into the next tile while the consumers drain the previous one.
-constexpr int WS_MAXU = 8;  // utterances one workgroup's tile run may touch (prologue scalars kept in LDS)
+// (1563) PLUS barrier (624) instead of their maximum.  Here ONE 512-thread workgroup per CU holds both tiles and the
+// alternation is explicit: the two halves (waves 0-3 / 4-7; one wave of each per SIMD) own the two 256 x 128 tiles of a
+// 256 (m) x 256 (t) supertile and run the same loop one phase apart, with two workgroup barriers per K-step:
+//
+//     phase 2s   : half 0 issues the MFMAs of step s      | half 1 stages (transform, split, LDS writes, load issue)
+//     phase 2s+1 : half 0 stages                          | half 1 issues the MFMAs of step s
+//
+// so the matrix pipe always has exactly one wave per SIMD feeding it and the VALU/LDS-write work of the other half runs
+// beside it.  Consequences of the fixed alternation:
+//   * both halves use the same weight tile, so each stages only half of it (LDS ring of two weight slots: slot s&1 is
+//     read in phases 2s, 2s+1 and rewritten in phases 2s+2 (half 1) and 2s+3 (half 0));
+//   * a half never stages and computes at the same time, so it needs ONE activation slot;
+//   * the register queues of loads in flight are consumed and refilled in place (static rotation by a wave-uniform
+//     switch): a register move out of a queue slot would make hipcc wait for the load that is landing in it;
+//   * a tile's drain falls into its half's staging phase; the accumulators are re-initialised right there with the
+//     residual tile of the half's NEXT tile (out_conv) so that no load round trip sits between the last MFMA and the
+//     stores -- the residual streams in behind the stores while the other half computes.
+// The workgroup is persistent over a contiguous run of supertiles (t fastest, then m-tile, then utterance).
+constexpr int PP_MAXU = 2;  // utterances one workgroup's run may touch (prologue tables kept in LDS)
 
-struct WsTile {
-  int n, mt, tt;
+template <int PLANES>
+struct PpLds {
+  static constexpr int A_SLOT = PLANES * XB_M * XB_K * 2;  // 8 KiB per plane
+  static constexpr int B_SLOT = PLANES * XB_T * XB_K * 2;  // 4 KiB per plane
+  static constexpr int NA = 3;                             // weight ring slots
+  static constexpr int D = 3;                              // raw activation ring slots per half
+  static constexpr int RAW = XB_K * XB_T * 4;              // one K-step of raw fp32 activations [16][128]
+  static constexpr int OFF_RAW = NA * A_SLOT;              // [half][D][RAW]
+  static constexpr int OFF_B = OFF_RAW + 2 * D * RAW;      // split activation slot of half 0 | half 1
+  static constexpr int OFF_TAB = OFF_B + 2 * B_SLOT;       // [PP_MAXU][sc[512] | sh[512]] floats
+  static constexpr int OFF_BIAS = OFF_TAB + PP_MAXU * 1024 * 4;  // [2 supertile parities][bias[256] | bias_n[256]] floats
+  static constexpr int TOTAL = OFF_BIAS + 4 * XB_M * 4;    // PLANES = 3: 156 KiB
 };
+static_assert(PpLds<3>::TOTAL <= 160 * 1024, "one workgroup per CU");
 
-__device__ __forceinline__ WsTile ws_tile(int idx, int tiles_t, int tiles_m) {
-  WsTile t;
-  t.tt = idx % tiles_t;
-  const int r = idx / tiles_t;
-  t.mt = r % tiles_m;
-  t.n = r / tiles_m;
-  return t;
-}
+// All operand traffic of the K loop is LDS-DMA (buffer_load ... lds): weights straight into a 3-slot ring in their
+// final image, raw fp32 activations into a per-half 3-slot ring from which the owning half transforms / splits them
+// into its bf16 slot one step later.  No operand waits in registers, so there are no register queues to rotate and
+// hipcc's load bookkeeping cannot serialise the pipeline; the waits are counted by hand (every wave issues the same
+// DMA sequence every iteration -- steps past the end go through an empty descriptor -- so "vmcnt(n)" always means
+// "everything but my n youngest operations").
+// The scalar unit is shared by the eight waves of the CU, so the per-iteration scalar path is kept to counters and
+// adds: each pipeline stage (activation DMA, weight DMA, staging, compute) walks the K-steps with its own (supertile,
+// step) counter and only decodes (utterance, m-tile, t-pair), rebuilds descriptors etc. when it crosses a supertile.
+template <int V>
+using bic = std::integral_constant<int, V>;
 
 template <int PLANES, bool TR, bool STATS, bool RES>
-__global__ __launch_bounds__(512, 1) void conv1x1_bf16_ws_kernel(BfArgs a) {
-  using L = BfLds<PLANES>;
-  constexpr int NSLOT = 3;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * L::SLOT + 2 * 512 * 4 + WS_MAXU * 2 * 4];
-  float* tab = reinterpret_cast<float*>(smem + NSLOT * L::SLOT);  // gamma[512] | beta[512]
-  float* scal = tab + 1024;                                       // [WS_MAXU][2]: mean, rstd of utterance n_lo + u
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool consumer = wave < 4;  // wave-uniform
+__global__ __launch_bounds__(512, 1) void conv1x1_bf16_pp_kernel(BfArgs a) {
+  using L = PpLds<PLANES>;
+  constexpr int D = L::D, NA = L::NA;
+  constexpr int P = 2 + PLANES;                   // DMA operations per wave per iteration: 2 activation, PLANES weight
+  // Iteration i issues x(i+D) and A(i+2) at the start of its compute phase (2 + PLANES operations, in that order).
+  constexpr int W_X = PLANES + (D - 1) * P;       // youngest operations allowed in flight when x(i+1) must have landed
+  constexpr int W_A = P;                          // ... when this wave's share of A(i+1) must have landed
+  __shared__ __attribute__((aligned(16))) unsigned char smem[L::TOTAL];
+  float* tab = reinterpret_cast<float*>(smem + L::OFF_TAB);
+  float* bias_lds = reinterpret_cast<float*>(smem + L::OFF_BIAS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = wave >> 2;  // half
+  const int hw = wave & 3;
+  const int ptid = tid & 255;
+  const int wm = hw >> 1, wt = hw & 1;
+  const int lr = lane & 31, lh = lane >> 5;
 
-  const int ntiles = a.tiles_t * a.tiles_m * a.N;
+  const int S = a.ksteps;
+  const int st_per = (a.tiles_t + 1) >> 1;
+  const int nsuper = st_per * a.tiles_m * a.N;
   const int G = gridDim.x;
-  const int lo = (int)((long long)blockIdx.x * ntiles / G), hi = (int)((long long)(blockIdx.x + 1) * ntiles / G);
+  const int lo = (int)((long long)blockIdx.x * nsuper / G), hi = (int)((long long)(blockIdx.x + 1) * nsuper / G);
   if (lo >= hi) return;
-  const int total = (hi - lo) * a.ksteps;
-  const int n_lo = ws_tile(lo, a.tiles_t, a.tiles_m).n;
+  const int total = (hi - lo) * S;
+  auto decode = [&](int idx, int& n, int& mt, int& t2) {  // supertile index -> utterance, m-tile, pair of t-tiles
+    t2 = idx % st_per;
+    const int r = idx / st_per;
+    mt = r % a.tiles_m;
+    n = r / a.tiles_m;
+  };
+  int n_lo, mt_lo, t2_lo;
+  decode(lo, n_lo, mt_lo, t2_lo);
 
   const float slope = (TR && a.pro.prelu) ? a.pro.slope[0] : 1.f;
+  const bool plain_tr = !a.pro.pre_relu && !a.pro.post_tanh;  // kernel-uniform: scale/shift + PReLU only
   if constexpr (TR) {
     const bool has_norm = a.pro.norm != PS_NORM_NONE;
-    for (int k = tid; k < 512; k += 512) {
-      tab[k] = (has_norm && k < a.K) ? a.pro.gamma[k] : (k < a.K ? 1.f : 0.f);
-      tab[512 + k] = (has_norm && k < a.K) ? a.pro.beta[k] : 0.f;
-    }
-    const int n_hi = ws_tile(hi - 1, a.tiles_t, a.tiles_m).n;
-    // every wave reduces the producer's partial statistics itself (no cross-wave step); wave u % 8 stores
-    for (int u = 0; u <= n_hi - n_lo; ++u) {
+    const int n_hi = ((hi - 1) / st_per) / a.tiles_m;
+    for (int u = 0; u <= n_hi - n_lo; ++u) {  // every wave reduces the producer's partial statistics itself
       float mean = 0.f, rstd = 1.f;
       if (a.pro.norm == PS_NORM_GLOBAL) {
         double sa = 0.0, sq = 0.0;
@@ -387,233 +428,317 @@ __global__ __launch_bounds__(512, 1) void conv1x1_bf16_ws_kernel(BfArgs a) {
         mean = (float)m;
         rstd = (float)(1.0 / sqrt(var + (double)a.pro.eps));
       }
-      if (wave == (u & 7) && lane == 0) {
-        scal[2 * u] = mean;
-        scal[2 * u + 1] = rstd;
+      const int k = tid;  // 512 threads, 512 table rows
+      float sc = 0.f, sh = 0.f;
+      if (k < a.K) {
+        sc = has_norm ? a.pro.gamma[k] * rstd : 1.f;
+        sh = has_norm ? a.pro.beta[k] - mean * sc : 0.f;
       }
+      tab[u * 1024 + k] = sc;
+      tab[u * 1024 + 512 + k] = sh;
     }
   }
-  __syncthreads();
 
-  if (!consumer) {
-    // =============================== producers =====================================================================
-    const int ptid = tid - 256;
-    constexpr int A_PIECES = 2 * PLANES;
-    constexpr int AD = 2, BD = 3;  // K-steps of weights / activations in flight
-    const int bt = ptid & 127, bh = ptid >> 7;
-    const int xb_voff = (8 * bh * a.ldt + bt) * 4;
-    u32x4v areg[AD][A_PIECES];
-    float breg[BD][8];
-    // load side: global step -> (tile, ks); steps past the end re-read the last one
-    auto issue_a = [&](int g, auto q_c) {
-      constexpr int q = decltype(q_c)::value;
-      const int gc = g < total ? g : total - 1;
-      const WsTile t = ws_tile(lo + gc / a.ksteps, a.tiles_t, a.tiles_m);
-      const int ks = gc % a.ksteps;
-      const u32x4v* src = reinterpret_cast<const u32x4v*>(a.wt) + ((size_t)t.mt * a.ksteps + ks) * (L::A_BYTES / 16);
-#pragma unroll
-      for (int i = 0; i < A_PIECES; ++i) areg[q][i] = src[ptid + 256 * i];
-    };
-    auto issue_b = [&](int g, auto q_c) {
-      constexpr int q = decltype(q_c)::value;
-      const int gc = g < total ? g : total - 1;
-      const WsTile t = ws_tile(lo + gc / a.ksteps, a.tiles_t, a.tiles_m);
-      const int ks = gc % a.ksteps;
-      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(a.x) + (size_t)t.n * a.K * a.ldt, 0, a.K * a.ldt * 4, 0x00020000);
-      const int soff = (ks * XB_K * a.ldt + t.tt * XB_T) * 4;
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        breg[q][j] =
-            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, xb_voff, soff + j * a.ldt * 4, 0));
-    };
-    auto stage = [&](int g) {  // write step g (queue heads) into its ring slot
-      unsigned char* sa = smem + (g % NSLOT) * L::SLOT;
-#pragma unroll
-      for (int i = 0; i < A_PIECES; ++i) reinterpret_cast<u32x4v*>(sa)[ptid + 256 * i] = areg[AD - 1][i];
-      float v[8];
-      const int ks = g % a.ksteps;
-      float mean = 0.f, rstd = 1.f;
-      if constexpr (TR) {
-        const int u = ws_tile(lo + g / a.ksteps, a.tiles_t, a.tiles_m).n - n_lo;
-        mean = scal[2 * u];
-        rstd = scal[2 * u + 1];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float x = breg[BD - 1][j];
-        if constexpr (TR) {
-          const int k = ks * XB_K + 8 * bh + j;
-          if (a.pro.pre_relu) x = fmaxf(x, 0.f);
-          const float sc = tab[k] * rstd;
-          x = x * sc + (tab[512 + k] - mean * sc);
-          if (a.pro.prelu) x = prelu(x, slope);
-          if (a.pro.post_tanh) x = tanhf(x);
-          if (k >= a.K) x = 0.f;
-        }
-        v[j] = x;
-      }
-      unsigned char* sb = sa + L::A_BYTES;
-#pragma unroll
-      for (int p = 0; p < PLANES; ++p) {
-        bf16x8 piece;
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          const bf16x2 h = __builtin_convertvector(f32x2v{v[j], v[j + 1]}, bf16x2);
-          piece[j] = h[0];
-          piece[j + 1] = h[1];
-          if (p + 1 < PLANES) {
-            const f32x2v back = __builtin_convertvector(h, f32x2v);
-            v[j] -= back[0];
-            v[j + 1] -= back[1];
-          }
-        }
-        *reinterpret_cast<bf16x8*>(sb + ((p * XB_T + bt) * XB_K + 8 * bh) * 2) = piece;
-      }
-    };
-    using i0 = std::integral_constant<int, 0>;
-    using i1 = std::integral_constant<int, 1>;
-    using i2 = std::integral_constant<int, 2>;
-    // fill the queues: heads (index AD-1 / BD-1) = step 0
-    issue_a(0, i1{});
-    issue_a(1, i0{});
-    issue_b(0, i2{});
-    issue_b(1, i1{});
-    issue_b(2, i0{});
-    unsigned long long p_stage = 0, p_bar = 0, p_prev = 0;
-    if (a.stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(p_prev)::"memory");
-    for (int i = 0; i < total + 2; ++i) {
-      if (i < total) {
-        stage(i);
-        // advance the queues, refill the tails
-#pragma unroll
-        for (int q = 0; q < A_PIECES; ++q) areg[1][q] = areg[0][q];
-        issue_a(i + 2, i0{});
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          breg[2][j] = breg[1][j];
-          breg[1][j] = breg[0][j];
-        }
-        issue_b(i + 3, i0{});
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (a.stamps) {
-        unsigned long long now;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-        p_stage += now - p_prev;
-        p_prev = now;
-      }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (a.stamps) {
-        unsigned long long now;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-        p_bar += now - p_prev;
-        p_prev = now;
-      }
-    }
-    if (a.stamps && tid == 256) {
-      unsigned long long* d = a.stamps + (size_t)blockIdx.x * 6;
-      d[2] = p_stage;
-      d[3] = p_bar;
-    }
-    return;
-  }
-
-  // ================================= consumers ======================================================================
-  const int wm = wave >> 1, wt = wave & 1;
-  const int lr = lane & 31, lh = lane >> 5;
-  f32x16 acc[4][2];
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = zero16;
-
-  auto compute = [&](int slot) {
-    const unsigned char* sa = smem + slot * L::SLOT;
-    const unsigned char* sb = sa + L::A_BYTES;
-    bf16x8 bf[PLANES][2];
-#pragma unroll
-    for (int p = 0; p < PLANES; ++p)
-#pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
-        bf[p][ti] = *reinterpret_cast<const bf16x8*>(sb + ((p * XB_T + wt * 64 + ti * 32 + lr) * XB_K + 8 * lh) * 2);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      bf16x8 af[PLANES];
-#pragma unroll
-      for (int p = 0; p < PLANES; ++p)
-        af[p] = *reinterpret_cast<const bf16x8*>(sa + ((p * XB_M + wm * 128 + mi * 32 + lr) * XB_K + 8 * lh) * 2);
-#pragma unroll
-      for (int ti = 0; ti < 2; ++ti) {
-        if constexpr (PLANES == 3) {
-          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][ti], acc[mi][ti], 0, 0, 0);
-          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0][ti], acc[mi][ti], 0, 0, 0);
-          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2][ti], acc[mi][ti], 0, 0, 0);
-          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0][ti], acc[mi][ti], 0, 0, 0);
-          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1][ti], acc[mi][ti], 0, 0, 0);
-        }
-        acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0][ti], acc[mi][ti], 0, 0, 0);
-      }
+  // ---- activation DMA: raw fp32 [16][128] of one K-step -> ring slot --------------------------------------------------
+  // piece (16 B) p = i*256 + hw*64 + lane = row p>>5, frames 4*(p&31)..; a wave's DMA covers two rows of 128 frames
+  const int x_voff = ((lane >> 5) * a.ldt + (lane & 31) * 4) * 4;
+  const int x_step = XB_K * a.ldt * 4, x_half = 8 * a.ldt * 4;
+  float* const raw_w = reinterpret_cast<float*>(smem + L::OFF_RAW + h * D * L::RAW) + hw * 256;
+  int xi = lo, xk = 0, xso = 0;  // supertile, step, scalar offset of the step's first row of this wave
+  __amdgpu_buffer_rsrc_t xr;
+  auto x_setup = [&]() {
+    int n, mt, t2;
+    decode(xi, n, mt, t2);
+    const bool ok = xi < hi && 2 * t2 + h < a.tiles_t;  // past the end / tile outside the row: empty descriptor
+    xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)n * a.K * a.ldt, 0,
+                                           ok ? a.K * a.ldt * 4 : 0, 0x00020000);
+    xso = (hw * 2 * a.ldt + (2 * t2 + h) * XB_T) * 4;
+  };
+  auto dma_x = [&](int slot) {
+    float* dst = raw_w + slot * (L::RAW / 4);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, x_voff, xso, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst + 1024, 16, x_voff, xso + x_half, 0, 0);
+  };
+  auto x_advance = [&]() {
+    xso += x_step;
+    if (++xk == S) {
+      xk = 0;
+      ++xi;
+      x_setup();
     }
   };
 
-  auto drain = [&](const WsTile& t) {
-    const int m0 = t.mt * XB_M, t0 = t.tt * XB_T, n = t.n;
-    float fsum = 0.f, fsq = 0.f;
-    const int slab = a.M * a.ldt * 4;
-    const __amdgpu_buffer_rsrc_t yr =
-        __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)n * a.M * a.ldt, 0, slab, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(RES ? a.res : a.y) + (size_t)n * a.M * a.ldt, 0, slab, 0x00020000);
+  // ---- weight DMA: this half's share (half a slot) of one K-step, already in its LDS image ----------------------------
+  const int w_voff = lane * 16;
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned short*>(a.wt), 0, a.tiles_m * S * L::A_SLOT, 0x00020000);
+  const int a_share = (h * PLANES * 256 + hw * 64) * 16;  // byte offset of this wave's pieces inside a slot
+  int ai = lo, ak = 0, aso = 0;
+  auto a_setup = [&]() {
+    int n, mt, t2;
+    decode(ai, n, mt, t2);
+    // past the end: an offset outside the descriptor (reads nothing, writes zeros)
+    aso = ai < hi ? mt * S * L::A_SLOT + a_share : 0x7f000000;
+  };
+  auto dma_a = [&](int slot) {
+    float* dst = reinterpret_cast<float*>(smem + slot * L::A_SLOT + a_share);
+#pragma unroll
+    for (int i = 0; i < PLANES; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst + i * 1024, 16, w_voff, aso + i * 4096, 0, 0);
+  };
+  auto a_advance = [&]() {
+    aso += L::A_SLOT;
+    if (++ak == S) {
+      ak = 0;
+      ++ai;
+      a_setup();
+    }
+  };
+
+  // bias rows of supertile (n, mt) -> LDS (one 1-KiB DMA each for bias and bias_n, wave 0 only; its extra operations
+  // only make its counted waits stricter).  Issued while the supertile's step 0 is staged, read by the drains S - 1
+  // or more iterations later, after this wave has passed a counted wait and a barrier.
+  auto bias_dma = [&](int n, int mt, int par) {
     const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.bias ? a.bias : a.x), 0, a.bias ? a.M * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t bnr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.bias_n ? a.bias_n + (size_t)n * a.M : a.x), 0, a.bias_n ? a.M * 4 : 0, 0x00020000);
-    const int lane_off = (4 * lh * a.ldt + lr) * 4;
+    float* dst = bias_lds + par * 2 * XB_M;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(br, dst, 16, w_voff, mt * XB_M * 4, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(bnr, dst + XB_M, 16, w_voff, mt * XB_M * 4, 0, 0);
+  };
+
+  // ---- staging: raw ring slot -> this half's bf16 slot (prologue transform, split into PLANES bf16 terms) -------------
+  const int bt = ptid & 127, bh = ptid >> 7;  // frame, k-half
+  const float* const raw_r = reinterpret_cast<const float*>(smem + L::OFF_RAW + h * D * L::RAW) + 8 * bh * XB_T + bt;
+  unsigned char* const bx_w = smem + L::OFF_B + h * L::B_SLOT + (bt * XB_K + 8 * bh) * 2;
+  int si = lo, sk = 0, spar = 0;  // supertile, step, bias-table parity of the step to stage next
+  const float* stab = tab + 8 * bh;  // this thread's table rows of the current utterance and step
+  auto s_setup = [&]() {
+    int n, mt, t2;
+    decode(si, n, mt, t2);
+    stab = tab + (n - n_lo) * 1024 + 8 * bh;
+    if (wave == 0 && si < hi) bias_dma(n, mt, spar);
+  };
+  auto stage_b = [&](int slot) {
+    if (si >= hi || (a.ablate & 4)) return;
+    const float* raw = raw_r + slot * (L::RAW / 4);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = raw[j * XB_T];
+    if constexpr (TR) {
+      const f32x4 sc0 = *reinterpret_cast<const f32x4*>(stab), sc1 = *reinterpret_cast<const f32x4*>(stab + 4);
+      const f32x4 sh0 = *reinterpret_cast<const f32x4*>(stab + 512), sh1 = *reinterpret_cast<const f32x4*>(stab + 516);
+      if (plain_tr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = prelu(v[j] * (j < 4 ? sc0[j & 3] : sc1[j & 3]) + (j < 4 ? sh0[j & 3] : sh1[j & 3]), slope);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float u = v[j];
+          if (a.pro.pre_relu) u = fmaxf(u, 0.f);
+          u = u * (j < 4 ? sc0[j & 3] : sc1[j & 3]) + (j < 4 ? sh0[j & 3] : sh1[j & 3]);
+          u = prelu(u, slope);
+          if (a.pro.post_tanh) u = tanhf(u);
+          v[j] = u;
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p) {
+      bf16x8 piece;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const bf16x2 hh = __builtin_convertvector(f32x2v{v[j], v[j + 1]}, bf16x2);
+        piece[j] = hh[0];
+        piece[j + 1] = hh[1];
+        if (p + 1 < PLANES) {
+          const f32x2v back = __builtin_convertvector(hh, f32x2v);
+          v[j] -= back[0];
+          v[j + 1] -= back[1];
+        }
+      }
+      *reinterpret_cast<bf16x8*>(bx_w + p * XB_T * XB_K * 2) = piece;
+    }
+  };
+  auto s_advance = [&]() {
+    stab += XB_K;
+    if (++sk == S) {
+      sk = 0;
+      ++si;
+      spar ^= 1;
+      s_setup();
+    }
+  };
+
+  // ---- compute side ---------------------------------------------------------------------------------------------------
+  f32x16 acc[4][2];
+  const int lane_off = (4 * lh * a.ldt + lr) * 4;
+  // this half's tile of supertile idx exists?
+  auto tile_ok = [&](int idx, int t2) { return idx < hi && 2 * t2 + h < a.tiles_t; };
+  // accumulators <- residual tile of this half's tile of supertile idx (zeros when there is no residual / no such tile)
+  auto init_acc = [&](int idx) {
+    if constexpr (RES) {
+      int n, mt, t2;
+      decode(idx, n, mt, t2);
+      const int slab = a.M * a.ldt * 4;
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(a.res) + (size_t)n * a.M * a.ldt, 0, tile_ok(idx, t2) ? slab : 0, 0x00020000);
+      const int tile_off = ((mt * XB_M + wm * 128) * a.ldt + (2 * t2 + h) * XB_T + wt * 64) * 4;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rc = mi * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti)
+            acc[mi][ti][r] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, tile_off + rc * a.ldt * 4 + ti * 128, 0));
+        }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ti][r] = 0.f;
+    }
+  };
+  // hipcc waits for pending loads at the first use of a register; this empty use pins that wait (and keeps hipcc from
+  // restructuring the accumulators around the drain)
+  auto acc_fence = [&]() {
+    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]),
+                 "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
+  };
+
+  const unsigned char* const a_frag = smem + ((wm * 128 + lr) * XB_K + 8 * lh) * 2;
+  const unsigned char* const b_frag = smem + L::OFF_B + h * L::B_SLOT + ((wt * 64 + lr) * XB_K + 8 * lh) * 2;
+#ifdef PS_PP_STAMPS
+  unsigned long long st_f = 0, st_m = 0, st_prev = 0;
+#define PP_STAMP(bucket)                                                          \
+  if (a.stamps) {                                                                 \
+    unsigned long long now;                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory"); \
+    bucket += now - st_prev;                                                      \
+    st_prev = now;                                                                \
+  }
+#else
+#define PP_STAMP(bucket)
+#endif
+  // `after(mi)` runs behind the MFMAs of row block mi (mi = 0, 1, 2): the DMA pieces and the scalar bookkeeping of the
+  // iteration ride between MFMA blocks, where an LDS-DMA piece costs the stream ~60 cycles instead of several hundred
+  // in front of the first MFMA
+  auto compute = [&](int aslot, auto&& after) {
+    const unsigned char* sa = a_frag + aslot * L::A_SLOT;
+    bf16x8 bf[PLANES][2], af[2][PLANES];
+    // fragment reads in the order the MFMAs use them: (W1, x1), (W2, x0), (W0, x2), ...
+    constexpr int ORD_A[3] = {1, 2, 0}, ORD_B[3] = {1, 0, 2};
+#pragma unroll
+    for (int q = 0; q < PLANES; ++q) {
+      const int pa = PLANES == 3 ? ORD_A[q] : 0, pb = PLANES == 3 ? ORD_B[q] : 0;
+      af[0][pa] = *reinterpret_cast<const bf16x8*>(sa + pa * XB_M * XB_K * 2);
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+        bf[pb][ti] = *reinterpret_cast<const bf16x8*>(b_frag + (pb * XB_T + ti * 32) * XB_K * 2);
+    }
+    PP_STAMP(st_f)
+    if (a.ablate & 1) {
+      after(bic<0>{});
+      after(bic<1>{});
+      after(bic<2>{});
+      return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      // the next row block's weight fragments are requested before this block's MFMAs issue
+      if (mi < 3) {
+#pragma unroll
+        for (int p = 0; p < PLANES; ++p)
+          af[(mi + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(sa + ((p * XB_M + (mi + 1) * 32) * XB_K) * 2);
+      }
+      const bf16x8* f = af[mi & 1];
+      // smallest terms first; the two column blocks alternate so that consecutive MFMAs never share an accumulator
+      if constexpr (PLANES == 3) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], bf[1][ti], acc[mi][ti], 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], bf[0][ti], acc[mi][ti], 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], bf[2][ti], acc[mi][ti], 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], bf[0][ti], acc[mi][ti], 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], bf[1][ti], acc[mi][ti], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], bf[0][ti], acc[mi][ti], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (mi == 0) after(bic<0>{});
+      if (mi == 1) after(bic<1>{});
+      if (mi == 2) after(bic<2>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // finished tile of supertile idx: bias, statistics, stores; then the accumulators take the residual of this half's
+  // next tile.  Element (mi, ti, r) = row 128 wm + 32 mi + (r&3) + 8 (r>>2) + 4 lh, column 64 wt + 32 ti + lr.
+  auto drain = [&](int idx, int parity) {
+    int n, mt, t2, nn, nmt, nt2;
+    decode(idx, n, mt, t2);
+    decode(idx + 1, nn, nmt, nt2);
+    const bool ok = 2 * t2 + h < a.tiles_t;
+    const int m0 = mt * XB_M, t0 = (2 * t2 + h) * XB_T;
+    float fsum = 0.f, fsq = 0.f;
+    const int slab = a.M * a.ldt * 4;
+    const __amdgpu_buffer_rsrc_t yr =
+        __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)n * a.M * a.ldt, 0, ok ? slab : 0, 0x00020000);
     const int tile_off = ((m0 + wm * 128) * a.ldt + t0 + wt * 64) * 4;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(RES ? a.res : a.y) + (size_t)nn * a.M * a.ldt, 0, (RES && tile_ok(idx + 1, nt2)) ? slab : 0,
+        0x00020000);
+    [[maybe_unused]] const int ntile_off = ((nmt * XB_M + wm * 128) * a.ldt + (2 * nt2 + h) * XB_T + wt * 64) * 4;
     float cm[2];
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) cm[ti] = (t0 + wt * 64 + ti * 32 + lr < a.T) ? 1.f : 0.f;
+    const float* bl = bias_lds + parity * 2 * XB_M + wm * 128 + 4 * lh;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-      float bsum[16], rv[2][16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rc = mi * 32 + (r & 3) + 8 * (r >> 2);
-        const int moff = (m0 + wm * 128 + rc + 4 * lh) * 4;
-        bsum[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, moff, 0, 0)) +
-                  __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bnr, moff, 0, 0));
-        if constexpr (RES) {
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + mi * 32 + 8 * rq) +
+                         *reinterpret_cast<const f32x4*>(bl + XB_M + mi * 32 + 8 * rq);
 #pragma unroll
-          for (int ti = 0; ti < 2; ++ti)
-            rv[ti][r] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, tile_off + rc * a.ldt * 4 + ti * 128, 0));
-        }
-      }
+        for (int r3 = 0; r3 < 4; ++r3) {
+          const int r = rq * 4 + r3;
+          const int rc = mi * 32 + r3 + 8 * rq;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rc = mi * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-          float v = acc[mi][ti][r] + bsum[r];
-          if constexpr (STATS) {
-            const float vm = v * cm[ti];
-            fsum += vm;
-            fsq += vm * vm;
+          for (int ti = 0; ti < 2; ++ti) {
+            const float v = acc[mi][ti][r] + b4[r3];
+            if constexpr (STATS) {
+              const float vm = v * cm[ti];
+              fsum += vm;
+              fsq += vm * vm;
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, lane_off,
+                                                  tile_off + rc * a.ldt * 4 + ti * 128, 0);
+            if constexpr (RES)
+              acc[mi][ti][r] = __builtin_bit_cast(
+                  float, __builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, ntile_off + rc * a.ldt * 4 + ti * 128, 0));
+            else
+              acc[mi][ti][r] = 0.f;
           }
-          if constexpr (RES) v += rv[ti][r];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, lane_off,
-                                                tile_off + rc * a.ldt * 4 + ti * 128, 0);
+          // keep (store, reload) pairs in program order: hoisted reloads (or 128 pre-computed store values) would
+          // double the live accumulators
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
     if constexpr (STATS) {
       const double s = wave_sum((double)fsum), q = wave_sum((double)fsq);
-      if (lane == 0) {
+      if (lane == 0 && ok) {
         const int parts = a.tiles_m * a.tiles_t * 4;
-        const int part = (t.mt * a.tiles_t + t.tt) * 4 + wave;
+        const int part = (mt * a.tiles_t + 2 * t2 + h) * 4 + hw;
         double* dst = a.ostats + ((size_t)n * parts + part) * 2;
         dst[0] = s;
         dst[1] = q;
@@ -621,43 +746,130 @@ __global__ __launch_bounds__(512, 1) void conv1x1_bf16_ws_kernel(BfArgs a) {
     }
   };
 
-  int cks = 0, ctile = lo;
-  unsigned long long c_comp = 0, c_bar = 0, c_drain = 0, c_prev = 0;
-  if (a.stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_prev)::"memory");
-#define WS_STAMP(bucket)                                                          \
-  if (a.stamps) {                                                                 \
-    unsigned long long now;                                                       \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory"); \
-    bucket += now - c_prev;                                                       \
-    c_prev = now;                                                                 \
+  // ---- prologue: activations of steps 0 .. D-1, weights of steps 0 and 1, bias, residual of the first tile --------------
+  x_setup();
+  a_setup();
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    dma_x(j);
+    x_advance();
   }
-  for (int i = 0; i < total + 2; ++i) {
-    if (i >= 2) {
-      compute((i - 2) % NSLOT);
-      WS_STAMP(c_comp)
-      if (++cks == a.ksteps) {
-        drain(ws_tile(ctile, a.tiles_t, a.tiles_m));
-        WS_STAMP(c_drain)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = zero16;
-        cks = 0;
-        ++ctile;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  dma_a(0);
+  a_advance();
+  dma_a(1);
+  a_advance();
+  if (wave == 0) bias_dma(n_lo, mt_lo, 0);
+  init_acc(lo);
+  acc_fence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // tables, raw step 0 and the first weight slots are in LDS
+  stage_b(0);
+  stab += XB_K;  // (step 1 of the first supertile: S >= 2)
+  sk = 1;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (h == 1) {  // half 1 runs one phase behind
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    WS_STAMP(c_bar)
   }
-  if (a.stamps && tid == 0) {
-    unsigned long long* d = a.stamps + (size_t)blockIdx.x * 6;
-    d[0] = c_comp;
-    d[1] = c_bar;
-    d[4] = c_drain;
+
+#ifdef PS_PP_STAMPS
+  unsigned long long st_c = 0, st_s = 0, st_b = 0, st_d = 0, st_t0 = 0;
+  if (a.stamps) {
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0)::"memory");
+    st_prev = st_t0;
+  }
+#endif
+
+  // ---- main loop: [DMA issue] compute(g) | barrier X | [drain] stage(g+1) | barrier Y -------------------------------------
+  // Counted waits and drains: a drain puts >= 128 operations behind everything issued before it, so whatever was
+  // issued before a drain has landed once the drain's operations have been ISSUED (at most 63 stay in flight) and
+  // needs no wait; counting through it would wait for the drain's own traffic.  `sd` = iterations since the last
+  // drain; only operations issued after that drain are waited for, which gives its stores (and residual loads) two
+  // iterations in the background before anything queues behind them.
+  int ci = lo, ck = 0;  // compute: supertile, step
+  int parity = 0;       // bias-table parity of ci
+  int rx = 0;           // g % D: raw ring slot refilled this iteration (step g + D); step g + 1 is read from slot rx + 1
+  int ra = 0;           // g % NA: weight ring slot of step g
+  int sd = 1000;
+  for (int g = 0; g < total; ++g) {
+    int sl = ra + 2;  // weight ring slot of step g + 2 (its previous tenant, step g - 1, was last read a phase ago)
+    sl = sl >= NA ? sl - NA : sl;
+    compute(ra, [&](auto blk_c) {
+      constexpr int blk = decltype(blk_c)::value;
+      if constexpr (blk == 0) dma_x(rx);
+      if constexpr (blk == 1) dma_a(sl);
+      if constexpr (blk == 2) {
+        x_advance();
+        a_advance();
+      }
+    });
+    PP_STAMP(st_m)
+    // before barrier X: this wave's pieces of the raw activations of step g+1 (issued in iteration g-2) have landed;
+    // half 1 also its share of the weights of step g+1 (issued in iteration g-1; read by half 0 right after barrier Y,
+    // which half 1 meets straight from its MFMAs)
+    if (h == 0) {
+      if (sd == 1 || sd == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W_X) : "memory");
+    } else {
+      if (sd == 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W_A) : "memory");
+    }
+    PP_STAMP(st_c)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    PP_STAMP(st_b)
+    __builtin_amdgcn_s_setprio(3);
+    const int rs = rx + 1 == D ? 0 : rx + 1;
+    ++sd;
+    if (ck == S - 1) {
+      drain(ci, parity);
+      parity ^= 1;
+      sd = 0;
+      PP_STAMP(st_d)
+      stage_b(rs);
+      acc_fence();  // the wait for the residual loads belongs on THIS path, not in front of every iteration's MFMAs
+    } else {
+      stage_b(rs);
+    }
+    s_advance();
+    if (++ck == S) {
+      ck = 0;
+      ++ci;
+    }
+    rx = rs;
+    ra = ra + 1 == NA ? 0 : ra + 1;
+    // before barrier Y: half 0's share of the weights of step g+1 (issued in iteration g-1) has landed
+    if (h == 0 && sd >= 2)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W_A) : "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(0);
+    PP_STAMP(st_s)
+    if (h == 0 || g + 1 < total) {  // half 1 started one barrier late
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    PP_STAMP(st_b)
+  }
+#ifdef PS_PP_STAMPS
+  if (a.stamps && (tid & 255) == 0) {
+    unsigned long long now;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+    unsigned long long* d = a.stamps + ((size_t)blockIdx.x * 2 + h) * 6;
+    d[0] = now - st_t0;
+    d[1] = st_c + (st_f << 20) + (st_m << 42);  // < 2^20 / 2^22 / 2^22 ticks each
+    d[2] = st_s;
+    d[3] = st_b;
+    d[4] = st_d;
     d[5] = (unsigned long long)total;
   }
+#endif
 }
 
 static int bf16_cus() {
@@ -675,27 +887,29 @@ static int bf16_cus() {
 template <int PLANES>
 static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
   const bool stats = a.ostats != nullptr, res = a.res != nullptr;
-  // The wave-specialised persistent kernel is NOT the default yet: its producers need 3100-4200 cycles per K-step
-  // (integer divisions of the tile walk, un-pipelined table reads, queue moves) against 2000 for the consumers, and
-  // its drains are un-overlapped, so it is 25-40 % slower than the simple kernel (tools/stamp_bf16.py).  ps_debug_flags
-  // bit 27 selects it (tests run both); it also needs >= one tile per CU and a bounded utterance span per workgroup.
-  const long long ntiles = (long long)a.tiles_t * a.tiles_m * N;
-  const int G = (int)(ntiles < bf16_cus() ? ntiles : bf16_cus());
-  const long long per_wg = (ntiles + G - 1) / G, per_utt = (long long)a.tiles_t * a.tiles_m;
-  const bool ws = (g_debug_flags & (1 << 27)) && ntiles >= bf16_cus() && (per_wg + per_utt - 1) / per_utt + 1 <= WS_MAXU;
-  if (ws) {
-#define PS_WS(TRV, STV, RSV) \
-  hipLaunchKernelGGL((conv1x1_bf16_ws_kernel<PLANES, TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)
+  // The ping-pong kernel needs enough supertiles to give every CU work, K-steps to pipeline over, and a bounded
+  // utterance span per workgroup (prologue tables in LDS); everything else takes the simple kernel.  ps_debug_flags
+  // bit 27 forces the simple kernel (tests run both).
+  const int st_per = (a.tiles_t + 1) / 2;
+  const long long nsuper = (long long)st_per * a.tiles_m * N;
+  const int cus = bf16_cus();
+  const int G = (int)(nsuper < cus ? nsuper : cus);
+  const long long per_wg = (nsuper + G - 1) / G, per_utt = (long long)st_per * a.tiles_m;
+  const bool big = 2 * nsuper >= cus || (g_debug_flags & (1 << 28));  // bit 28: ping-pong kernel at any size (tests)
+  const bool pp = !(g_debug_flags & (1 << 27)) && a.ksteps >= 4 && big && (per_wg + per_utt - 2) / per_utt + 1 <= PP_MAXU;
+  if (pp) {
+#define PS_PP(TRV, STV, RSV) \
+  hipLaunchKernelGGL((conv1x1_bf16_pp_kernel<PLANES, TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)
     if (tr) {
-      if (stats) PS_WS(true, true, false);
-      else if (res) PS_WS(true, false, true);
-      else PS_WS(true, false, false);
+      if (stats) PS_PP(true, true, false);
+      else if (res) PS_PP(true, false, true);
+      else PS_PP(true, false, false);
     } else {
-      if (stats) PS_WS(false, true, false);
-      else if (res) PS_WS(false, false, true);
-      else PS_WS(false, false, false);
+      if (stats) PS_PP(false, true, false);
+      else if (res) PS_PP(false, false, true);
+      else PS_PP(false, false, false);
     }
-#undef PS_WS
+#undef PS_PP
     return;
   }
   dim3 grid(a.tiles_t, a.tiles_m, N);

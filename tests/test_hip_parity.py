@@ -730,7 +730,7 @@ def test_fused_streaming_step_kernels(H, dev):
 @pytest.mark.parametrize("n,k,m,t,mode", [(2, 24, 12, 77, "plain"), (2, 256, 256, 500, "norm_stats"),
                                           (1, 256, 512, 300, "norm_res"), (2, 512, 256, 129, "stats"),
                                           (1, 40, 300, 128, "affine"),
-                                          # >= 256 tiles: the wave-specialised persistent kernel, runs across utterances
+                                          # many tiles: the persistent ping-pong kernel, runs across utterances, odd tile counts
                                           (9, 64, 256, 3800, "norm_stats"), (5, 48, 512, 3700, "norm_res"),
                                           (9, 40, 200, 3800, "plain")])
 def test_conv1x1_bf16_planes(H, dev, planes, tol, n, k, m, t, mode):
@@ -753,8 +753,8 @@ def test_conv1x1_bf16_planes(H, dev, planes, tol, n, k, m, t, mode):
     want = mode in ("norm_stats", "stats")
     if res is not None:
         ref = ref + res.double()
-    # flag bit 27 = the wave-specialised persistent variant (taken only when there is at least one tile per CU)
-    for flags in (0, 1 << 27):
+    # flag bit 27 = simple kernel only, bit 28 = the persistent ping-pong kernel at any size
+    for flags in (0, 1 << 27, 1 << 28):
         old = _abi.lib().ps_debug_flags(flags)
         try:
             y, st = H.conv1x1_bf16(H.pad_rows(x.to(dev)), t, H.pack_wt_bf16(w.to(dev), planes), m, pro, b.to(dev), None,

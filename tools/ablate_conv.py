@@ -42,7 +42,7 @@ for name, (K, M, pro, res) in shapes.items():
         res_line.append(f"{fname}={us:.0f}us")
     lib.ps_debug_flags(0)
     for planes, abl in ((3, 0), (3, 8), (1, 0), (1, 8)):
-        lib.ps_debug_flags(abl << 24)  # abl 8 = bit 27: wave-specialised persistent kernel
+        lib.ps_debug_flags(abl << 24)  # abl 8 = bit 27: simple (non-persistent) kernel
         wb = hip.pack_wt_bf16(torch.randn(M, K, device=dev) * 0.05, planes)
         for _ in range(3):
             hip.conv1x1_bf16(x, T, wb, M, p, bias, None, r, want_stats=not res, out=y)

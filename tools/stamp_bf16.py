@@ -6,6 +6,8 @@ from puresound_amd import hip, _abi
 dev = torch.device("cuda:0"); lib = _abi.lib()
 N, T = 32, 3999; ldt = _abi.padded_frames(T)
 shapes = {"in": (512, 256, False, False), "pw": (256, 256, True, False), "out": (256, 512, True, True)}
+ABL = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+lib.ps_debug_flags(ABL << 24)
 for planes in (3, 1):
     for name, (K, M, pro, res) in shapes.items():
         x = torch.randn(N, K, ldt, device=dev); wb = hip.pack_wt_bf16(torch.randn(M, K, device=dev) * 0.05, planes)
@@ -23,12 +25,16 @@ for planes in (3, 1):
         hip.conv1x1_bf16(x, T, wb, M, p, bias, None, r, want_stats=not res, out=y)
         torch.cuda.synchronize(); lib.ps_debug_buffer(None)
         s = buf.cpu().numpy().reshape(nwg, 6).astype(np.int64)
-        if lib.ps_debug_flags(-1) & (1 << 27):  # wave-specialised kernel: one record per CU-resident workgroup
-            s = s[:256]
-            tot = np.maximum(s[:, 5], 1)
-            print(f"bf16x{planes} {name} [ws]: ticks/WG {int(np.median(tot))}; per tick med: consumer compute {np.median(s[:,0]/tot):.0f} "
-                  f"consumer barrier-wait {np.median(s[:,1]/tot):.0f} | producer stage {np.median(s[:,2]/tot):.0f} producer "
-                  f"barrier-wait {np.median(s[:,3]/tot):.0f}; drain total/WG {np.median(s[:,4]):.0f}")
+        if not (lib.ps_debug_flags(-1) & (1 << 27)):  # ping-pong kernel: one record per (workgroup, half)
+            s = s[:512]
+            for h in (0, 1):
+                q = s[h::2]
+                tot = np.maximum(q[:, 5], 1)
+                tiles = tot / ((K + 15) // 16)
+                wv, fr, mf = q[:, 1] & ((1 << 20) - 1), (q[:, 1] >> 20) & ((1 << 22) - 1), q[:, 1] >> 42
+                print(f"bf16x{planes} {name} [pp half {h}]: steps/WG {int(np.median(tot))} total cyc {int(np.median(q[:,0]))}; per step med: "
+                      f"frag+dma {np.median(fr/tot):.0f} mfma {np.median(mf/tot):.0f} wait {np.median(wv/tot):.0f} stage {np.median(q[:,2]/tot):.0f} barrier-wait {np.median(q[:,3]/tot):.0f}; "
+                      f"drain per tile {np.median(q[:,4]/tiles):.0f}")
             continue
         span = s[:, 5].max() - s[:, 0].min()
         ks = (K + 15) // 16
