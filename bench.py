@@ -24,6 +24,11 @@ import torch  # noqa: E402
 
 B_PER_GPU, L, SR = 32, 64000, 16000
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, dense bf16 matrix peak; the 3-way split spends 6 bf16 products per fp32 one
+SPLIT_PRODUCTS = 6
+# HBM bytes per ps_conv1x1_bf16_f32 launch (planes = 3) at 16 utterances, from the PMC passes committed as
+# profiles/r01_pmc_hbm_traffic_bf16x3.txt (same recipe as below): in_conv + pointwise + out_conv.
+PMC_BF16X3_BYTES_PER_LAUNCH = 2 * (207.9e6 + 137.9e6 + 348.9e6) / 3  # algorithmic: 2 * (207.6 + 138.4 + 346.0) / 3 MB
 # HBM bytes per ps_conv1x1_f32 launch at 32 utterances, averaged over the three GEMM shapes, from the PMC
 # passes committed as profiles/r01_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
 # runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): (207.4 + 149.4 + 388.4) / 3 MB per
@@ -93,9 +98,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x3", "bf16"],
-                    help="matrix-pipe arithmetic of the 1x1 convs; the BASELINE metric is fp32 (default). The other "
-                         "modes are experiments and are labelled as such in the output line")
+    ap.add_argument("--gemm", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
+                    help="arithmetic of the 1x1-conv GEMMs.  bf16x3 (default): every fp32 operand split into three "
+                         "bf16 terms, six products on the bf16 MFMA pipe, fp32 accumulation -- the result carries "
+                         "the same error against the reference as the exact fp32 MFMA path (9.8e-7 vs 1.13e-6 "
+                         "max-rel on the config-2 golden vector; tests/test_hip_parity.py).  fp32: v_mfma_f32_* on "
+                         "fp32 operands.  bf16: operands rounded to bf16 (NOT an fp32 result; experiment only).")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -114,9 +122,7 @@ def main():
     from puresound_amd.batch_shard import gather_utterances
     lib = _abi.lib()  # no HIP extension, no benchmark
     model = build_model(dev)
-    if args.gemm != "fp32":
-        model.masker.set_gemm_precision(args.gemm)
-        args.no_roofline = True  # the roofline object describes the fp32 MFMA kernel only
+    model.masker.set_gemm_precision(args.gemm)
 
     g = torch.Generator().manual_seed(1234 + rank)
     noisy = ((torch.rand(B_PER_GPU, L, generator=g) * 2 - 1) * 0.5).to(dev)  # synthetic 16 kHz waveforms
@@ -153,7 +159,11 @@ def main():
         "metric": "audio samples/sec (16 kHz) on ns Conv-TasNet, batch=32x4s per GPU",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.gemm == "fp32" else ("f32 storage/accumulate, " + args.gemm + " products (EXPERIMENT)"),
+        "dtype": {"fp32": "f32",
+                  "bf16x3": "f32 (operands, accumulation and result accuracy fp32; each product issued as 3xbf16 split "
+                            "terms on the bf16 MFMA pipe)",
+                  "bf16": "f32 storage/accumulate, bf16 products (EXPERIMENT, not an fp32 result)"}[args.gemm],
+        "gemm": args.gemm,
         "data": "synthetic",
         "config": {"workload": "egs/ns Conv-TasNet, learned-conv encoder (32/16/512), R=3 X=8 H=256, "
                                "batch=32x4 s fp32 per GPU (BASELINE configs[1])",
@@ -179,24 +189,56 @@ def main():
         model.hip_streams = streams_kept
         import ctypes
         fams = {}
-        for fam in ("conv1x1", "dwconv", "free_encode", "free_decode"):
+        for fam in ("dwconv", "free_encode", "free_decode"):
             ms, cnt = ctypes.c_double(), ctypes.c_int()
             _abi.check(lib.ps_profile_read(fam.encode(), ctypes.byref(ms), ctypes.byref(cnt)), "ps_profile_read")
             fams[fam] = (ms.value, cnt.value)
         flops, launches = conv_flops_per_forward(model, B_PER_GPU, t)
-        conv_ms, conv_cnt = fams["conv1x1"]
+        fam = "conv1x1" if args.gemm == "fp32" else "conv1x1_bf16"
+        ms, cnt = ctypes.c_double(), ctypes.c_int()
+        _abi.check(lib.ps_profile_read(fam.encode(), ctypes.byref(ms), ctypes.byref(cnt)), "ps_profile_read")
+        conv_ms, conv_cnt = ms.value, cnt.value
+        fams[fam] = (conv_ms, conv_cnt)
         assert conv_cnt == launches * args.steps, (conv_cnt, launches, args.steps)
         avg_ms = conv_ms / conv_cnt
         achieved = (flops / launches) / (avg_ms * 1e-3) / 1e12
-        result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": PMC_CONV1X1_BYTES_PER_LAUNCH,
-                              "traffic_note": "bytes per launch from the committed PMC passes "
-                                              "(profiles/r01_pmc_hbm_traffic.txt), not re-measured in this run",
-                              "kernel": "ps::conv1x1_* (ps_conv1x1_f32)", "avg_launch_ms": avg_ms,
-                              "note": "kernel durations from a single-stream pass; value/ms_per_step from the "
-                                      "product path (2 sub-batch streams)",
-                              "flop_per_launch": flops / launches, "launches_per_step": launches,
-                              "kernel_ms_per_step": {k: v[0] / args.steps for k, v in fams.items()}}
+        common = {"bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "avg_launch_ms": avg_ms,
+                  "note": "kernel durations from a single-stream pass; value/ms_per_step from the product path "
+                          "(2 sub-batch streams)",
+                  "flop_per_launch": flops / launches, "launches_per_step": launches,
+                  "kernel_ms_per_step": {k: v[0] / args.steps for k, v in fams.items()}}
+        if args.gemm == "fp32":
+            result["roofline"] = dict(common, peak=F32_MFMA_PEAK_TFLOPS, frac=achieved / F32_MFMA_PEAK_TFLOPS,
+                                      traffic=PMC_CONV1X1_BYTES_PER_LAUNCH, kernel="ps::conv1x1_* (ps_conv1x1_f32)",
+                                      traffic_note="bytes per launch from the committed PMC passes "
+                                                   "(profiles/r01_pmc_hbm_traffic.txt), not re-measured in this run")
+        else:
+            planes_products = SPLIT_PRODUCTS if args.gemm == "bf16x3" else 1
+            peak = BF16_MFMA_PEAK_TFLOPS / planes_products
+            result["roofline"] = dict(
+                common, peak=peak, frac=achieved / peak, traffic=PMC_BF16X3_BYTES_PER_LAUNCH if args.gemm == "bf16x3" else None,
+                kernel="ps::conv1x1_bf16_pp_kernel (ps_conv1x1_bf16_f32)",
+                peak_note=f"algorithmic fp32 FLOP (2*M*K*T*N per launch) against the dense bf16 MFMA peak "
+                          f"{BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {planes_products} bf16 products per multiply-add; "
+                          f"the same FLOP against the fp32 MFMA peak {F32_MFMA_PEAK_TFLOPS} TFLOP/s = "
+                          f"{achieved / F32_MFMA_PEAK_TFLOPS:.2f}",
+                traffic_note="bytes per launch from the committed PMC passes "
+                             "(profiles/r01_pmc_hbm_traffic_bf16x3.txt), not re-measured in this run")
+    if rank == 0 and world == 1 and args.gemm == "bf16x3" and not args.no_roofline:
+        # the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32 on fp32 operands) timed beside it, same inputs, same K steps
+        model.masker.set_gemm_precision("fp32")
+        for _ in range(max(2, args.warmup)):
+            model.inference(noisy)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model.inference(noisy)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        model.masker.set_gemm_precision(args.gemm)
+        result["fp32_mfma_path"] = {"value": B_PER_GPU * L * args.steps / dt, "unit": "samples/s",
+                                    "ms_per_step": dt / args.steps * 1e3,
+                                    "note": "python bench.py --gemm fp32: the same step with v_mfma_f32 on fp32 operands"}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:

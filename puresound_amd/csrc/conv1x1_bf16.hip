@@ -809,13 +809,15 @@ __global__ __launch_bounds__(512, 1) void conv1x1_bf16_pp_kernel(BfArgs a) {
     // before barrier X: this wave's pieces of the raw activations of step g+1 (issued in iteration g-2) have landed;
     // half 1 also its share of the weights of step g+1 (issued in iteration g-1; read by half 0 right after barrier Y,
     // which half 1 meets straight from its MFMAs)
+    // (`sd` still holds last iteration's count here: 0 = the drain ran in iteration g-1, 1 = in iteration g-2, both
+    //  AFTER the operations waited for were issued; a drain in g-3 or earlier lies before them and hides nothing)
     if (h == 0) {
-      if (sd == 1 || sd == 2)
+      if (sd <= 1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W_X) : "memory");
     } else {
-      if (sd == 1)
+      if (sd == 0)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W_A) : "memory");
@@ -844,7 +846,8 @@ __global__ __launch_bounds__(512, 1) void conv1x1_bf16_pp_kernel(BfArgs a) {
     }
     rx = rs;
     ra = ra + 1 == NA ? 0 : ra + 1;
-    // before barrier Y: half 0's share of the weights of step g+1 (issued in iteration g-1) has landed
+    // before barrier Y: half 0's share of the weights of step g+1 (issued in iteration g-1) has landed (sd is up to
+    // date here: 0 = drained just now, 1 = in iteration g-1)
     if (h == 0 && sd >= 2)
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W_A) : "memory");
     else
