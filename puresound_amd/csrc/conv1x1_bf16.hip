@@ -521,7 +521,10 @@ __global__ __launch_bounds__(512, 1) void conv1x1_bf16_pp_kernel(BfArgs a) {
     if (wave == 0 && si < hi) bias_dma(n, mt, spar);
   };
   auto stage_b = [&](int slot) {
-    if (si >= hi || (a.ablate & 4)) return;
+    if (si >= hi) return;
+#ifdef PS_PP_STAMPS
+    if (a.ablate & 4) return;
+#endif
     const float* raw = raw_r + slot * (L::RAW / 4);
     float v[8];
 #pragma unroll
@@ -643,12 +646,14 @@ __global__ __launch_bounds__(512, 1) void conv1x1_bf16_pp_kernel(BfArgs a) {
         bf[pb][ti] = *reinterpret_cast<const bf16x8*>(b_frag + (pb * XB_T + ti * 32) * XB_K * 2);
     }
     PP_STAMP(st_f)
+#ifdef PS_PP_STAMPS
     if (a.ablate & 1) {
       after(bic<0>{});
       after(bic<1>{});
       after(bic<2>{});
       return;
     }
+#endif
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       // the next row block's weight fragments are requested before this block's MFMAs issue
