@@ -380,6 +380,14 @@ int ps_conv_tasnet_f32(const ps_tcn_block* blocks_host, int n_blocks, const floa
                        const float* dvec, int embed_norm, int N, int T, int ldt, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* Five moments of an (estimate, reference) waveform pair per row -- sum a, sum b, sum a^2, sum b^2, sum ab over L
+ * samples, fp64 -- as per-workgroup partials [N][ps_wave_moments_chunks(L)][5] (the caller adds them up).  Every
+ * SDR / SI-SNR variant of the reference's SDRLoss.forward (puresound/nnet/loss/sdr.py:104-183), si_snr (:263-299) and
+ * inactive_sdr_loss (:302-322) is algebra on these moments, so the mean / subtract / project / square / sum passes of
+ * the reference become one streaming pass.  lda / ldb: row strides in floats. */
+int ps_wave_moments_chunks(int L);
+int ps_wave_moments_f64(const float* a, const float* b, double* partials, int N, int L, int lda, int ldb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,8 @@ SIGNATURES = {
     "ps_chan_layernorm_f32": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
     "ps_film_apply_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
     "ps_embed_bias_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "ps_wave_moments_chunks": (C.c_int, [C.c_int]),
+    "ps_wave_moments_f64": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
     "ps_conv_tasnet_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "ps_conv_tasnet_f32": (C.c_int, [C.POINTER(TcnBlock), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                      C.c_int, _vp, C.c_size_t, _vp]),

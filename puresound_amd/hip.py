@@ -474,6 +474,25 @@ def add_position(x: torch.Tensor, pe: torch.Tensor, q: int, q_stride: int, lengt
     return y
 
 
+def wave_moments(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Rows of two waveform batches [R, L] (last-dim contiguous) -> fp64 moments [R, 5] = (sum a, sum b, sum a^2,
+    sum b^2, sum ab) in one streaming pass (ps_wave_moments_f64)."""
+    require_device(a, "wave_moments")
+    require_device(b, "wave_moments")
+    if a.dim() != 2 or a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise RuntimeError("wave_moments: two fp32 tensors of the same shape [R, L]")
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if b.stride(1) != 1:
+        b = b.contiguous()
+    r, length = a.shape
+    chunks = lib().ps_wave_moments_chunks(length)
+    part = torch.empty(r, chunks, 5, dtype=torch.float64, device=a.device)
+    check(lib().ps_wave_moments_f64(ptr(a), ptr(b), ptr(part), r, length, a.stride(0), b.stride(0),
+                                    stream_ptr(a.device)), "ps_wave_moments_f64")
+    return part.sum(1)
+
+
 def lstm_cell(gates: torch.Tensor, c: torch.Tensor, h: torch.Tensor, hidden: int, dirs: int, t: int) -> None:
     """One cell update per (unit, frame): gates padded [N,D*4H,ld] (complete pre-activations), c in place, h out
     (both [N,D*H,ld'] rows, possibly views into larger row blocks)."""

@@ -1,7 +1,8 @@
 """Mirror of the inference side of `puresound.nnet` (see the module docstrings for file:line parity)."""
 from types import SimpleNamespace
 
-from .base_nn import SoTaskWrapModule
+from .base_nn import SiMoTaskWrapModule, SoTaskWrapModule
+from .loss.sdr import SDRLoss
 from .conv_tasnet import TCN, ConvTasNet, GatedTCN
 from .dprnn import DPRNN
 from .lobe.encoder import ConvEncDec, FbankEnc, FreeEncDec
@@ -22,7 +23,7 @@ class _Namespace(SimpleNamespace):
         raise AttributeError(name)
 
 
-NS = _Namespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
+NS = _Namespace(SoTaskWrapModule=SoTaskWrapModule, SiMoTaskWrapModule=SiMoTaskWrapModule, SDRLoss=SDRLoss, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                      ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                      AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM, MemLSTM=MemLSTM, Unet=Unet, UnetTcn=UnetTcn,
                 DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, DPARN=DPARN, DPARNblock2D=DPARNblock2D,

@@ -229,6 +229,10 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             cur.wait_stream(s)
         return out
 
+    def _align_waveform(self, enh_wav: torch.Tensor, ref_wav: torch.Tensor):
+        """base_nn.py:398-412: a shorter reference is left-padded with zeros, a longer one cuts the estimate."""
+        return _align_waveform(enh_wav, ref_wav)
+
     # -- speaker branch (base_nn.py:697-705, 724-738) ---------------------------------------------------
     def _speaker_embedding_from_feats(self, x: torch.Tensor, t: int) -> torch.Tensor:
         """speaker_net layer by layer on padded enrolment features (base_nn.py:697-705): Magnitude, TCN (consecutive
@@ -305,3 +309,97 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         self.train()
         print(f"Current training mode is: {self.training}")
         print("---------------Verbose logging---------------")
+
+
+
+def _align_waveform(enh_wav: torch.Tensor, ref_wav: torch.Tensor):
+    enh_l, ref_l = enh_wav.shape[-1], ref_wav.shape[-1]
+    if enh_l != ref_l:
+        if ref_l < enh_l:
+            ref_wav = torch.nn.functional.pad(ref_wav, (enh_l - ref_l, 0))  # align from last
+        else:
+            enh_wav = enh_wav[..., :ref_l]                                  # align from begin
+    return enh_wav, ref_wav
+
+
+class SiMoTaskWrapModule(EncDecMaskerBaseModel):
+    """Single input, multi output (speech separation) wrapper, inference side of base_nn.py:780-939: the masker returns
+    M masks [N, M, C, T] for one mixture; every (utterance, source) pair is masked and decoded like a row of a batch of
+    N*M utterances, so mask constraint, mask multiply, decoder GEMV + overlap-add and the output constraint run in the
+    same fused decoder launch as the single-output path.  `forward(noisy, ref_clean, inactive_labels)` returns the
+    signal loss of the estimate (forward only; the HIP path has no autograd)."""
+
+    def __init__(self, encoder: nn.Module, masker: nn.Module, loss_func_wav: Optional[nn.Module] = None,
+                 f_type: str = "real", mask_type: str = "real", mask_constraint: str = "linear",
+                 output_constraint: str = "linear", drop_first_bin: bool = False, verbose: bool = True) -> None:
+        super().__init__()
+        self.f_type = f_type
+        self.mask_type = mask_type
+        self.encoder = encoder
+        self.masker = masker
+        self.loss_func_wav = loss_func_wav
+        self.mask_constraint = mask_constraint
+        self.output_constraint = output_constraint
+        self.drop_first_bin = drop_first_bin
+        if verbose:
+            print(f"Total params: {self.overall_parameters}")
+
+    def _align_waveform(self, enh_wav: torch.Tensor, ref_wav: torch.Tensor):
+        return _align_waveform(enh_wav, ref_wav)
+
+    @torch.no_grad()
+    def inference(self, noisy: torch.Tensor) -> torch.Tensor:
+        """noisy [N, L] -> separated waveforms [N, M, L_out] (base_nn.py:922-939)."""
+        hip.require_device(noisy, "SiMoTaskWrapModule.inference")
+        mask_act = self.check_mask_constraint(self.mask_constraint)
+        pairing = self.check_mask_pairing(self.mask_type, self.f_type)
+        out_mode = self.output_constraint.lower()
+        if out_mode not in ("linear", "sigmoid"):
+            raise NameError("Non support type.")
+        stft = isinstance(self.encoder, ConvEncDec)
+        if stft and pairing not in ("complex", "real"):
+            raise NotImplementedError("HIP inference path with an STFT encoder: (complex, complex) or (real, real)")
+        if not stft and (not isinstance(self.encoder, FreeEncDec) or pairing != "real"):
+            raise NotImplementedError("HIP inference path: FreeEncDec encoder with (real, real) masks")
+        noisy = noisy.contiguous()
+        if stft:
+            enc = self.encoder.encoder
+            feats, t = enc.encode_padded(noisy, self.drop_first_bin)
+        else:
+            feats, t = self.encoder.encode_padded(noisy)
+        mask = self.masker(feats[..., :t])  # any masker with the reference contract: [N, C, T] -> [N, M, C, T]
+        assert mask.dim() == 4, "SIMO task needed 4D tensor has shape [N, Ch, C, T]"
+        batch, chout, fdim, tdim = mask.shape
+        if fdim != feats.shape[1] or tdim != t:
+            raise RuntimeError(f"SiMo masker returned {tuple(mask.shape)} for features [{batch}, {feats.shape[1]}, {t}]")
+        mask_pad = hip.pad_rows(mask.reshape(batch * chout, fdim, tdim).float())
+        if mask_pad.shape[-1] != feats.shape[-1]:
+            raise RuntimeError("SiMo: padded mask rows do not match the feature rows")
+        feats_rep = feats.repeat_interleave(chout, dim=0)  # noisy.unsqueeze(1).repeat(1, chout, 1, 1), base_nn.py:929
+        if stft:
+            if pairing == "complex":
+                enh = hip.complex_mask(feats_rep, mask_pad, mask_act)
+                # base_nn.py:934 reshapes the complex product [N*M, F, T, 2] to [N, M, 2F, T]: the interleaved
+                # (re, im) pairs are re-read as 2F rows of T frames.  That is the arithmetic a model trained with the
+                # reference has seen, so it is reproduced (a gather on the small masked spectrum, off the hot path)
+                half = fdim // 2
+                pairs = torch.stack([enh[:, :half, :t], enh[:, half:, :t]], dim=-1)
+                enh = hip.pad_rows(pairs.reshape(batch * chout, fdim, t).contiguous())
+            else:
+                enh = hip.real_mask(feats_rep, mask_pad, mask_act)
+            wav = enc.decode_padded(enh, t, self.drop_first_bin, out_mode)
+        else:
+            wav = self.encoder.decode_padded(feats_rep, t, mask_pad, mask_act, out_mode)
+        return wav.reshape(batch, chout, -1)
+
+    @torch.no_grad()
+    def forward(self, noisy: torch.Tensor, ref_clean: torch.Tensor,
+                inactive_labels: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """base_nn.py:899-920 without autograd: separated estimate -> align -> loss_func_wav([N*M, L], [N*M, L])."""
+        if self.loss_func_wav is None:
+            raise RuntimeError("SiMoTaskWrapModule.forward needs loss_func_wav")
+        enh = self.inference(noisy)
+        batch, chout = enh.shape[:2]
+        enh, ref_clean = self._align_waveform(enh, ref_clean)
+        labels = None if inactive_labels is None else inactive_labels.reshape(-1)
+        return self.loss_func_wav(enh.reshape(batch * chout, -1), ref_clean.reshape(batch * chout, -1), labels)

@@ -261,6 +261,17 @@ CASES = {
                                                       output_format="Magnitude", n_banks=20), B=2, L=700, seed=20),
     "enc_stft": dict(kind="encdec", enc=dict(kind="stft", n_fft=64, hop=16, drop_first_bin=False),
                      B=2, L=400, seed=18),
+    # ---- signal scores (loss/sdr.py) and the multi-output wrapper (base_nn.py:780-939), SURVEY 8(f) row 4 ----
+    "loss_sdr_modes": dict(kind="loss", B=5, M=3, L=4000, seed=71),
+    "simo_free": dict(kind="simo", enc=dict(kind="free", win=16, hop=8, C=24), heads=2,
+                      masker=masker_args(24, 0, False, [0, 0], tcn_kernel=3, tcn_dim=12, repeat_tcn=2,
+                                         tcn_dilated_basic=2, per_tcn_stack=2),
+                      wrap=dict(mask_constraint="ReLU"), B=2, L=1500, L_ref=1400, seed=73),
+    "simo_stft": dict(kind="simo", enc=dict(kind="stft", n_fft=32, hop=8, drop_first_bin=True), heads=2,
+                      masker=masker_args(32, 0, False, [0, 0], tcn_kernel=3, tcn_dim=12, repeat_tcn=1,
+                                         tcn_dilated_basic=2, per_tcn_stack=2),
+                      wrap=dict(mask_constraint="linear", f_type="Complex", mask_type="Complex", drop_first_bin=True),
+                      B=2, L=1200, L_ref=1100, seed=74),
 }
 
 # parameter counts measured on the reference itself by make_golden.py (its docstrings quote 13 372 725 for
@@ -283,6 +294,23 @@ def build_masker(ns, m):
         return getattr(ns, m["cls"])(*m["args"], **m["kw"])
     kw = {k: v for k, v in m.items() if k not in ("input_dim", "embed_dim", "embed_norm")}
     return ns.ConvTasNet(m["input_dim"], m["embed_dim"], m["embed_norm"], **kw)
+
+
+def build_simo_masker(ns, c):
+    """A separation masker with the contract SiMoTaskWrapModule expects ([N, C, T] -> [N, M, C, T]): M independent
+    Conv-TasNet heads on the same features (keys `masker.heads.{m}.*`)."""
+    import torch
+    import torch.nn as nn
+
+    class Heads(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.heads = nn.ModuleList([build_masker(ns, c["masker"]) for _ in range(c["heads"])])
+
+        def forward(self, x):
+            return torch.stack([h(x) for h in self.heads], dim=1)
+
+    return Heads()
 
 
 def build_speaker_net(ns, s):
@@ -309,6 +337,10 @@ def build(ns, name):
             kw["encoder_spk"] = ns.FbankEnc(**c["enc_spk"]["kw"])
         return ns.SoTaskWrapModule(encoder=build_encoder(ns, c["enc"]), masker=build_masker(ns, c["masker"]),
                                    verbose=False, **kw)
+    if c["kind"] == "simo":
+        return ns.SiMoTaskWrapModule(encoder=build_encoder(ns, c["enc"]), masker=build_simo_masker(ns, c),
+                                     loss_func_wav=ns.SDRLoss.init_mode("sisnr", reduction=False), verbose=False,
+                                     **c["wrap"])
     if c["kind"] == "masker":
         return build_masker(ns, c["masker"])
     if c["kind"] == "encdec":
@@ -358,6 +390,10 @@ def oracle_cfg(name):
     """The oracle's description of a wrapper case."""
     c = CASES[name]
     enc = dict(c["enc"])
+    if c["kind"] == "simo":
+        cfg = dict(encoder=enc, masker=full_masker_args(c["masker"]), heads=c["heads"])
+        cfg.update({k: v for k, v in c["wrap"].items() if k != "drop_first_bin"})
+        return cfg
     if c["masker"].get("cls") in ("Unet", "UnetTcn", "DPCRN", "DPARN"):
         cfg = dict(encoder=enc, masker=unet_args(c["masker"]), masker_kind=c["masker"]["oracle"])
     elif "cls" in c["masker"]:
@@ -393,3 +429,21 @@ def build_demo(ns, c):
     net.encoder = ns.FreeEncDec(win_length=h["win"], hop_length=h["hop"], laten_length=h["C"], output_active=True)
     net.masker = ns.StreamingSkiM(*c["args"], **c["kw"])
     return net
+
+
+def loss_inputs(c):
+    """Deterministic (estimate, reference) pairs of the loss case: reference = uniform noise with a per-row offset,
+    estimate = gain * reference + noise at per-row levels from -5 dB to +60 dB (the last row nearly identical), and
+    the [B, M, L] tensors of the source-aggregated modes."""
+    import numpy as np
+    import torch
+    g = np.random.Generator(np.random.Philox(key=c["seed"]))
+    b, m, length = c["B"], c["M"], c["L"]
+    ref3 = g.uniform(-0.5, 0.5, (b, m, length)) + g.uniform(-0.05, 0.05, (b, m, 1))
+    noise = g.uniform(-0.5, 0.5, (b, m, length))
+    snr_db = np.linspace(-5.0, 60.0, b * m).reshape(b, m, 1)
+    gain = g.uniform(0.5, 1.5, (b, m, 1))
+    est3 = gain * ref3 + noise * 10 ** (-snr_db / 20) + g.uniform(-0.02, 0.02, (b, m, 1))
+    est3, ref3 = torch.tensor(est3, dtype=torch.float32), torch.tensor(ref3, dtype=torch.float32)
+    labels = torch.tensor([False, True, False, False, True][:b] + [False] * max(0, b - 5))
+    return est3[:, 0].contiguous(), ref3[:, 0].contiguous(), est3, ref3, labels

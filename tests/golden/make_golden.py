@@ -29,7 +29,8 @@ if "torchaudio" not in sys.modules:
     sys.modules["torchaudio"] = ta
     sys.modules["torchaudio.functional"] = taf
 
-from puresound.nnet.base_nn import SoTaskWrapModule  # noqa: E402
+from puresound.nnet.base_nn import SiMoTaskWrapModule, SoTaskWrapModule  # noqa: E402
+from puresound.nnet.loss.sdr import SDRLoss, inactive_sdr_loss, si_snr  # noqa: E402
 from puresound.nnet.conv_tasnet import TCN, ConvTasNet, GatedTCN  # noqa: E402
 from puresound.nnet.lobe.encoder import ConvEncDec, FbankEnc, FreeEncDec  # noqa: E402
 from puresound.nnet.lobe.pooling import AttentiveStatisticsPooling  # noqa: E402
@@ -44,7 +45,7 @@ from puresound.nnet.lobe.trivial import Magnitude  # noqa: E402
 import cases  # noqa: E402
 from detweights import det_state_dict, det_wave  # noqa: E402
 
-REF = cases.namespace(SoTaskWrapModule=SoTaskWrapModule, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
+REF = cases.namespace(SoTaskWrapModule=SoTaskWrapModule, SiMoTaskWrapModule=SiMoTaskWrapModule, SDRLoss=SDRLoss, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                       ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                       AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM,
                       StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN, DPARN=DPARN,
@@ -223,11 +224,45 @@ def run_stream(name, c):
     return out
 
 
+@torch.no_grad()
+def run_loss(name, c):
+    """Every SDRLoss alias (per-row values), the inactive-label path, a thresholded run, si_snr, inactive_sdr_loss."""
+    est, ref, est3, ref3, labels = cases.loss_inputs(c)
+    out = {}
+    for mode in ("sisnr", "sdsdr", "sdr", "tsdr", "sasdr", "sasisnr", "satsdr"):
+        agg = mode.startswith("sa")
+        a, b = (est3, ref3) if agg else (est, ref)
+        out[mode] = SDRLoss.init_mode(mode, reduction=False)(a.clone(), b.clone()).numpy()
+        out[mode + "_mean"] = SDRLoss.init_mode(mode, reduction=True)(a.clone(), b.clone()).numpy()
+    out["sisnr_inactive"] = SDRLoss.init_mode("sisnr", reduction=False)(est.clone(), ref.clone(), labels).numpy()
+    out["sisnr_threshold"] = SDRLoss.init_mode("sisnr", reduction=False, threshold=-20.0)(est.clone(), ref.clone()).numpy()
+    out["raw_no_zero_mean"] = SDRLoss(scaled=True, zero_mean=False, reduction=False)(est.clone(), ref.clone()).numpy()
+    out["si_snr"] = si_snr(est.clone(), ref.clone(), reduction=False).numpy()
+    out["inactive_sdr"] = inactive_sdr_loss(est.clone(), ref.clone(), reduction=False).numpy()
+    return out
+
+
+@torch.no_grad()
+def run_simo(name, c):
+    model = cases.build(REF, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    noisy = det_wave(c["seed"], c["B"], c["L"])
+    wav = model.inference(noisy.clone())
+    ref_clean = det_wave(c["seed"] + 1, c["B"] * c["heads"], c["L_ref"]).reshape(c["B"], c["heads"], c["L_ref"])
+    labels = torch.zeros(c["B"], c["heads"], dtype=torch.bool)
+    labels[0, 1] = True
+    loss = model(noisy.clone(), ref_clean.clone(), labels)
+    loss_all_active = model(noisy.clone(), ref_clean.clone(), torch.zeros_like(labels))
+    return {"wav": wav.numpy(), "loss": loss.numpy(), "loss_all_active": loss_all_active.numpy()}
+
+
 def dump_state_dict_keys():
     """Key -> shape of every reference state_dict the mirror modules must reproduce (drop-in checkpoints)."""
     import json
     out = {}
-    for name in cases.CASES:
+    for name, c in cases.CASES.items():
+        if c["kind"] == "loss":  # functions of two waveforms, no parameters
+            continue
         model = cases.build(REF, name)
         out[name] = {k: list(v.shape) for k, v in model.state_dict().items()}
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
@@ -242,7 +277,7 @@ def main():
     dump_state_dict_keys()
     for name, c in cases.CASES.items():
         fn = {"wrap": run_wrap, "masker": run_masker, "encdec": run_encdec, "rnn": run_rnn,
-              "stream": run_stream, "unet": run_unet, "fbank": run_fbank}[c["kind"]]
+              "stream": run_stream, "unet": run_unet, "fbank": run_fbank, "loss": run_loss, "simo": run_simo}[c["kind"]]
         if only and name not in only:
             continue
         out = fn(name, c)

@@ -1049,3 +1049,72 @@ def test_lstm_kernel_row_sequences_with_partial_step_group(H, dev, hid, t):
             _abi.lib().ps_debug_flags(old)
         got = hout.view(n, hid, f, ld)[..., :t].cpu().permute(0, 2, 3, 1).reshape(n * f, t, hid)
         assert rel_max(got.numpy(), ref.numpy()) < 2e-5, flags
+
+
+# ------------------------------------------------------------------------------------------------
+# signal scores (ps_wave_moments_f64) and the multi-output wrapper
+# ------------------------------------------------------------------------------------------------
+DB_TOL = 2e-3  # dB, absolute
+
+
+def test_wave_moments_kernel(H, dev):
+    a, b = _rand((7, 20011), 301) + 0.1, _rand((7, 20011), 302) - 0.05
+    m = H.wave_moments(a.to(dev), b.to(dev)).cpu().numpy()
+    ad, bd = a.double().numpy(), b.double().numpy()
+    want = np.stack([ad.sum(1), bd.sum(1), (ad * ad).sum(1), (bd * bd).sum(1), (ad * bd).sum(1)], 1)
+    np.testing.assert_allclose(m, want, rtol=1e-12, atol=1e-9)
+    # strided rows (views of a wider buffer), one short row
+    wide = _rand((3, 9000), 303).to(dev)
+    m2 = H.wave_moments(wide[:, 100:5100], wide[:, 3000:8000]).cpu().numpy()
+    w = wide.cpu().double().numpy()
+    np.testing.assert_allclose(m2[:, 4], (w[:, 100:5100] * w[:, 3000:8000]).sum(1), rtol=1e-12, atol=1e-9)
+    with pytest.raises(RuntimeError):
+        H.wave_moments(a.to(dev), b[:, :100].to(dev))
+
+
+def test_sdr_scores_match_reference_on_hip(PA, dev, golden_dir):
+    from puresound_amd.nnet.loss.sdr import SDRLoss, inactive_sdr_loss, l2_norm, si_snr
+    g = _load(golden_dir, "loss_sdr_modes")
+    est, ref, est3, ref3, labels = (x.to(dev) for x in cases.loss_inputs(cases.CASES["loss_sdr_modes"]))
+    for mode in ("sisnr", "sdsdr", "sdr", "tsdr", "sasdr", "sasisnr", "satsdr"):
+        a, b = (est3, ref3) if mode.startswith("sa") else (est, ref)
+        np.testing.assert_allclose(SDRLoss.init_mode(mode, reduction=False)(a, b).cpu().numpy(), g[mode], atol=DB_TOL, rtol=0)
+        np.testing.assert_allclose(SDRLoss.init_mode(mode, reduction=True)(a, b).cpu().numpy(), g[mode + "_mean"],
+                                   atol=DB_TOL, rtol=0)
+    np.testing.assert_allclose(SDRLoss.init_mode("sisnr", reduction=False)(est, ref, labels).cpu().numpy(),
+                               g["sisnr_inactive"], atol=DB_TOL, rtol=0)
+    np.testing.assert_allclose(SDRLoss.init_mode("sisnr", reduction=False, threshold=-20.0)(est, ref).cpu().numpy(),
+                               g["sisnr_threshold"], atol=DB_TOL, rtol=0)
+    np.testing.assert_allclose(SDRLoss(scaled=True, zero_mean=False, reduction=False)(est, ref).cpu().numpy(),
+                               g["raw_no_zero_mean"], atol=DB_TOL, rtol=0)
+    np.testing.assert_allclose(si_snr(est, ref, reduction=False).cpu().numpy(), g["si_snr"], atol=DB_TOL, rtol=0)
+    np.testing.assert_allclose(inactive_sdr_loss(est, ref, reduction=False).cpu().numpy(), g["inactive_sdr"],
+                               atol=DB_TOL, rtol=0)
+    np.testing.assert_allclose(l2_norm(est, ref).cpu().numpy(), (est.cpu().double() * ref.cpu().double()).sum(-1, keepdim=True),
+                               rtol=1e-6)
+    with pytest.raises(NameError):
+        SDRLoss.init_mode("snr")
+    with pytest.raises(AssertionError):
+        SDRLoss.init_mode("sasdr")(est, ref)  # source-aggregated modes need [N, M, L]
+    with pytest.raises(RuntimeError):
+        si_snr(est.cpu(), ref.cpu())  # no CPU fallback
+
+
+@pytest.mark.parametrize("name", ["simo_free", "simo_stft"])
+def test_simo_wrapper_matches_reference_on_hip(PA, dev, golden_dir, name):
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    noisy = det_wave(c["seed"], c["B"], c["L"]).to(dev)
+    wav = model.inference(noisy).cpu().numpy()
+    assert wav.shape == g["wav"].shape
+    sl = slice(16, -16) if c["enc"]["kind"] == "stft" else slice(None)
+    assert rel_max(wav[..., sl], g["wav"][..., sl]) < TOL
+    ref_clean = det_wave(c["seed"] + 1, c["B"] * c["heads"], c["L_ref"]).reshape(c["B"], c["heads"], c["L_ref"]).to(dev)
+    labels = torch.zeros(c["B"], c["heads"], dtype=torch.bool, device=dev)
+    labels[0, 1] = True
+    np.testing.assert_allclose(model(noisy, ref_clean, labels).cpu().numpy(), g["loss"], atol=DB_TOL, rtol=0)
+    np.testing.assert_allclose(model(noisy, ref_clean, torch.zeros_like(labels)).cpu().numpy(), g["loss_all_active"],
+                               atol=DB_TOL, rtol=0)

@@ -232,3 +232,52 @@ def test_fbank_encoder_matches_reference(golden_dir, name):
     y = O.fbank_encode(wav, sd, "encoder.", c["kw"]["hop_length"], c["kw"]["trainable"])
     assert y.shape == g["feats"].shape
     assert rel_max(y.numpy(), g["feats"]) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# signal scores (loss/sdr.py) and the multi-output wrapper (base_nn.py:780-939)
+# ------------------------------------------------------------------------------------------------
+from oracle import loss_oracle as LO  # noqa: E402
+
+DB_TOL = 2e-3  # dB, absolute: the scores are logarithms of ratios of fp32 sums (the reference's own fp32 noise at 60 dB)
+
+
+def test_sdr_scores_match_reference(golden_dir):
+    g = _load(golden_dir, "loss_sdr_modes")
+    est, ref, est3, ref3, labels = cases.loss_inputs(cases.CASES["loss_sdr_modes"])
+    for mode in LO.MODES:
+        f = LO.mode_flags(mode)
+        a, b = (est3, ref3) if f["source_aggregated"] else (est, ref)
+        np.testing.assert_allclose(LO.sdr_loss(a, b, reduction=False, **f).numpy(), g[mode], atol=DB_TOL, rtol=0)
+        np.testing.assert_allclose(LO.sdr_loss(a, b, reduction=True, **f).numpy(), g[mode + "_mean"], atol=DB_TOL, rtol=0)
+    f = LO.mode_flags("sisnr")
+    np.testing.assert_allclose(LO.sdr_loss(est, ref, reduction=False, inactive_labels=labels, **f).numpy(),
+                               g["sisnr_inactive"], atol=DB_TOL, rtol=0)
+    np.testing.assert_allclose(LO.sdr_loss(est, ref, reduction=False, threshold=-20.0, **f).numpy(),
+                               g["sisnr_threshold"], atol=DB_TOL, rtol=0)
+    np.testing.assert_allclose(LO.sdr_loss(est, ref, scaled=True, zero_mean=False, reduction=False).numpy(),
+                               g["raw_no_zero_mean"], atol=DB_TOL, rtol=0)
+    np.testing.assert_allclose(LO.si_snr(est, ref, reduction=False).numpy(), g["si_snr"], atol=DB_TOL, rtol=0)
+    np.testing.assert_allclose(LO.inactive_sdr_loss(est, ref, reduction=False).numpy(), g["inactive_sdr"], atol=DB_TOL,
+                               rtol=0)
+    with pytest.raises(NameError):
+        LO.mode_flags("snr")
+
+
+@pytest.mark.parametrize("name", ["simo_free", "simo_stft"])
+def test_simo_wrapper_matches_reference(golden_dir, name):
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name)
+    sd = {k: v.float() for k, v in det_state_dict(model).items()}
+    cfg = cases.oracle_cfg(name)
+    noisy = det_wave(c["seed"], c["B"], c["L"])
+    wav = LO.simo_inference(noisy, sd, cfg)
+    sl = slice(16, -16) if c["enc"]["kind"] == "stft" else slice(None)
+    assert rel_max(wav.numpy()[..., sl], g["wav"][..., sl]) < TOL
+    ref_clean = det_wave(c["seed"] + 1, c["B"] * c["heads"], c["L_ref"]).reshape(c["B"], c["heads"], c["L_ref"])
+    labels = torch.zeros(c["B"], c["heads"], dtype=torch.bool)
+    labels[0, 1] = True
+    np.testing.assert_allclose(LO.simo_forward(noisy, ref_clean, sd, cfg, labels).numpy(), g["loss"], atol=DB_TOL, rtol=0)
+    np.testing.assert_allclose(LO.simo_forward(noisy, ref_clean, sd, cfg, torch.zeros_like(labels)).numpy(),
+                               g["loss_all_active"], atol=DB_TOL, rtol=0)

@@ -12,7 +12,9 @@ for gemm in sys.argv[1:] or ["fp32", "bf16x3", "bf16"]:
     model = bench.build_model(dev)
     if gemm != "fp32":
         model.masker.set_gemm_precision(gemm)
-    for streams in (1, 2, 4):
+    from puresound_amd import _abi
+    for streams, cap in ((1, 0), (2, 0), (2, 128), (2, 160), (4, 64), (4, 128), (3, 96)):
+        _abi.lib().ps_debug_flags(cap << 8)
         model.hip_streams = streams
         for _ in range(5):
             model.inference(noisy)
@@ -21,4 +23,4 @@ for gemm in sys.argv[1:] or ["fp32", "bf16x3", "bf16"]:
         for _ in range(20):
             model.inference(noisy)
         torch.cuda.synchronize()
-        print(f"{gemm:7s} hip_streams={streams}: {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms/step", flush=True)
+        print(f"{gemm:7s} hip_streams={streams} grid cap {cap}: {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms/step", flush=True)
