@@ -13,6 +13,7 @@ from .. import hip
 import os
 
 FUSE_PROJ_LN = os.environ.get("PS_FUSE_PROJ_LN", "1") == "1"   # 0: separate projection GEMM + LayerNorm kernels
+FUSE_PROJ_LN_MAX_FRAMES = int(os.environ.get("PS_FUSE_PROJ_LN_MAX_FRAMES", "8192"))
 
 
 def param_signature(module: nn.Module, device) -> tuple:
@@ -89,7 +90,9 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
                         out=torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev))
     hseq, state = hip.lstm(gx, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride, h0, c0, want_state,
                            state_shift, state_out)
-    if proj["M"] <= 256 and FUSE_PROJ_LN:
+    # the fused projection + LayerNorm kernel is the short-row kernel (16-frame workgroups): on long rows (the 2-D
+    # maps of DPCRN / DPARN: F * ld frames) the MFMA GEMM plus a LayerNorm pass is faster
+    if proj["M"] <= 256 and FUSE_PROJ_LN and t <= FUSE_PROJ_LN_MAX_FRAMES:
         y, _ = hip.proj_layernorm(hseq, t, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"], norm["eps"], x)
         return y, state
     p, _ = hip.conv1x1(hseq, t, proj["wt"], proj["M"], None, proj["bias"],
