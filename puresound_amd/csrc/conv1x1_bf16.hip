@@ -371,6 +371,24 @@ static_assert(PpLds<3>::TOTAL <= 160 * 1024, "one workgroup per CU");
 template <int V>
 using bic = std::integral_constant<int, V>;
 
+// Sum over the 64 lanes on DPP row rotations (every lane of a 16-lane row ends up with the row's total) and four
+// v_readlane: ~30 instructions with no LDS round trips.  (The fp64 butterfly of wave_sum() is 24 ds_bpermute with a
+// wait each -- 2.5 k cycles per tile drain next to the partner half's MFMA stream.)  fp32 is enough here: each lane's
+// value is already an fp32 sum over its 128 elements.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto ror = [](float x, auto ctl_c) {
+    constexpr int ctl = decltype(ctl_c)::value;  // 0x120 + n = row_ror:n
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctl, 0xf, 0xf, false));
+  };
+  v += ror(v, bic<0x128>{});
+  v += ror(v, bic<0x124>{});
+  v += ror(v, bic<0x122>{});
+  v += ror(v, bic<0x121>{});
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+}
+
 template <int PLANES, bool TR, bool STATS, bool RES>
 __global__ __launch_bounds__(512, 1) void conv1x1_bf16_pp_kernel(BfArgs a) {
   using L = PpLds<PLANES>;
@@ -740,7 +758,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_bf16_pp_kernel(BfArgs a) {
       }
     }
     if constexpr (STATS) {
-      const double s = wave_sum((double)fsum), q = wave_sum((double)fsq);
+      const double s = wave_sum_dpp(fsum), q = wave_sum_dpp(fsq);
       if (lane == 0 && ok) {
         const int parts = a.tiles_m * a.tiles_t * 4;
         const int part = (mt * a.tiles_t + 2 * t2 + h) * 4 + hw;
