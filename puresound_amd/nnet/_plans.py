@@ -16,6 +16,19 @@ FUSE_PROJ_LN = os.environ.get("PS_FUSE_PROJ_LN", "1") == "1"   # 0: separate pro
 FUSE_PROJ_LN_MAX_FRAMES = int(os.environ.get("PS_FUSE_PROJ_LN_MAX_FRAMES", "8192"))
 
 
+# Arithmetic of the LSTM input projections (the large GEMMs of the recurrent maskers: [4H*D x C] over every frame):
+# "fp32" = v_mfma_f32 on fp32 operands, "bf16x3" = fp32-accurate 3 x bf16 split, "bf16" = operands rounded to bf16 (what
+# BASELINE.json names for the DPRNN configuration).  Same switch as ConvTasNet.set_gemm_precision, process-wide.
+RECURRENT_GEMM = {"name": os.environ.get("PS_RECURRENT_GEMM", "fp32")}
+_PLANES = {"fp32": 0, "bf16": 1, "bf16x3": 3}
+
+
+def set_recurrent_gemm_precision(name: str) -> None:
+    if name not in _PLANES:
+        raise ValueError(f"gemm precision must be one of {sorted(_PLANES)}")
+    RECURRENT_GEMM["name"] = name
+
+
 def param_signature(module: nn.Module, device) -> tuple:
     sig = [(t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers())]
     sig.append(module.training)
@@ -59,7 +72,8 @@ def lstm_plan(lstm: nn.LSTM, device) -> dict:
         wih.append(_f32(getattr(lstm, "weight_ih_l0" + suf), device))
         bias.append(_f32(getattr(lstm, "bias_ih_l0" + suf), device) + _f32(getattr(lstm, "bias_hh_l0" + suf), device))
         whh.append(_f32(getattr(lstm, "weight_hh_l0" + suf), device).t().contiguous())
-    return dict(wih=hip.pack_wt(torch.cat(wih, 0)), bias=torch.cat(bias).contiguous(),
+    return dict(wih=hip.pack_wt(torch.cat(wih, 0)), wih_rows=torch.cat(wih, 0).contiguous(), wih_planes={},
+                bias=torch.cat(bias).contiguous(),
                 whh_t=torch.stack(whh).contiguous(), H=hid, D=dirs, rows=dirs * 4 * hid, I=lstm.input_size)
 
 
@@ -86,8 +100,14 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
     """x + LN(proj(LSTM(x))) on padded [N,C,ldt] (dprnn.py:154-172, skim.py:215-227) -> (x', final states)."""
     n, _, ldt = x.shape
     dev = x.device
-    gx, _ = hip.conv1x1(x, t, rnn["wih"], rnn["rows"], None, rnn["bias"],
-                        out=torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev))
+    planes = _PLANES[RECURRENT_GEMM["name"]]
+    gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev)
+    if planes and rnn["I"] >= 64:
+        if planes not in rnn["wih_planes"]:
+            rnn["wih_planes"][planes] = hip.pack_wt_bf16(rnn["wih_rows"], planes)
+        hip.conv1x1_bf16(x, t, rnn["wih_planes"][planes], rnn["rows"], None, rnn["bias"], out=gx)
+    else:
+        hip.conv1x1(x, t, rnn["wih"], rnn["rows"], None, rnn["bias"], out=gx)
     hseq, state = hip.lstm(gx, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride, h0, c0, want_state,
                            state_shift, state_out)
     # the fused projection + LayerNorm kernel is the short-row kernel (16-frame workgroups): on long rows (the 2-D

@@ -33,7 +33,8 @@ def cfg4(args):
         model.inference(noisy)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
-    line = {"config": "cfg4 DPRNN(128,64,128,6 blocks,K=20,causal) fp32", "batch": args.batch, "ms_per_forward": ms,
+    line = {"config": "cfg4 DPRNN(128,64,128,6 blocks,K=20,causal) fp32 storage", "input_projection_gemm": args.gemm,
+            "batch": args.batch, "ms_per_forward": ms,
             "samples_per_s": args.batch * 64000 / ms * 1e3}
     if args.profile:
         import ctypes as C
@@ -68,7 +69,8 @@ def dpcrn(args):
         model.inference(noisy)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
-    line = {"config": "ns_dpcrn_v0_causal (STFT 512/128 + DPCRN(1,32,32,32,64,128; H=128)) fp32", "batch": args.batch,
+    line = {"config": "ns_dpcrn_v0_causal (STFT 512/128 + DPCRN(1,32,32,32,64,128; H=128)) fp32 storage",
+            "input_projection_gemm": args.gemm, "batch": args.batch,
             "ms_per_forward": ms, "samples_per_s": args.batch * 64000 / ms * 1e3}
     if args.profile:
         import ctypes as C
@@ -125,9 +127,13 @@ if __name__ == "__main__":
     ap.add_argument("--chunks", type=int, default=500)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="ps_debug_flags (kernel variant switches)")
+    ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+                    help="arithmetic of the LSTM input projections (puresound_amd.nnet._plans.set_recurrent_gemm_precision)")
     a = ap.parse_args()
     if a.flags:
         _abi.lib().ps_debug_flags(a.flags)
+    from puresound_amd.nnet import _plans
+    _plans.set_recurrent_gemm_precision(a.gemm)
     if "cfg4" in a.which:
         cfg4(a)
     if "cfg5" in a.which:
