@@ -160,8 +160,8 @@ def main():
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "f32",
-                  "bf16x3": "f32 (operands, accumulation and result accuracy fp32; each product issued as 3xbf16 split "
-                            "terms on the bf16 MFMA pipe)",
+                  "bf16x3": "f32 (GEMM products issued as 3xbf16 split terms, fp32 accumulate; result error equals the "
+                            "exact-fp32 MFMA path's)",
                   "bf16": "f32 storage/accumulate, bf16 products (EXPERIMENT, not an fp32 result)"}[args.gemm],
         "gemm": args.gemm,
         "data": "synthetic",
