@@ -1,0 +1,27 @@
+"""Latency of ONE 4 s utterance through the config-2 model (north star: >= 30 x real time per utterance)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import json
+import numpy as np
+import torch
+import bench
+
+dev = torch.device("cuda:0")
+model = bench.build_model(dev)
+g = torch.Generator().manual_seed(1234)
+for gemm in ("fp32", "bf16x3"):
+    model.masker.set_gemm_precision(gemm)
+    for n in (1, 4):
+        noisy = ((torch.rand(n, bench.L, generator=g) * 2 - 1) * 0.5).to(dev)
+        for _ in range(10):
+            model.inference(noisy)
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            model.inference(noisy)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e3)
+        lat = np.array(lat)
+        print(json.dumps({"config": "config 2 model, batch %d x 4 s" % n, "gemm": gemm, "ms_p50": float(np.percentile(lat, 50)),
+                          "ms_p90": float(np.percentile(lat, 90)), "x_realtime_p50": n * 4000.0 / float(np.percentile(lat, 50))}), flush=True)
