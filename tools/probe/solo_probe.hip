@@ -37,14 +37,15 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, unsigned long long* 
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 64 << 20, 0x00020000);
   auto body = [&](int it, auto q_c) {
     constexpr int q = decltype(q_c)::value;
-    if (MODE < 3) load_frags(q, it);
+    constexpr int BASE = MODE >= 7 ? 4 : (MODE >= 5 ? 3 : MODE);
+    if (BASE < 3) load_frags(q, it);
     float v[8];
-    if (MODE >= 1) {
+    if (BASE >= 1) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = raw[j * 128 + (it & 3)];
     }
-    if (MODE >= 3) load_frags(q ^ 1, it + 1);
-    if (MODE >= 4) {
+    if (BASE >= 3) load_frags(q ^ 1, it + 1);
+    if (BASE >= 4) {
       float* dst = reinterpret_cast<float*>(smem + 84 * 1024) + (tid >> 6) * 256;
       const int so = ((blockIdx.x * 2048 + (it & 1023)) * 8) * 1024;
 #pragma unroll
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, unsigned long long* 
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], bfq[q][0][ti], acc[mi][ti], 0, 0, 0);
     }
-    if (MODE >= 1) {
+    if (BASE >= 1) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float u = v[j] * 1.01f + 0.5f;
@@ -89,7 +90,9 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, unsigned long long* 
         *reinterpret_cast<bf16x8*>(bx + p * 4096) = piece;
       }
     }
-    if (MODE >= 4)
+    if (MODE == 5 || MODE == 7) __builtin_amdgcn_iglp_opt(0);
+    if (MODE == 6 || MODE == 8) __builtin_amdgcn_iglp_opt(1);
+    if (BASE >= 4)
       asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -120,12 +123,16 @@ int main() {
   hipMalloc(&cyc, 256 * 8);
   const int iters = 2000;
   unsigned long long h[256];
-  for (int mode : {0, 1, 3, 4}) {
+  for (int mode : {3, 4, 5, 6, 7, 8}) {
     for (int rep = 0; rep < 2; ++rep) {
       if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(256), dim3(256), 0, 0, out, cyc, iters, src);
       if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(256), dim3(256), 0, 0, out, cyc, iters, src);
       if (mode == 3) hipLaunchKernelGGL(probe<3>, dim3(256), dim3(256), 0, 0, out, cyc, iters, src);
       if (mode == 4) hipLaunchKernelGGL(probe<4>, dim3(256), dim3(256), 0, 0, out, cyc, iters, src);
+      if (mode == 5) hipLaunchKernelGGL(probe<5>, dim3(256), dim3(256), 0, 0, out, cyc, iters, src);
+      if (mode == 6) hipLaunchKernelGGL(probe<6>, dim3(256), dim3(256), 0, 0, out, cyc, iters, src);
+      if (mode == 7) hipLaunchKernelGGL(probe<7>, dim3(256), dim3(256), 0, 0, out, cyc, iters, src);
+      if (mode == 8) hipLaunchKernelGGL(probe<8>, dim3(256), dim3(256), 0, 0, out, cyc, iters, src);
       hipDeviceSynchronize();
     }
     hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
