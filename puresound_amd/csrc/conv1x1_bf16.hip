@@ -46,26 +46,32 @@ struct BfArgs {
   int ablate;  // profiling only (ps_debug_flags bits 24..26): 1 = no MFMA, 2 = no epilogue, 4 = no activation split
 };
 
-template <int PLANES>
+// TT = frames per workgroup tile: 128 (2 x 2 waves of 128 x 64) or 32 (4 x 1 waves of 64 x 32 -- the small-grid
+// variant: four times the workgroups for launches that cannot fill the chip, e.g. one utterance at a time)
+template <int PLANES, int TT = XB_T>
 struct BfLds {
   static constexpr int A_BYTES = PLANES * XB_M * XB_K * 2;  // 8 KiB per plane
-  static constexpr int B_BYTES = PLANES * XB_T * XB_K * 2;  // 4 KiB per plane
+  static constexpr int B_BYTES = PLANES * TT * XB_K * 2;    // 4 KiB per plane at TT = 128
   static constexpr int SLOT = A_BYTES + B_BYTES;
   static constexpr int KTAB = 512;   // floats per table: sc / sh of the prologue (K <= 512)
   static constexpr int TOTAL = 2 * SLOT + 2 * KTAB * 4 + 64;  // PLANES = 3: 76 KiB -> two workgroups per CU
 };
 
-template <int PLANES, bool TR, bool STATS, bool RES>
+template <int PLANES, bool TR, bool STATS, bool RES, int TT = XB_T>
 __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
-  using L = BfLds<PLANES>;
+  using L = BfLds<PLANES, TT>;
+  constexpr bool NARROW = TT != XB_T;
+  constexpr int MI = NARROW ? 2 : 4, TI = NARROW ? 1 : 2;  // 32 x 32 MFMA tiles per wave
+  constexpr int WROWS = MI * 32;                            // rows per wave
   __shared__ __attribute__((aligned(16))) unsigned char smem[L::TOTAL];
   float* tab = reinterpret_cast<float*>(smem + 2 * L::SLOT);  // sc[512] | sh[512]
   double* red = reinterpret_cast<double*>(smem + 2 * L::SLOT + 2 * L::KTAB * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wt = wave & 1;
+  const int wm = NARROW ? wave : wave >> 1, wt = NARROW ? 0 : wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
-  const int t0 = blockIdx.x * XB_T, mt = blockIdx.y, n = blockIdx.z;
+  const int t0 = blockIdx.x * TT, mt = blockIdx.y, n = blockIdx.z;
   const int m0 = mt * XB_M;
+  if (NARROW && t0 >= a.T) return;  // (the grid covers whole 128-frame tiles)
 
   // prologue tables (per utterance): u = x * sc[k] + sh[k]
   const bool has_norm = TR && a.pro.norm != PS_NORM_NONE;
@@ -87,7 +93,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
   // ---- staging ------------------------------------------------------------------------------------------------
   constexpr int A_PIECES = 2 * PLANES;  // 16-byte pieces per thread per K-step
   const u32x4v* wsrc = reinterpret_cast<const u32x4v*>(a.wt) + (size_t)mt * a.ksteps * (L::A_BYTES / 16);
-  const int bt = tid & 127, bh = tid >> 7;  // activation staging: frame, k-half
+  const int bt = tid % TT, bh = (tid / TT) & 1;  // activation staging: frame, k-half
+  const bool b_active = tid < 2 * TT;           // (narrow tiles: 64 of the 256 threads)
   // weights (L2 resident) are fetched one K-step ahead, activations (HBM) two: breg is a two-deep register queue
   constexpr int A_DEPTH = PLANES == 1 ? 2 : 1;  // weight K-steps in flight (register budget)
   u32x4v areg[A_DEPTH][A_PIECES];
@@ -110,13 +117,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       breg[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, xb_voff, soff + j * a.ldt * 4, 0));
+    (void)b_active;  // idle threads load in-range duplicates (tid % TT) and skip the LDS write
   };
   auto store_step = [&](int ks, int slot, auto q_c) {
     constexpr int q = decltype(q_c)::value;
     unsigned char* sa = smem + slot * L::SLOT;
 #pragma unroll
     for (int i = 0; i < A_PIECES; ++i) reinterpret_cast<u32x4v*>(sa)[tid + 256 * i] = areg[A_DEPTH - 1][i];
-    if (a.ablate & 4) return;
+    if ((a.ablate & 4) || !b_active) return;
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -146,15 +154,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
           v[j + 1] -= back[1];
         }
       }
-      *reinterpret_cast<bf16x8*>(sb + ((p * XB_T + bt) * XB_K + 8 * bh) * 2) = piece;
+      *reinterpret_cast<bf16x8*>(sb + ((p * TT + bt) * XB_K + 8 * bh) * 2) = piece;
     }
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[MI][TI];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ti][r] = 0.f;
 
@@ -162,20 +170,20 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
     if (a.ablate & 1) return;
     const unsigned char* sa = smem + slot * L::SLOT;
     const unsigned char* sb = sa + L::A_BYTES;
-    bf16x8 bf[PLANES][2];
+    bf16x8 bf[PLANES][TI];
 #pragma unroll
     for (int p = 0; p < PLANES; ++p)
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
-        bf[p][ti] = *reinterpret_cast<const bf16x8*>(sb + ((p * XB_T + wt * 64 + ti * 32 + lr) * XB_K + 8 * lh) * 2);
+      for (int ti = 0; ti < TI; ++ti)
+        bf[p][ti] = *reinterpret_cast<const bf16x8*>(sb + ((p * TT + wt * 64 + ti * 32 + lr) * XB_K + 8 * lh) * 2);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
       bf16x8 af[PLANES];
 #pragma unroll
       for (int p = 0; p < PLANES; ++p)
-        af[p] = *reinterpret_cast<const bf16x8*>(sa + ((p * XB_M + wm * 128 + mi * 32 + lr) * XB_K + 8 * lh) * 2);
+        af[p] = *reinterpret_cast<const bf16x8*>(sa + ((p * XB_M + wm * WROWS + mi * 32 + lr) * XB_K + 8 * lh) * 2);
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti) {
+      for (int ti = 0; ti < TI; ++ti) {
         if constexpr (PLANES == 3) {
           // smallest terms first
           acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][ti], acc[mi][ti], 0, 0, 0);
@@ -261,22 +269,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
   const __amdgpu_buffer_rsrc_t bnr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.bias_n ? a.bias_n + (size_t)n * a.M : a.x), 0, a.bias_n ? a.M * 4 : 0, 0x00020000);
   const int lane_off = (4 * lh * a.ldt + lr) * 4;
-  const int tile_off = ((m0 + wm * 128) * a.ldt + t0 + wt * 64) * 4;
-  float cm[2];
+  const int tile_off = ((m0 + wm * WROWS) * a.ldt + t0 + wt * 64) * 4;
+  float cm[TI];
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti) cm[ti] = (t0 + wt * 64 + ti * 32 + lr < a.T) ? 1.f : 0.f;
+  for (int ti = 0; ti < TI; ++ti) cm[ti] = (t0 + wt * 64 + ti * 32 + lr < a.T) ? 1.f : 0.f;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    float bsum[16], rv[2][16];
+  for (int mi = 0; mi < MI; ++mi) {
+    float bsum[16], rv[TI][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rc = mi * 32 + (r & 3) + 8 * (r >> 2);
-      const int moff = (m0 + wm * 128 + rc + 4 * lh) * 4;
+      const int moff = (m0 + wm * WROWS + rc + 4 * lh) * 4;
       bsum[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, moff, 0, 0)) +
                 __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bnr, moff, 0, 0));
       if constexpr (RES) {
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < TI; ++ti)
           rv[ti][r] = __builtin_bit_cast(
               float, __builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, tile_off + rc * a.ldt * 4 + ti * 128, 0));
       }
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int rc = mi * 32 + (r & 3) + 8 * (r >> 2);
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti) {
+      for (int ti = 0; ti < TI; ++ti) {
         float v = acc[mi][ti][r] + bsum[r];
         if constexpr (STATS) {
           const float vm = v * cm[ti];
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
       }
     }
   }
-  if (a.stamps && tid == 0) {
+  if (a.stamps && tid == 0 && !NARROW) {
     unsigned long long now;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
     unsigned long long* d = a.stamps + ((size_t)(n * a.tiles_m + mt) * a.tiles_t + blockIdx.x) * 6;
@@ -310,9 +318,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
     d[5] = now;
   }
   if constexpr (STATS) {
-    const double s = wave_sum((double)fsum), q = wave_sum((double)fsq);
-    if (lane == 0) {
-      const int parts = a.tiles_m * a.tiles_t * 4;
+    double s = wave_sum((double)fsum), q = wave_sum((double)fsq);
+    const int parts = a.tiles_m * a.tiles_t * 4;  // four slots per 256 x 128 tile: its waves, or its narrow workgroups
+    if constexpr (NARROW) {
+      __syncthreads();  // every wave is done with the operand slots: `red` may be anywhere in LDS
+      if (lane == 0) {
+        red[wave * 2] = s;
+        red[wave * 2 + 1] = q;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        s = red[0] + red[2] + red[4] + red[6];
+        q = red[1] + red[3] + red[5] + red[7];
+        double* dst = a.ostats + ((size_t)n * parts + (mt * a.tiles_t + (blockIdx.x >> 2)) * 4 + (blockIdx.x & 3)) * 2;
+        dst[0] = s;
+        dst[1] = q;
+      }
+    } else if (lane == 0) {
       const int part = (mt * a.tiles_t + blockIdx.x) * 4 + wave;
       double* dst = a.ostats + ((size_t)n * parts + part) * 2;
       dst[0] = s;
@@ -940,9 +962,17 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
 #undef PS_PP
     return;
   }
-  dim3 grid(a.tiles_t, a.tiles_m, N);
-#define PS_BF(TRV, STV, RSV) \
-  hipLaunchKernelGGL((conv1x1_bf16_kernel<PLANES, TRV, STV, RSV>), grid, dim3(256), 0, stream, a)
+  // launches that cannot fill the chip with 256 x 128 tiles (one or a few utterances) take 256 x 32 tiles: four times
+  // the workgroups, a quarter of the staging and MFMA work each (ps_debug_flags bit 29 keeps the wide tile)
+  const bool narrow = 2 * (long long)a.tiles_t * a.tiles_m * N <= cus && !(g_debug_flags & (1 << 29));
+  dim3 grid(narrow ? a.tiles_t * 4 : a.tiles_t, a.tiles_m, N);
+#define PS_BF(TRV, STV, RSV)                                                                                        \
+  do {                                                                                                              \
+    if (narrow)                                                                                                     \
+      hipLaunchKernelGGL((conv1x1_bf16_kernel<PLANES, TRV, STV, RSV, 32>), grid, dim3(256), 0, stream, a);          \
+    else                                                                                                            \
+      hipLaunchKernelGGL((conv1x1_bf16_kernel<PLANES, TRV, STV, RSV, XB_T>), grid, dim3(256), 0, stream, a);        \
+  } while (0)
   if (tr) {
     if (stats) PS_BF(true, true, false);
     else if (res) PS_BF(true, false, true);
