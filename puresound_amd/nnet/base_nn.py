@@ -202,7 +202,9 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         # half's kernels (and its HBM-bound depthwise/encoder/decoder launches) overlaps the other half's
         # MFMA-bound GEMMs.  Results are bit-identical to the single-stream run.
         n = noisy.shape[0]
-        lanes = min(int(getattr(self, "hip_streams", 2)), n // 2) if n >= 4 else 1
+        # (below 16 utterances a launch no longer fills the chip and halving it costs more than the overlap returns:
+        #  tools/batch_sweep.py)
+        lanes = min(int(getattr(self, "hip_streams", 2)), n // 8) if n >= 16 else 1
         if isinstance(self.masker, SkiM) and self.masker.causal:
             # the reference's causal Mem-LSTM hand-over leaks the last segment state of utterance n-1 into
             # utterance n (skim.py:102-109): keep the batch in one piece so the result stays identical to it

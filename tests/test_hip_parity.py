@@ -417,7 +417,7 @@ def test_stream_split_is_bit_identical(PA, dev):
     model = cases.build(PA.NS, "tiny_free").eval()
     model.load_state_dict(det_state_dict(model))
     model.to(dev)
-    noisy = det_wave(4, 7, 2500).to(dev)
+    noisy = det_wave(4, 25, 2500).to(dev)  # (the split starts at 16 utterances)
     model.hip_streams = 1
     one = model.inference(noisy)
     for lanes in (2, 3):
