@@ -269,9 +269,9 @@ __device__ __forceinline__ void conv1x1_body(const Conv1x1Args& a, float* lds) {
   // (+ residual), statistics, store.  Written on float2 so that hipcc emits packed VALU (v_pk_add/mul/fma):
   // VALU issue slots are the scarce resource next to a co-resident wave's MFMAs.  Rows >= M need no mask:
   // their weights and (out-of-descriptor) bias rows are zero, so they add exactly 0 to the statistics; pad
-  // columns are masked by a per-lane 0/1 factor per column block.
+  // columns are masked by a per-lane select per column block.
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  auto drain_pair = [&](auto sub_c, auto r_c, f32x2 bias2, const f32x2 (&cm2)[2], __amdgpu_buffer_rsrc_t yr, int soff,
+  auto drain_pair = [&](auto sub_c, auto r_c, f32x2 bias2, const bool (&cm2)[2], __amdgpu_buffer_rsrc_t yr, int soff,
                         int ldt4, f32x2& fsum2, f32x2& fsq2) {
     constexpr int sub = decltype(sub_c)::value, r = decltype(r_c)::value;  // r even
     constexpr int mi = sub >> 1, ti = sub & 1;
@@ -279,7 +279,9 @@ __device__ __forceinline__ void conv1x1_body(const Conv1x1Args& a, float* lds) {
     float v0 = acc[mi][ti][r] + bias2[0];
     float v1 = acc[mi][ti][r + 1] + bias2[1];
     if constexpr (STATS) {
-      const f32x2 vm = f32x2{v0, v1} * cm2[ti];
+      // (a select, not a 0/1 factor: a pad column may hold anything -- the depthwise kernel leaves the pad frames of
+      //  its output untouched -- and 0 * NaN would poison the statistics of the whole utterance)
+      const f32x2 vm = cm2[ti] ? f32x2{v0, v1} : f32x2{0.f, 0.f};
       fsum2 += vm;
       fsq2 += vm * vm;
     }
@@ -362,12 +364,9 @@ __device__ __forceinline__ void conv1x1_body(const Conv1x1Args& a, float* lds) {
     int ldt4 = a.ldt * 4;
     asm volatile("" : "+s"(ldt4));
     f32x2 fsum2 = {0.f, 0.f}, fsq2 = {0.f, 0.f};
-    f32x2 cm2[2];
+    bool cm2[2];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-      const float c = (t.t0 + wt * 64 + ti * 32 + lr < a.T) ? 1.f : 0.f;
-      cm2[ti] = f32x2{c, c};
-    }
+    for (int ti = 0; ti < 2; ++ti) cm2[ti] = t.t0 + wt * 64 + ti * 32 + lr < a.T;
     // slot i = sub*8 + kk: MFMA (mi, ti) = (sub>>1, sub&1), k-pair kk; drains pair kk of sub-tile sub-1
     float av[2], bv[2];
     f32x2 bp[2];

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
   const int lr = lane & 31, lh = lane >> 5;
   const int t0 = blockIdx.x * TT, mt = blockIdx.y, n = blockIdx.z;
   const int m0 = mt * XB_M;
-  if (NARROW && t0 >= a.T) return;  // (the grid covers whole 128-frame tiles)
+  // (narrow tiles: the grid covers whole 128-frame tiles, pad frames included -- every kernel of the path writes the
+  //  pad frames of its output with finite values so that no later stage can read uninitialised memory as data)
 
   // prologue tables (per utterance): u = x * sc[k] + sh[k]
   const bool has_norm = TR && a.pro.norm != PS_NORM_NONE;
@@ -270,9 +271,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
       const_cast<float*>(a.bias_n ? a.bias_n + (size_t)n * a.M : a.x), 0, a.bias_n ? a.M * 4 : 0, 0x00020000);
   const int lane_off = (4 * lh * a.ldt + lr) * 4;
   const int tile_off = ((m0 + wm * WROWS) * a.ldt + t0 + wt * 64) * 4;
-  float cm[TI];
+  bool cm[TI];  // (a select, not a 0/1 factor: a pad frame may hold anything and 0 * NaN would poison the statistics)
 #pragma unroll
-  for (int ti = 0; ti < TI; ++ti) cm[ti] = (t0 + wt * 64 + ti * 32 + lr < a.T) ? 1.f : 0.f;
+  for (int ti = 0; ti < TI; ++ti) cm[ti] = t0 + wt * 64 + ti * 32 + lr < a.T;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     float bsum[16], rv[TI][16];
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
       for (int ti = 0; ti < TI; ++ti) {
         float v = acc[mi][ti][r] + bsum[r];
         if constexpr (STATS) {
-          const float vm = v * cm[ti];
+          const float vm = cm[ti] ? v : 0.f;
           fsum += vm;
           fsq += vm * vm;
         }
@@ -743,9 +744,9 @@ __global__ __launch_bounds__(512, 1) void conv1x1_bf16_pp_kernel(BfArgs a) {
         const_cast<float*>(RES ? a.res : a.y) + (size_t)nn * a.M * a.ldt, 0, (RES && tile_ok(idx + 1, nt2)) ? slab : 0,
         0x00020000);
     [[maybe_unused]] const int ntile_off = ((nmt * XB_M + wm * 128) * a.ldt + (2 * nt2 + h) * XB_T + wt * 64) * 4;
-    float cm[2];
+    bool cm[2];  // (a select, not a 0/1 factor: 0 * NaN would poison the statistics)
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) cm[ti] = (t0 + wt * 64 + ti * 32 + lr < a.T) ? 1.f : 0.f;
+    for (int ti = 0; ti < 2; ++ti) cm[ti] = t0 + wt * 64 + ti * 32 + lr < a.T;
     const float* bl = bias_lds + parity * 2 * XB_M + wm * 128 + 4 * lh;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_bf16_pp_kernel(BfArgs a) {
           for (int ti = 0; ti < 2; ++ti) {
             const float v = acc[mi][ti][r] + b4[r3];
             if constexpr (STATS) {
-              const float vm = v * cm[ti];
+              const float vm = cm[ti] ? v : 0.f;
               fsum += vm;
               fsq += vm * vm;
             }
