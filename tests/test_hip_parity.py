@@ -1131,8 +1131,9 @@ def test_simo_wrapper_matches_reference_on_hip(PA, dev, golden_dir, name):
 # uninitialised memory: pad frames / scratch buffers come from torch.empty, i.e. from whatever the caching allocator
 # last held.  Nothing read from there may reach a result (a 0 * NaN in a statistics mask once did).
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["tiny_free", "tiny_free_relu_causal", "tiny_stft", "cfg2_short", "cfg3_short",
-                                  "cfg4_short", "tse_unet_tcn_causal_short", "ns_dpcrn_short"])
+@pytest.mark.parametrize("name", ["tiny_free", "tiny_free_relu_causal", "tiny_stft", "cfg1_short", "cfg2_short", "cfg3_short",
+                                  "cfg4_short", "cfg4_tse_short", "tse_unet_tcn_causal_short", "tse_unet_tcn_short",
+                                  "ns_dpcrn_short", "ns_dparn_short", "tse_skim_causal_short", "tse_skim_fbank_short"])
 @pytest.mark.parametrize("gemm", ["fp32", "bf16x3"])
 def test_results_do_not_depend_on_uninitialised_memory(PA, dev, golden_dir, name, gemm):
     c = cases.CASES[name]
