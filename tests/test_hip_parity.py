@@ -41,6 +41,17 @@ def _load(golden_dir, name):
     return dict(np.load(os.path.join(golden_dir, name + ".npz")))
 
 
+@pytest.fixture(autouse=True)
+def _nan_in_the_allocator_cache(dev):
+    """Every GPU test starts with NaN-filled blocks in torch's caching allocator, so that `torch.empty` scratch and
+    pad frames hold NaN rather than the zeros of a fresh process: a kernel that lets uninitialised memory reach a
+    result fails its parity check instead of passing by luck."""
+    junk = [torch.full((1 << 22,), float("nan"), device=dev) for _ in range(16)]  # 16 x 16 MiB
+    junk += [torch.full((n,), float("nan"), device=dev) for n in (1 << 10, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20)]
+    del junk
+    yield
+
+
 def _rand(shape, seed, lo=-1.0, hi=1.0):
     g = np.random.Generator(np.random.Philox(key=seed))
     return torch.tensor(g.uniform(lo, hi, shape), dtype=torch.float32)
