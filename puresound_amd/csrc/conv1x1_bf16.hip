@@ -14,11 +14,15 @@
 // v_mfma_f32_32x32x16_bf16: A fragment = 8 consecutive k of one row, B fragment = 8 consecutive k of one column, so
 // both operand tiles live in LDS k-innermost ([row][16 k] bf16 = 32 B per row, read with ds_read_b128, conflict free).
 // Weights arrive already split and in exactly that image from the host packer ([m-tile][k-step][plane][256][16]), so
-// a K-step of weights is a straight 8*PLANES KiB copy.  Activations are fp32 [k][t] in HBM: thread (t, k-half) loads
-// its 8 k values of one frame (coalesced along t), applies the prologue, splits, and writes one 16-byte LDS row piece
-// per plane.  Tile 256 (m) x 128 (t) per workgroup, 2 x 2 waves of 128 x 64 (the accumulator layout and the epilogue
-// are those of the fp32 kernel), two LDS slots, one barrier per K-step, global loads of step s+1 in flight over the
-// MFMAs of step s.
+// a K-step of weights is a straight 8*PLANES KiB copy.  Activations are fp32 [k][t] in HBM: they are transformed
+// (prologue), split and written as one 16-byte LDS row piece per plane and (frame, k-half).
+//
+// Two kernels:
+//   * conv1x1_bf16_pp_kernel ("ping-pong", the one the Conv-TasNet shapes run on): one persistent 512-thread workgroup
+//     per CU whose two halves alternate between an MFMA phase and a staging phase; all operand traffic by LDS-DMA.
+//   * conv1x1_bf16_kernel: one tile per workgroup (256 x 128, or 256 x 32 when even those cannot fill the chip), two
+//     LDS slots, operands staged through registers, one barrier per K-step -- for everything the persistent kernel
+//     does not take (few tiles, K < 64, workgroup runs that would span more than two utterances).
 #include <type_traits>
 
 #include "ps_common.h"
