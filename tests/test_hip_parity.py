@@ -1166,3 +1166,34 @@ def test_results_do_not_depend_on_uninitialised_memory(PA, dev, golden_dir, name
         assert torch.isfinite(out).all()
         sl = slice(16, -16) if c["enc"]["kind"] == "stft" else slice(None)
         assert rel_max(out.cpu().numpy()[:, sl], g["wav"][:, sl]) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# hipGraph replay of a whole inference call (small batches)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["tiny_free", "cfg2_short", "cfg3_short", "cfg4_short"])
+def test_graphed_inference_is_bit_identical(PA, dev, name):
+    from puresound_amd.graphs import GraphedInference
+    c = cases.CASES[name]
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    fast = GraphedInference(model)
+    for seed, batch in ((c["seed"], c["B"]), (c["seed"] + 7, c["B"]), (c["seed"] + 9, 1)):  # replay, replay, new shape
+        noisy = det_wave(seed, batch, c["L"]).to(dev)
+        enroll = det_wave(seed + 1, batch, c["L_enroll"]).to(dev) if "L_enroll" in c else None
+        eager = model.inference(noisy, enroll) if enroll is not None else model.inference(noisy)
+        a = fast(noisy, enroll)
+        b = fast(noisy, enroll)
+        assert torch.equal(a, eager) and torch.equal(b, eager) and a.data_ptr() != b.data_ptr()
+    assert len(fast._graphs) == 2
+    sd = det_state_dict(model)
+    key = next(k for k in sd if k.endswith("weight") and sd[k].dim() > 1)
+    sd[key] = sd[key] * 1.5  # a weight update drops the graphs (same signature as the kernel plans)
+    model.load_state_dict(sd)
+    noisy = det_wave(c["seed"], c["B"], c["L"]).to(dev)
+    enroll = det_wave(c["seed"] + 1, c["B"], c["L_enroll"]).to(dev) if "L_enroll" in c else None
+    eager = model.inference(noisy, enroll) if enroll is not None else model.inference(noisy)
+    assert torch.equal(fast(noisy, enroll), eager)
+    with pytest.raises(RuntimeError):
+        fast(noisy.cpu())
