@@ -1,0 +1,38 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (runs the real script on the GPU box)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", *extra], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("gemm", ["bf16x3", "fp32"])
+def test_bench_line(gemm):
+    d = _run("--gemm", gemm)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "samples/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 32 * 64000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["traffic"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.0
+    assert r["peak"] == (157.3 if gemm == "fp32" else 2500.0 / 6)
+    if gemm == "bf16x3":
+        assert d["fp32_mfma_path"]["ms_per_step"] > d["ms_per_step"]  # the exact-fp32 MFMA path, timed beside it
+    assert "cpu_baseline" not in d  # (--no-cpu-baseline)
