@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
