@@ -14,7 +14,6 @@ namespace ps {
 
 constexpr int ATT_SQ = 4;     // sequences per workgroup
 constexpr int ATT_MAXD = 64;  // head dimension
-constexpr int ATT_MAXL = 256; // positions (threads per sequence)
 
 struct AttArgs {
   const float* qkv;
