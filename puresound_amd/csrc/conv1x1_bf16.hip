@@ -925,6 +925,411 @@ __global__ __launch_bounds__(512, 1) void conv1x1_bf16_pp_kernel(BfArgs a) {
 #endif
 }
 
+// ---- single-wave-per-SIMD variant (experiment, ps_debug_flags bit 30) ------------------------------------------------
+// One 256-thread workgroup per CU, one wave per SIMD with the whole 512-register file: the fragments of K-step g+1 are
+// read from LDS while the MFMAs of step g issue (two fragment sets in registers), the activations of step g+2 are
+// split in the same stream, and there is ONE barrier per K-step.  Same rings, same counted waits as the ping-pong
+// kernel; tiles are walked one at a time.  State: parity-green, 5-10 % slower than the ping-pong kernel per launch
+// (220 / 123 / 255 us against 204 / 107 / 244 for in / pointwise / out at 32 utterances) with the tile drain still at
+// the end of the tile; what it is for is the register budget to hold a finished tile (a second accumulator set) and
+// spread its stores over the next tile's K-steps, which the 256-register waves of the ping-pong kernel cannot.
+// (Every lambda is force-inlined: called from the two copies of the loop body, hipcc otherwise keeps the captured
+// accumulators and fragment sets in scratch memory -- 9 x slower.)
+template <int PLANES>
+struct SoloLds {
+  static constexpr int A_SLOT = PLANES * XB_M * XB_K * 2;
+  static constexpr int B_SLOT = PLANES * XB_T * XB_K * 2;
+  static constexpr int NA = 3, D = 3;
+  static constexpr int RAW = XB_K * XB_T * 4;
+  static constexpr int OFF_RAW = NA * A_SLOT;
+  static constexpr int OFF_B = OFF_RAW + D * RAW;
+  static constexpr int OFF_TAB = OFF_B + 2 * B_SLOT;
+  static constexpr int OFF_BIAS = OFF_TAB + PP_MAXU * 1024 * 4;
+  static constexpr int TOTAL = OFF_BIAS + 4 * XB_M * 4;  // PLANES = 3: 132 KiB
+};
+
+template <int PLANES, bool TR, bool STATS, bool RES>
+__global__ __launch_bounds__(256, 1) void conv1x1_bf16_solo_kernel(BfArgs a) {
+  using L = SoloLds<PLANES>;
+  constexpr int P = 2 + 2 * PLANES;  // DMA operations per wave per K-step: 2 activation pieces, 2 * PLANES weight pieces
+  __shared__ __attribute__((aligned(16))) unsigned char smem[L::TOTAL];
+  float* tab = reinterpret_cast<float*>(smem + L::OFF_TAB);
+  float* bias_lds = reinterpret_cast<float*>(smem + L::OFF_BIAS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wt = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int S = a.ksteps;  // even (launcher)
+  const int ntiles = a.tiles_t * a.tiles_m * a.N;
+  const int G = gridDim.x;
+  const int lo = (int)((long long)blockIdx.x * ntiles / G), hi = (int)((long long)(blockIdx.x + 1) * ntiles / G);
+  if (lo >= hi) return;
+  const int total = (hi - lo) * S;
+  auto decode = [&](int idx, int& n, int& mt, int& tt) __attribute__((always_inline)) {
+    tt = idx % a.tiles_t;
+    const int r = idx / a.tiles_t;
+    mt = r % a.tiles_m;
+    n = r / a.tiles_m;
+  };
+  int n_lo, mt_lo, tt_lo;
+  decode(lo, n_lo, mt_lo, tt_lo);
+
+  const float slope = (TR && a.pro.prelu) ? a.pro.slope[0] : 1.f;
+  const bool plain_tr = !a.pro.pre_relu && !a.pro.post_tanh;
+  if constexpr (TR) {
+    const bool has_norm = a.pro.norm != PS_NORM_NONE;
+    const int n_hi = ((hi - 1) / a.tiles_t) / a.tiles_m;
+    for (int u = 0; u <= n_hi - n_lo; ++u) {
+      float mean = 0.f, rstd = 1.f;
+      if (a.pro.norm == PS_NORM_GLOBAL) {
+        double sa = 0.0, sq = 0.0;
+        const double* src = a.pro.stats + (size_t)(n_lo + u) * a.pro.parts * 2;
+        for (int i = lane; i < a.pro.parts; i += 64) {
+          sa += src[2 * i];
+          sq += src[2 * i + 1];
+        }
+        sa = wave_sum(sa);
+        sq = wave_sum(sq);
+        const double m = sa / a.pro.count;
+        double var = sq / a.pro.count - m * m;
+        var = var > 0.0 ? var : 0.0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)a.pro.eps));
+      }
+      for (int k = tid; k < 512; k += 256) {
+        float sc = 0.f, sh = 0.f;
+        if (k < a.K) {
+          sc = has_norm ? a.pro.gamma[k] * rstd : 1.f;
+          sh = has_norm ? a.pro.beta[k] - mean * sc : 0.f;
+        }
+        tab[u * 1024 + k] = sc;
+        tab[u * 1024 + 512 + k] = sh;
+      }
+    }
+  }
+
+  // ---- activation DMA -------------------------------------------------------------------------------------------------
+  const int x_voff = ((lane >> 5) * a.ldt + (lane & 31) * 4) * 4;
+  const int x_step = XB_K * a.ldt * 4, x_half = 8 * a.ldt * 4;
+  float* const raw_w = reinterpret_cast<float*>(smem + L::OFF_RAW) + wave * 256;
+  int xi = lo, xk = 0, xso = 0;
+  __amdgpu_buffer_rsrc_t xr;
+  auto x_setup = [&]() __attribute__((always_inline)) {
+    int n, mt, tt;
+    decode(xi, n, mt, tt);
+    xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)n * a.K * a.ldt, 0,
+                                           xi < hi ? a.K * a.ldt * 4 : 0, 0x00020000);
+    xso = (wave * 2 * a.ldt + tt * XB_T) * 4;
+  };
+  auto dma_x = [&](int slot) __attribute__((always_inline)) {
+    float* dst = raw_w + slot * (L::RAW / 4);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, x_voff, xso, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst + 1024, 16, x_voff, xso + x_half, 0, 0);
+  };
+  auto x_advance = [&]() __attribute__((always_inline)) {
+    xso += x_step;
+    if (++xk == S) {
+      xk = 0;
+      ++xi;
+      x_setup();
+    }
+  };
+  // ---- weight DMA -----------------------------------------------------------------------------------------------------
+  const int w_voff = lane * 16;
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned short*>(a.wt), 0, a.tiles_m * S * L::A_SLOT, 0x00020000);
+  const int a_share = wave * 64 * 16;
+  int ai = lo, ak = 0, aso = 0;
+  auto a_setup = [&]() __attribute__((always_inline)) {
+    int n, mt, tt;
+    decode(ai, n, mt, tt);
+    aso = ai < hi ? mt * S * L::A_SLOT + a_share : 0x7f000000;
+  };
+  auto dma_a = [&](int slot) __attribute__((always_inline)) {
+    float* dst = reinterpret_cast<float*>(smem + slot * L::A_SLOT + a_share);
+#pragma unroll
+    for (int i = 0; i < 2 * PLANES; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst + i * 1024, 16, w_voff, aso + i * 4096, 0, 0);
+  };
+  auto a_advance = [&]() __attribute__((always_inline)) {
+    aso += L::A_SLOT;
+    if (++ak == S) {
+      ak = 0;
+      ++ai;
+      a_setup();
+    }
+  };
+  auto bias_dma = [&](int n, int mt, int par) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.bias ? a.bias : a.x), 0, a.bias ? a.M * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bnr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.bias_n ? a.bias_n + (size_t)n * a.M : a.x), 0, a.bias_n ? a.M * 4 : 0, 0x00020000);
+    float* dst = bias_lds + par * 2 * XB_M;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(br, dst, 16, w_voff, mt * XB_M * 4, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(bnr, dst + XB_M, 16, w_voff, mt * XB_M * 4, 0, 0);
+  };
+
+  // ---- staging --------------------------------------------------------------------------------------------------------
+  const int bt = tid & 127, bh = tid >> 7;
+  const float* const raw_r = reinterpret_cast<const float*>(smem + L::OFF_RAW) + 8 * bh * XB_T + bt;
+  unsigned char* const bx_w = smem + L::OFF_B + (bt * XB_K + 8 * bh) * 2;
+  int si = lo, sk = 0, spar = 0;
+  const float* stab = tab + 8 * bh;
+  auto s_setup = [&]() __attribute__((always_inline)) {
+    int n, mt, tt;
+    decode(si, n, mt, tt);
+    stab = tab + (n - n_lo) * 1024 + 8 * bh;
+    if (wave == 0 && si < hi) bias_dma(n, mt, spar);
+  };
+  auto stage_b = [&](int rslot, int bslot) __attribute__((always_inline)) {
+    if (si >= hi) return;
+    const float* raw = raw_r + rslot * (L::RAW / 4);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = raw[j * XB_T];
+    if constexpr (TR) {
+      const f32x4 sc0 = *reinterpret_cast<const f32x4*>(stab), sc1 = *reinterpret_cast<const f32x4*>(stab + 4);
+      const f32x4 sh0 = *reinterpret_cast<const f32x4*>(stab + 512), sh1 = *reinterpret_cast<const f32x4*>(stab + 516);
+      if (plain_tr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = prelu(v[j] * (j < 4 ? sc0[j & 3] : sc1[j & 3]) + (j < 4 ? sh0[j & 3] : sh1[j & 3]), slope);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float u = v[j];
+          if (a.pro.pre_relu) u = fmaxf(u, 0.f);
+          u = u * (j < 4 ? sc0[j & 3] : sc1[j & 3]) + (j < 4 ? sh0[j & 3] : sh1[j & 3]);
+          u = prelu(u, slope);
+          if (a.pro.post_tanh) u = tanhf(u);
+          v[j] = u;
+        }
+      }
+    }
+    unsigned char* dstb = bx_w + bslot * L::B_SLOT;
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p) {
+      bf16x8 piece;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const bf16x2 hh = __builtin_convertvector(f32x2v{v[j], v[j + 1]}, bf16x2);
+        piece[j] = hh[0];
+        piece[j + 1] = hh[1];
+        if (p + 1 < PLANES) {
+          const f32x2v back = __builtin_convertvector(hh, f32x2v);
+          v[j] -= back[0];
+          v[j + 1] -= back[1];
+        }
+      }
+      *reinterpret_cast<bf16x8*>(dstb + p * XB_T * XB_K * 2) = piece;
+    }
+  };
+  auto s_advance = [&]() __attribute__((always_inline)) {
+    stab += XB_K;
+    if (++sk == S) {
+      sk = 0;
+      ++si;
+      spar ^= 1;
+      s_setup();
+    }
+  };
+
+  // ---- compute side ---------------------------------------------------------------------------------------------------
+  f32x16 acc[4][2];
+  const int lane_off = (4 * lh * a.ldt + lr) * 4;
+  auto init_acc = [&](int idx) __attribute__((always_inline)) {
+    if constexpr (RES) {
+      int n, mt, tt;
+      decode(idx, n, mt, tt);
+      const int slab = a.M * a.ldt * 4;
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(a.res) + (size_t)n * a.M * a.ldt, 0, idx < hi ? slab : 0, 0x00020000);
+      const int tile_off = ((mt * XB_M + wm * 128) * a.ldt + tt * XB_T + wt * 64) * 4;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rc = mi * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti)
+            acc[mi][ti][r] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, tile_off + rc * a.ldt * 4 + ti * 128, 0));
+        }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ti][r] = 0.f;
+    }
+  };
+  auto acc_fence = [&]() __attribute__((always_inline)) {
+    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]),
+                 "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
+  };
+  const unsigned char* const a_frag = smem + ((wm * 128 + lr) * XB_K + 8 * lh) * 2;
+  const unsigned char* const b_frag = smem + L::OFF_B + ((wt * 64 + lr) * XB_K + 8 * lh) * 2;
+  bf16x8 fb[2][PLANES][2], fa[2][4][PLANES];  // two fragment sets: the one the MFMAs read, the one being prefetched
+  auto read_frags = [&](auto q_c, int aslot, int bslot) __attribute__((always_inline)) {
+    constexpr int q = decltype(q_c)::value;
+    const unsigned char* sa = a_frag + aslot * L::A_SLOT;
+    const unsigned char* sb = b_frag + bslot * L::B_SLOT;
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) fb[q][p][ti] = *reinterpret_cast<const bf16x8*>(sb + (p * XB_T + ti * 32) * XB_K * 2);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int p = 0; p < PLANES; ++p)
+        fa[q][mi][p] = *reinterpret_cast<const bf16x8*>(sa + ((p * XB_M + mi * 32) * XB_K) * 2);
+  };
+  auto mfma_block = [&](auto q_c, auto mi_c) __attribute__((always_inline)) {
+    constexpr int q = decltype(q_c)::value, mi = decltype(mi_c)::value;
+    if constexpr (PLANES == 3) {
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][mi][1], fb[q][1][ti], acc[mi][ti], 0, 0, 0);
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][mi][2], fb[q][0][ti], acc[mi][ti], 0, 0, 0);
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][mi][0], fb[q][2][ti], acc[mi][ti], 0, 0, 0);
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][mi][1], fb[q][0][ti], acc[mi][ti], 0, 0, 0);
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][mi][0], fb[q][1][ti], acc[mi][ti], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][mi][0], fb[q][0][ti], acc[mi][ti], 0, 0, 0);
+  };
+
+  auto drain = [&](int idx, int parity) __attribute__((always_inline)) {
+    int n, mt, tt;
+    decode(idx, n, mt, tt);
+    const int m0 = mt * XB_M, t0 = tt * XB_T;
+    float fsum = 0.f, fsq = 0.f;
+    const int slab = a.M * a.ldt * 4;
+    const __amdgpu_buffer_rsrc_t yr =
+        __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)n * a.M * a.ldt, 0, slab, 0x00020000);
+    const int tile_off = ((m0 + wm * 128) * a.ldt + t0 + wt * 64) * 4;
+    int nn, nmt, ntt;
+    decode(idx + 1, nn, nmt, ntt);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(RES ? a.res : a.y) + (size_t)nn * a.M * a.ldt, 0, (RES && idx + 1 < hi) ? slab : 0, 0x00020000);
+    [[maybe_unused]] const int ntile_off = ((nmt * XB_M + wm * 128) * a.ldt + ntt * XB_T + wt * 64) * 4;
+    bool cm[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) cm[ti] = t0 + wt * 64 + ti * 32 + lr < a.T;
+    const float* bl = bias_lds + parity * 2 * XB_M + wm * 128 + 4 * lh;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + mi * 32 + 8 * rq) +
+                         *reinterpret_cast<const f32x4*>(bl + XB_M + mi * 32 + 8 * rq);
+#pragma unroll
+        for (int r3 = 0; r3 < 4; ++r3) {
+          const int r = rq * 4 + r3;
+          const int rc = mi * 32 + r3 + 8 * rq;
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti) {
+            const float v = acc[mi][ti][r] + b4[r3];
+            if constexpr (STATS) {
+              const float vm = cm[ti] ? v : 0.f;
+              fsum += vm;
+              fsq += vm * vm;
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, lane_off,
+                                                  tile_off + rc * a.ldt * 4 + ti * 128, 0);
+            if constexpr (RES)
+              acc[mi][ti][r] = __builtin_bit_cast(
+                  float, __builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, ntile_off + rc * a.ldt * 4 + ti * 128, 0));
+            else
+              acc[mi][ti][r] = 0.f;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if constexpr (STATS) {
+      const double s = wave_sum_dpp(fsum), q = wave_sum_dpp(fsq);
+      if (lane == 0) {
+        const int parts = a.tiles_m * a.tiles_t * 4;
+        double* dst = a.ostats + ((size_t)n * parts + (mt * a.tiles_t + tt) * 4 + wave) * 2;
+        dst[0] = s;
+        dst[1] = q;
+      }
+    }
+  };
+
+  // ---- prologue -------------------------------------------------------------------------------------------------------
+  x_setup();
+  a_setup();
+  for (int j = 0; j < 3; ++j) {
+    dma_x(j);
+    x_advance();
+    dma_a(j);
+    a_advance();
+  }
+  if (wave == 0) bias_dma(n_lo, mt_lo, 0);
+  init_acc(lo);
+  acc_fence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  stage_b(0, 0);  // x(0) -> Bx[0]
+  s_advance();
+  stage_b(1, 1);  // x(1) -> Bx[1]
+  s_advance();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  dma_x(0);  // x(3) -> raw slot 0 (x(0) has been staged)
+  x_advance();
+  read_frags(bic<0>{}, 0, 0);
+
+  int ci = lo, ck = 0, parity = 0;
+  int r3 = 0;  // g % 3
+  auto body = [&](int g, auto q_c) __attribute__((always_inline)) {
+    constexpr int q = decltype(q_c)::value;
+    const int r1 = r3 + 1 == 3 ? 0 : r3 + 1, r2 = r1 + 1 == 3 ? 0 : r1 + 1;
+    read_frags(bic<q ^ 1>{}, r1, (g + 1) & 1);  // fragments of step g+1
+    mfma_block(q_c, bic<0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    dma_x(r1);  // x(g+4) -> raw slot (g+4) % 3
+    x_advance();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(q_c, bic<1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    dma_a(r3);  // A(g+3) -> slot g % 3 (its fragments are in registers)
+    a_advance();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(q_c, bic<2>{});
+    mfma_block(q_c, bic<3>{});
+    if (ck == S - 1) {
+      drain(ci, parity);
+      parity ^= 1;
+      stage_b(r2, g & 1);  // x(g+2) -> Bx[g & 1]
+      acc_fence();
+    } else {
+      stage_b(r2, g & 1);
+    }
+    s_advance();
+    if (++ck == S) {
+      ck = 0;
+      ++ci;
+    }
+    r3 = r1;
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  for (int g = 0; g < total; g += 2) {
+    body(g, bic<0>{});
+    body(g + 1, bic<1>{});
+  }
+}
+
 static int bf16_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -952,6 +1357,26 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
   const long long per_wg = (nsuper + G - 1) / G, per_utt = (long long)st_per * a.tiles_m;
   const bool big = 2 * nsuper >= cus || (g_debug_flags & (1 << 28));  // bit 28: ping-pong kernel at any size (tests)
   const bool pp = !(g_debug_flags & (1 << 27)) && a.ksteps >= 4 && big && (per_wg + per_utt - 2) / per_utt + 1 <= PP_MAXU;
+  const long long ntiles_all = (long long)a.tiles_t * a.tiles_m * N;
+  const int Gs = (int)(ntiles_all < cus ? ntiles_all : cus);
+  const long long per_wg_s = (ntiles_all + Gs - 1) / Gs, per_utt_s = (long long)a.tiles_t * a.tiles_m;
+  const bool solo = (g_debug_flags & (1 << 30)) && a.ksteps >= 4 && a.ksteps % 2 == 0 && ntiles_all >= cus &&
+                    (per_wg_s + per_utt_s - 2) / per_utt_s + 1 <= PP_MAXU;
+  if (solo) {
+#define PS_SOLO(TRV, STV, RSV) \
+  hipLaunchKernelGGL((conv1x1_bf16_solo_kernel<PLANES, TRV, STV, RSV>), dim3(Gs, 1), dim3(256), 0, stream, a)
+    if (tr) {
+      if (stats) PS_SOLO(true, true, false);
+      else if (res) PS_SOLO(true, false, true);
+      else PS_SOLO(true, false, false);
+    } else {
+      if (stats) PS_SOLO(false, true, false);
+      else if (res) PS_SOLO(false, false, true);
+      else PS_SOLO(false, false, false);
+    }
+#undef PS_SOLO
+    return;
+  }
   if (pp) {
 #define PS_PP(TRV, STV, RSV) \
   hipLaunchKernelGGL((conv1x1_bf16_pp_kernel<PLANES, TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)

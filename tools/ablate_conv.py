@@ -41,7 +41,7 @@ for name, (K, M, pro, res) in shapes.items():
         us = e0.elapsed_time(e1) / reps * 1e3
         res_line.append(f"{fname}={us:.0f}us")
     lib.ps_debug_flags(0)
-    for planes, abl in ((3, 0), (3, 8), (1, 0), (1, 8)):
+    for planes, abl in ((3, 0), (3, 8), (3, 64), (1, 0), (1, 8), (1, 64)):  # 64 = bit 30: single-wave experiment
         lib.ps_debug_flags(abl << 24)  # abl 8 = bit 27: simple (non-persistent) kernel
         wb = hip.pack_wt_bf16(torch.randn(M, K, device=dev) * 0.05, planes)
         for _ in range(3):
