@@ -753,7 +753,9 @@ def test_fused_streaming_step_kernels(H, dev):
                                           # deep K loops over many supertiles: the counted DMA waits of the ping-pong
                                           # kernel (a wait that is too weak shows as stale operands, first with planes = 1)
                                           (8, 512, 256, 3999, "stats"), (8, 256, 512, 3999, "norm_res"),
-                                          (8, 256, 256, 3999, "norm_stats")])
+                                          (8, 256, 256, 3999, "norm_stats"),
+                                          # per-utterance bias (the speaker embedding folded into in_conv) at that size
+                                          (8, 512, 256, 3999, "stats_bias_n")])
 def test_conv1x1_bf16_planes(H, dev, planes, tol, n, k, m, t, mode):
     from puresound_amd import _abi
     x = _rand((n, k, t), 121) + 0.2
@@ -770,8 +772,11 @@ def test_conv1x1_bf16_planes(H, dev, planes, tol, n, k, m, t, mode):
         keep = (gamma.to(dev), beta.to(dev), slope.to(dev))
         pro = H.make_prologue(_abi.PS_NORM_AFFINE, True, None, 0.0, 0.0, keep[0], keep[1], keep[2])
     ref = torch.matmul(w.double(), a) + b.double().reshape(1, -1, 1)
+    bias_n = _rand((n, m), 127) if mode.endswith("bias_n") else None
+    if bias_n is not None:
+        ref = ref + bias_n.double().reshape(n, m, 1)
     res = _rand((n, m, t), 126) if mode == "norm_res" else None
-    want = mode in ("norm_stats", "stats")
+    want = mode in ("norm_stats", "stats", "stats_bias_n")
     if res is not None:
         ref = ref + res.double()
     # flag bit 27 = simple kernel only (small grids take its 256 x 32 tile), bit 29 = keep its 256 x 128 tile,
@@ -780,7 +785,8 @@ def test_conv1x1_bf16_planes(H, dev, planes, tol, n, k, m, t, mode):
     for flags in (0, 1 << 27, (1 << 27) | (1 << 29), 1 << 28, 1 << 30):
         old = _abi.lib().ps_debug_flags(flags)
         try:
-            y, st = H.conv1x1_bf16(H.pad_rows(x.to(dev)), t, H.pack_wt_bf16(w.to(dev), planes), m, pro, b.to(dev), None,
+            y, st = H.conv1x1_bf16(H.pad_rows(x.to(dev)), t, H.pack_wt_bf16(w.to(dev), planes), m, pro, b.to(dev),
+                                   None if bias_n is None else bias_n.to(dev),
                                    None if res is None else H.pad_rows(res.to(dev)), want_stats=want)
             torch.cuda.synchronize()
         finally:
