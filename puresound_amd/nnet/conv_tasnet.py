@@ -70,9 +70,12 @@ class TCN(_PlanCache, nn.Module):
         self._plan_sig = None
 
     # -- kernel-side weight layout ----------------------------------------------------------------
-    #: arithmetic of the three 1x1 convs: "fp32" (exact fp32 MFMA, default), "bf16" (bf16 products, fp32 accumulate:
-    #: what BASELINE.json names for its bf16 configurations) or "bf16x3" (fp32-accurate 3-way bf16 split)
-    gemm_precision = "fp32"
+    #: arithmetic of the three 1x1 convs: "bf16x3" (default: every fp32 operand as three bf16 terms, six products on the
+    #: bf16 matrix pipe, fp32 accumulation -- the same deviation from the reference as fp32 MFMA operands, DESIGN.md 4.1b;
+    #: 1.36 x faster at 32 utterances, 1.5 x at one), "fp32" (v_mfma_f32 on fp32 operands; a row's result is then
+    #: bit-identical whatever batch it is part of) or "bf16" (operands rounded to bf16: what BASELINE.json names for its
+    #: bf16 configurations; not an fp32 result)
+    gemm_precision = "bf16x3"
 
     def plan(self, device: torch.device) -> dict:
         planes = GEMM_PLANES[self.gemm_precision]
@@ -344,7 +347,7 @@ class ConvTasNet(_PlanCache, nn.Module):
         self._workspace = None
 
     def set_gemm_precision(self, name: str) -> "ConvTasNet":
-        """"fp32" (default) | "bf16" | "bf16x3" for the 1x1 convs of every normal TCN block (see TCN.gemm_precision)."""
+        """"bf16x3" (default) | "fp32" | "bf16" for the 1x1 convs of every normal TCN block (see TCN.gemm_precision)."""
         if name not in GEMM_PLANES:
             raise ValueError(f"gemm precision must be one of {sorted(GEMM_PLANES)}")
         for stack in self.tcn_list:

@@ -472,6 +472,7 @@ def test_full_batch_properties(PA, dev, golden_dir):
     model = cases.build(PA.NS, name).eval()
     model.load_state_dict(det_state_dict(model))
     model.to(dev)
+    model.masker.set_gemm_precision("fp32")  # (bit-for-bit batch independence is the fp32 MFMA path's property)
     first = det_wave(cases.CASES[name]["seed"], 1, 64000)
     rest = det_wave(99, 31, 64000)
     batch = torch.cat([first, rest]).to(dev)
@@ -840,11 +841,12 @@ def test_full_size_properties_of_the_other_baseline_configs(PA, dev, name, gemm)
     sd = det_state_dict(model)
     model.load_state_dict(sd)
     model.to(dev)
-    if gemm != "fp32":  # the split GEMM (masker and speaker net): rows agree to fp32 rounding instead of bit for bit
+    # fp32 MFMA operands: rows bit for bit independent of the batch; split GEMM: to fp32 rounding
+    if hasattr(model.masker, "set_gemm_precision"):
         model.masker.set_gemm_precision(gemm)
-        for m in model.speaker_net:
-            if hasattr(m, "gemm_precision"):
-                m.gemm_precision = gemm
+    for m in (model.speaker_net if getattr(model, "speaker_net", None) is not None else []):
+        if hasattr(m, "gemm_precision"):
+            m.gemm_precision = gemm
     tse = "L_enroll" in c
     noisy = det_wave(301, 32, 64000)
     enroll = det_wave(302, 32, 64000) if tse else None
