@@ -79,6 +79,8 @@ class TCN(_PlanCache, nn.Module):
 
     def plan(self, device: torch.device) -> dict:
         planes = GEMM_PLANES[self.gemm_precision]
+        if max(self.in_channels, self.hid_channels) > 512:
+            planes = 0  # ps_conv1x1_bf16_f32 keeps prologue tables for up to 512 input channels: wider blocks run fp32
         sig = (_param_signature(self), str(device), planes)
         if self._plan is not None and self._plan_sig == sig:
             return self._plan
