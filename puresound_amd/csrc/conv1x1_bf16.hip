@@ -1330,6 +1330,8 @@ __global__ __launch_bounds__(256, 1) void conv1x1_bf16_solo_kernel(BfArgs a) {
   }
 }
 
+#include "conv1x1_bf16_ob.inc"
+
 static int bf16_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -1375,6 +1377,21 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
       else PS_SOLO(false, false, false);
     }
 #undef PS_SOLO
+    return;
+  }
+  if (pp && !(g_debug_flags & 32)) {  // bit 5: keep the two-barrier ping-pong kernel (tests run both)
+#define PS_OB(TRV, STV, RSV) \
+  hipLaunchKernelGGL((conv1x1_bf16_ob_kernel<PLANES, TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)
+    if (tr) {
+      if (stats) PS_OB(true, true, false);
+      else if (res) PS_OB(true, false, true);
+      else PS_OB(true, false, false);
+    } else {
+      if (stats) PS_OB(false, true, false);
+      else if (res) PS_OB(false, false, true);
+      else PS_OB(false, false, false);
+    }
+#undef PS_OB
     return;
   }
   if (pp) {
