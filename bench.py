@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="HIP streams the batch is split over inside one GPU (default: the model's own default)")
     ap.add_argument("--gemm", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
                     help="arithmetic of the 1x1-conv GEMMs.  bf16x3 (default): every fp32 operand split into three "
                          "bf16 terms, six products on the bf16 MFMA pipe, fp32 accumulation -- the result carries "
@@ -123,6 +125,8 @@ def main():
     lib = _abi.lib()  # no HIP extension, no benchmark
     model = build_model(dev)
     model.masker.set_gemm_precision(args.gemm)
+    if args.streams is not None:
+        model.hip_streams = args.streams
 
     g = torch.Generator().manual_seed(1234 + rank)
     noisy = ((torch.rand(B_PER_GPU, L, generator=g) * 2 - 1) * 0.5).to(dev)  # synthetic 16 kHz waveforms

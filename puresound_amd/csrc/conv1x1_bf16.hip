@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_bf16_solo_kernel(BfArgs a) {
   }
 }
 
-#include "conv1x1_bf16_ob.inc"
+#include "conv1x1_bf16_il.inc"
 
 static int bf16_cus() {
   static int cus = 0;
@@ -1379,19 +1379,22 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
 #undef PS_SOLO
     return;
   }
-  if (pp && !(g_debug_flags & 32)) {  // bit 5: keep the two-barrier ping-pong kernel (tests run both)
-#define PS_OB(TRV, STV, RSV) \
-  hipLaunchKernelGGL((conv1x1_bf16_ob_kernel<PLANES, TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)
+  // bit 5: keep the two-barrier ping-pong kernel (tests run both).  The interleaved kernel's chunked prologue is
+  // scale / shift + PReLU only.
+  const bool plain_tr = !a.pro.pre_relu && !a.pro.post_tanh;
+  if (pp && plain_tr && !(g_debug_flags & 32)) {
+#define PS_IL(TRV, STV, RSV) \
+  hipLaunchKernelGGL((conv1x1_bf16_il_kernel<PLANES, TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)
     if (tr) {
-      if (stats) PS_OB(true, true, false);
-      else if (res) PS_OB(true, false, true);
-      else PS_OB(true, false, false);
+      if (stats) PS_IL(true, true, false);
+      else if (res) PS_IL(true, false, true);
+      else PS_IL(true, false, false);
     } else {
-      if (stats) PS_OB(false, true, false);
-      else if (res) PS_OB(false, false, true);
-      else PS_OB(false, false, false);
+      if (stats) PS_IL(false, true, false);
+      else if (res) PS_IL(false, false, true);
+      else PS_IL(false, false, false);
     }
-#undef PS_OB
+#undef PS_IL
     return;
   }
   if (pp) {

@@ -783,7 +783,7 @@ def test_conv1x1_bf16_planes(H, dev, planes, tol, n, k, m, t, mode):
     # flag bit 27 = simple kernel only (small grids take its 256 x 32 tile), bit 29 = keep its 256 x 128 tile,
     # bit 28 = the persistent ping-pong kernel at any size
     # bit 30 = the single-wave-per-SIMD experiment (where the launch is large enough for it)
-    # bit 5 (32) = the two-barrier ping-pong kernel instead of the one-barrier persistent kernel
+    # bit 5 (32) = the two-barrier ping-pong kernel instead of the interleaved one-barrier kernel
     for flags in (0, 32, 1 << 27, (1 << 27) | (1 << 29), 1 << 28, (1 << 28) | 32, 1 << 30):
         old = _abi.lib().ps_debug_flags(flags)
         try:

@@ -41,10 +41,10 @@ for name, (K, M, pro, res) in shapes.items():
         us = e0.elapsed_time(e1) / reps * 1e3
         res_line.append(f"{fname}={us:.0f}us")
     lib.ps_debug_flags(0)
-    # flags: 0 = default (one-barrier persistent kernel), 32 = two-barrier ping-pong kernel, bit 27 = simple kernel,
+    # flags: 0 = default (interleaved one-barrier persistent kernel), 32 = two-barrier ping-pong kernel, bit 27 = simple kernel,
     # bit 30 = single-wave experiment; extra flag bits from the command line are OR-ed in (kernel experiments)
     extra = int(sys.argv[1], 0) if len(sys.argv) > 1 else 0
-    for planes, abl in ((3, 0), (3, 32), (3, 8 << 24), (1, 0), (1, 32)):
+    for planes, abl in ((3, 0), (3, 32), (1, 0), (1, 32)):
         lib.ps_debug_flags(abl | (extra if abl == 0 else 0))
         wb = hip.pack_wt_bf16(torch.randn(M, K, device=dev) * 0.05, planes)
         for _ in range(3):
@@ -57,6 +57,6 @@ for name, (K, M, pro, res) in shapes.items():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 10 * 1e3
-        res_line.append(f"bf16x{planes}/{ {0: 'ob', 32: 'pp'}.get(abl, 'simple') }={us:.0f}us ({flop / us / 1e6 * (6 if planes == 3 else 1) / 2500:.2f})")
+        res_line.append(f"bf16x{planes}/{ {0: 'il', 32: 'pp'}.get(abl, 'simple') }={us:.0f}us ({flop / us / 1e6 * (6 if planes == 3 else 1) / 2500:.2f})")
     lib.ps_debug_flags(0)
     print(name, f"(peak {flop / 157.3e12 * 1e6:.0f}us)", "  ".join(res_line), flush=True)

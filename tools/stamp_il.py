@@ -1,6 +1,6 @@
-"""Cycle buckets of conv1x1_bf16_ob_kernel per (workgroup, half) from a -DPS_PP_STAMPS build (s_memtime):
-MFMA burst / staging (+ DMA issue for half 1) / wait + barrier / drain.  Run on the GPU box:
-  make -C puresound_amd/csrc clean all EXTRA=-DPS_PP_STAMPS && python tools/stamp_ob.py [extra debug flags]"""
+"""Cycle buckets of conv1x1_bf16_il_kernel per (workgroup, half) from a -DPS_PP_STAMPS build (s_memtime):
+interval body (MFMAs + chunks) / wait + barrier / drain.  Run on the GPU box:
+  make -C puresound_amd/csrc clean all EXTRA=-DPS_PP_STAMPS && python tools/stamp_il.py [extra debug flags]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -31,5 +31,5 @@ for planes in (3,):
             tot = np.maximum(q[:, 5], 1)
             tiles = tot / ((K + 15) // 16)
             print(f"bf16x{planes} {name} [half {h}]: steps/WG {int(np.median(tot))} total cyc {int(np.median(q[:,0]))} = {np.median(q[:,0]/tot):.0f}/step; "
-                  f"per step med: mfma {np.median(q[:,1]/tot):.0f} stage {np.median(q[:,2]/tot):.0f} wait+barrier {np.median(q[:,3]/tot):.0f}; "
+                  f"per step med: body {np.median(q[:,1]/tot):.0f} stage {np.median(q[:,2]/tot):.0f} wait+barrier {np.median(q[:,3]/tot):.0f}; "
                   f"drain per tile {np.median(q[:,4]/tiles):.0f}", flush=True)

@@ -6,5 +6,5 @@ for arg in "$@"; do
   touch puresound_amd/csrc/conv1x1_bf16.hip
   make -C puresound_amd/csrc EXTRA="-DPS_PP_STAMPS $extra" > /dev/null 2>&1 || { echo "build failed: $extra"; exit 1; }
   echo "== EXTRA=$extra flags=$flags"
-  timeout -k 10 120 python tools/stamp_ob.py $flags 2>/dev/null
+  timeout -k 10 120 python tools/stamp_il.py $flags 2>/dev/null
 done
