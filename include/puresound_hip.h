@@ -171,6 +171,11 @@ int ps_embed_bias_f32(const float* dvec, const float* w_embed, float* bias_n, in
  * ------------------------------------------------------------------------------------------- */
 int ps_attn_stats_pool_f32(const float* logits, const float* x, float* out, int N, int C, int T, int ldt,
                            float eps, void* stream);
+/* The same with the `lengths` argument of the reference (lobe/pooling.py:87-107): lengths is [N] relative lengths in
+ * (0, 1] (NULL = all ones); frame t of utterance n takes part iff (float)t < lengths[n] * (float)T, which is
+ * length_to_mask(lengths * L) (pooling.py:9-50) followed by masked_fill(-inf). */
+int ps_attn_stats_pool_len_f32(const float* logits, const float* x, const float* lengths, float* out, int N, int C,
+                               int T, int ldt, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ps_conv1x1_bf16_f32: the same operation as ps_conv1x1_f32 (same prologue, bias, residual, statistics, fp32 tensors

@@ -70,6 +70,7 @@ SIGNATURES = {
     "ps_conv1x1_bf16_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 6 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
     "ps_dwconv_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp]),
     "ps_attn_stats_pool_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "ps_attn_stats_pool_len_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
     "ps_lstm_f32": (C.c_int, [C.POINTER(LstmArgs), _vp]),
     "ps_unfold_taps_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 7 + [_vp, _vp, _vp, C.c_int, _vp]),
     "ps_gated_product_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [C.POINTER(Prologue), C.POINTER(Prologue), _vp]),
@@ -143,6 +144,18 @@ def require_device(t: torch.Tensor, what: str) -> None:
                            f"there is no CPU fallback")
     if t.dtype != torch.float32:
         raise RuntimeError(f"{what}: fp32 tensors only (got {t.dtype})")
+
+
+def require_weight(w: torch.Tensor, like: torch.Tensor, what: str) -> None:
+    """A parameter handed to a kernel as a raw pointer: it has to live on the input's device, as contiguous fp32 --
+    a model left on the CPU, on another GPU or in half precision would otherwise reach the kernel as a wild pointer."""
+    if not w.is_cuda or w.device != like.device:
+        raise RuntimeError(f"{what}: the module's parameters are on {w.device} but the input is on {like.device} "
+                           f"(move the model with .to(device); there is no CPU fallback)")
+    if w.dtype != torch.float32:
+        raise RuntimeError(f"{what}: fp32 parameters only (got {w.dtype})")
+    if not w.is_contiguous():
+        raise RuntimeError(f"{what}: parameters must be contiguous")
 
 
 def padded_frames(t: int) -> int:

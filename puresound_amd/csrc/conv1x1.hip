@@ -220,8 +220,8 @@ __device__ __forceinline__ void conv1x1_body(const Conv1x1Args& a, float* lds) {
     if (pre_relu) {  // kernel-uniform
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v0[e] = fmaxf(v0[e], 0.f);
-        v1[e] = fmaxf(v1[e], 0.f);
+        v0[e] = relu_keep_nan(v0[e]);
+        v1[e] = relu_keep_nan(v1[e]);
       }
     }
 #pragma unroll

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
       float u = breg[q][j];
       if constexpr (TR) {
         const int k = ks * XB_K + 8 * bh + j;
-        if (a.pro.pre_relu) u = fmaxf(u, 0.f);
+        if (a.pro.pre_relu) u = relu_keep_nan(u);
         u = u * tab[k] + tab[512 + k];
         if (a.pro.prelu) u = prelu(u, slope);
         if (a.pro.post_tanh) u = tanhf(u);
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_bf16_pp_kernel(BfArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float u = v[j];
-          if (a.pro.pre_relu) u = fmaxf(u, 0.f);
+          if (a.pro.pre_relu) u = relu_keep_nan(u);
           u = u * (j < 4 ? sc0[j & 3] : sc1[j & 3]) + (j < 4 ? sh0[j & 3] : sh1[j & 3]);
           u = prelu(u, slope);
           if (a.pro.post_tanh) u = tanhf(u);
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_bf16_solo_kernel(BfArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float u = v[j];
-          if (a.pro.pre_relu) u = fmaxf(u, 0.f);
+          if (a.pro.pre_relu) u = relu_keep_nan(u);
           u = u * (j < 4 ? sc0[j & 3] : sc1[j & 3]) + (j < 4 ? sh0[j & 3] : sh1[j & 3]);
           u = prelu(u, slope);
           if (a.pro.post_tanh) u = tanhf(u);

@@ -22,7 +22,7 @@ struct SmallArgs {
 };
 
 __device__ __forceinline__ float small_transform(const SmallArgs& a, float v, int k, float slope) {
-  if (a.pro.pre_relu) v = fmaxf(v, 0.f);
+  if (a.pro.pre_relu) v = relu_keep_nan(v);
   if (a.pro.norm == PS_NORM_AFFINE) v = v * a.pro.gamma[k] + a.pro.beta[k];
   if (a.pro.prelu) v = prelu(v, slope);
   if (a.pro.post_tanh) v = tanhf(v);

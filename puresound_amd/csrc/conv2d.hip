@@ -30,7 +30,7 @@ constexpr int C2D_UN = 8;       // k-pairs whose loads are in flight together
 
 __device__ __forceinline__ float act_apply(float u, int kind, float s) {
   switch (kind) {
-    case 1: return fmaxf(u, 0.f);
+    case 1: return relu_keep_nan(u);
     case 2: return u >= 0.f ? u : s * u;
     case 3: return u * tanhf(u > 20.f ? u : log1pf(expf(u)));
     case 4: return 1.f / (1.f + expf(-u));

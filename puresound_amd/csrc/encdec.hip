@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void free_encode_kernel(const float* __restric
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < WIN; ++j) s = fmaf(wc[j], xr[j], s);
-      if (relu) s = fmaxf(s, 0.f);
+      if (relu) s = relu_keep_nan(s);
       if (live) out[(size_t)c * ldt] = s;
     }
   } else {
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void free_encode_kernel(const float* __restric
       const float* wc = w + (size_t)c * win;
       float s = 0.f;
       for (int j = 0; j < win; ++j) s = fmaf(wc[j], xs[j], s);
-      if (relu) s = fmaxf(s, 0.f);
+      if (relu) s = relu_keep_nan(s);
       out[(size_t)c * ldt] = s;
     }
   }
@@ -58,13 +58,13 @@ __global__ __launch_bounds__(256) void free_encode_kernel(const float* __restric
 // workgroup (no atomics, deterministic).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float mask_act(float m, int act) {
-  if (act == PS_ACT_RELU) return fmaxf(m, 0.f);
+  if (act == PS_ACT_RELU) return relu_keep_nan(m);
   if (act == PS_ACT_SIGMOID) return 1.f / (1.f + expf(-m));
   return m;
 }
 
 __device__ __forceinline__ float out_constrain(float v, int mode) {
-  if (mode == PS_OUT_CLAMP) return fminf(fmaxf(v, -1.f), 1.f);
+  if (mode == PS_OUT_CLAMP) return clamp1_keep_nan(v);
   if (mode == PS_OUT_SIGMOID) return 1.f / (1.f + expf(-v));
   return v;
 }

@@ -29,11 +29,25 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return v;
 }
 
+// `lens` (optional, [N] relative lengths): frame t of utterance n takes part iff (float)t < lens[n] * (float)T, the
+// fp32 comparison of length_to_mask(lengths * L) (lobe/pooling.py:9-50, 100-107 of the reference); masked frames get
+// weight exp(-inf) = 0, i.e. they are left out of every sum.  No valid frame at all gives NaN as the reference does.
 __global__ __launch_bounds__(256) void attn_stats_pool_kernel(const float* __restrict__ logits,
-                                                              const float* __restrict__ x, float* __restrict__ out,
-                                                              int C, int T, int ldt, float eps) {
+                                                              const float* __restrict__ x,
+                                                              const float* __restrict__ lens, float* __restrict__ out,
+                                                              int C, int T_all, int ldt, float eps) {
   __shared__ float red[4];
   const int c = blockIdx.x, n = blockIdx.y;
+  int T = T_all;
+  if (lens) {  // valid frames are a prefix: count them with the reference's comparison
+    const float lim = lens[n] * (float)T_all;
+    int lo = 0, hi = T_all;  // first t with !((float)t < lim)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((float)mid < lim) lo = mid + 1; else hi = mid;
+    }
+    T = lo;
+  }
   const float* lr = logits + ((size_t)n * C + c) * ldt;
   const float* xr = x + ((size_t)n * C + c) * ldt;
   float m = -INFINITY;
@@ -57,14 +71,14 @@ __global__ __launch_bounds__(256) void attn_stats_pool_kernel(const float* __res
   s2 = block_sum(s2, red);
   if (threadIdx.x == 0) {
     out[(size_t)n * 2 * C + c] = mean;
-    out[(size_t)n * 2 * C + C + c] = sqrtf(fmaxf(s2 / s, eps));
+    out[(size_t)n * 2 * C + C + c] = sqrtf((s2 / s) < eps ? eps : (s2 / s))  /* clamp(eps), NaN kept */;
   }
 }
 
 }  // namespace ps
 
-extern "C" int ps_attn_stats_pool_f32(const float* logits, const float* x, float* out, int N, int C, int T, int ldt,
-                                      float eps, void* stream) {
+extern "C" int ps_attn_stats_pool_len_f32(const float* logits, const float* x, const float* lengths, float* out, int N,
+                                          int C, int T, int ldt, float eps, void* stream) {
   using namespace ps;
   if (!logits || !x || !out || N <= 0 || C <= 0 || T <= 0 || ldt < T || N > 65535) {
     set_error("ps_attn_stats_pool_f32: bad argument (N=%d C=%d T=%d ldt=%d)", N, C, T, ldt);
@@ -72,8 +86,8 @@ extern "C" int ps_attn_stats_pool_f32(const float* logits, const float* x, float
   }
   {
     LaunchTimer timer("attn_stats_pool", (hipStream_t)stream);
-    hipLaunchKernelGGL(attn_stats_pool_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, logits, x, out, C, T,
-                       ldt, eps);
+    hipLaunchKernelGGL(attn_stats_pool_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, logits, x, lengths, out,
+                       C, T, ldt, eps);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -81,4 +95,9 @@ extern "C" int ps_attn_stats_pool_f32(const float* logits, const float* x, float
     return (int)e;
   }
   return 0;
+}
+
+extern "C" int ps_attn_stats_pool_f32(const float* logits, const float* x, float* out, int N, int C, int T, int ldt,
+                                      float eps, void* stream) {
+  return ps_attn_stats_pool_len_f32(logits, x, nullptr, out, N, C, T, ldt, eps, stream);
 }

@@ -79,5 +79,9 @@ int conv1x1_small_launch(const float* x, const float* wt, float* y, int N, int K
                          hipStream_t stream);
 
 __device__ __forceinline__ float prelu(float v, float slope) { return v >= 0.f ? v : slope * v; }
+// torch.relu / clamp keep a NaN a NaN (fmaxf / fminf would return the other operand): the reference's own look-ahead
+// probe (base_nn.py:740-777) reads NaNs off the output
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ float clamp1_keep_nan(float v) { return v < -1.f ? -1.f : (v > 1.f ? 1.f : v); }
 
 }  // namespace ps

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void frame_kernel(const float* __restrict__ wa
 }
 
 __device__ __forceinline__ float act(float m, int a) {
-  if (a == PS_ACT_RELU) return fmaxf(m, 0.f);
+  if (a == PS_ACT_RELU) return relu_keep_nan(m);
   if (a == PS_ACT_SIGMOID) return 1.f / (1.f + expf(-m));
   return m;
 }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
     wsum += w * w;
   }
   if (wsum > 1e-10f) acc = acc / wsum;
-  if (out_mode == PS_OUT_CLAMP) acc = fminf(fmaxf(acc, -1.f), 1.f);
+  if (out_mode == PS_OUT_CLAMP) acc = clamp1_keep_nan(acc);
   if (out_mode == PS_OUT_SIGMOID) acc = 1.f / (1.f + expf(-acc));
   out[(size_t)n * Lout + g] = acc;
 }

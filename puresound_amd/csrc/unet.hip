@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void activation_kernel(float* __restrict__ x, 
   for (int e = 0; e < 4; ++e) {
     float u = (t + e < T) ? v[e] : 0.f;  // pad columns are cleared: nothing non-finite survives a layer
     switch (kind) {
-      case 1: u = fmaxf(u, 0.f); break;
+      case 1: u = relu_keep_nan(u); break;
       case 2: u = u >= 0.f ? u : s * u; break;
       case 3: u = u * tanhf(u > 20.f ? u : log1pf(expf(u))); break;  // mish = x tanh(softplus(x))
       case 4: u = 1.f / (1.f + expf(-u)); break;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void norm_activation_kernel(NormActArgs a) {
   for (int e = 0; e < 4; ++e) {
     float u = v[e] * sc + sh;
     switch (a.kind) {
-      case 1: u = fmaxf(u, 0.f); break;
+      case 1: u = relu_keep_nan(u); break;
       case 2: u = u >= 0.f ? u : s * u; break;
       case 3: u = u * tanhf(u > 20.f ? u : log1pf(expf(u))); break;
       case 4: u = 1.f / (1.f + expf(-u)); break;

@@ -19,6 +19,34 @@ import torch
 from . import hip
 
 
+def _cached_tensors(model: torch.nn.Module) -> list:
+    """Every tensor the model's modules cache outside their parameters / buffers: scratch workspaces, packed-weight
+    plans, identity tables.  A captured graph holds raw pointers into them, so the graph entry keeps them alive: a
+    module may replace a cache entry later (a larger workspace for a larger batch, a new plan) without pulling memory
+    from under an older graph."""
+    seen, out = set(), []
+
+    def walk(obj, depth):
+        if torch.is_tensor(obj):
+            if obj.is_cuda and id(obj) not in seen:
+                seen.add(id(obj))
+                out.append(obj)
+        elif depth < 6:
+            if isinstance(obj, dict):
+                for v in obj.values():
+                    walk(v, depth + 1)
+            elif isinstance(obj, (list, tuple)):
+                for v in obj:
+                    walk(v, depth + 1)
+
+    for m in model.modules():
+        for k, v in m.__dict__.items():
+            if k not in ("_parameters", "_buffers", "_modules"):
+                walk(v, 0)
+    walk(hip._EYE, 0)
+    return out
+
+
 class GraphedInference:
     def __init__(self, model: torch.nn.Module, max_graphs: int = 8) -> None:
         self.model = model
@@ -69,9 +97,9 @@ class GraphedInference:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_out = self.model.inference(*args)
-            entry = (graph, static_in, static_enroll, static_out)
+            entry = (graph, static_in, static_enroll, static_out, _cached_tensors(self.model))
             self._graphs[key] = entry
-        graph, static_in, static_enroll, static_out = entry
+        graph, static_in, static_enroll, static_out, _pinned = entry
         static_in.copy_(noisy)
         if static_enroll is not None:
             static_enroll.copy_(enroll)

@@ -10,7 +10,8 @@ from typing import Optional, Sequence
 import torch
 
 from . import _abi
-from ._abi import LstmArgs, Prologue, TcnBlock, check, lib, padded_frames, ptr, require_device, stream_ptr
+from ._abi import (LstmArgs, Prologue, TcnBlock, check, lib, padded_frames, ptr, require_device, require_weight,
+                   stream_ptr)
 
 
 def pack_wt(w: torch.Tensor) -> torch.Tensor:
@@ -54,6 +55,7 @@ def free_encode(wav: torch.Tensor, w: torch.Tensor, hop: int, relu: bool = False
     """wav [N,L], w [C,1,win] -> (feats padded [N,C,ldt], T).  `min_frames`: int or callable T -> frames the
     consumer needs the (zero-filled) rows to hold (segment padding of the dual-path maskers)."""
     require_device(wav, "free_encode")
+    require_weight(w, wav, "free_encode")
     wav = wav.contiguous()
     n, length = wav.shape
     c, _, win = w.shape
@@ -72,6 +74,7 @@ def free_decode(feats: torch.Tensor, t: int, w: torch.Tensor, hop: int, mask: Op
                 mask_act: str = "linear", out_mode: str = "none", out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """feats/mask padded [N,C,ldt] -> waveform [N,(T-1)*hop+win] (into `out` if given: contiguous rows)."""
     require_device(feats, "free_decode")
+    require_weight(w, feats, "free_decode")
     n, c, ldt = feats.shape
     win = w.shape[-1]
     if out is None:
@@ -202,13 +205,20 @@ def dwconv(x: torch.Tensor, t: int, w: torch.Tensor, b: Optional[torch.Tensor], 
     return y, stats
 
 
-def attn_stats_pool(logits: torch.Tensor, x: torch.Tensor, t: int, eps: float = 1e-12) -> torch.Tensor:
-    """attention logits / features padded [N,C,ldt] -> [N,2C] = cat(weighted mean, weighted std)."""
+def attn_stats_pool(logits: torch.Tensor, x: torch.Tensor, t: int, eps: float = 1e-12,
+                    lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """attention logits / features padded [N,C,ldt] -> [N,2C] = cat(weighted mean, weighted std); `lengths` [N]:
+    relative lengths, frames t with float(t) >= lengths[n] * T are masked out (lobe/pooling.py:100-107)."""
     require_device(x, "attn_stats_pool")
     n, c, ldt = x.shape
     out = torch.empty(n, 2 * c, dtype=torch.float32, device=x.device)
-    check(lib().ps_attn_stats_pool_f32(ptr(logits), ptr(x), ptr(out), n, c, t, ldt, float(eps),
-                                       stream_ptr(x.device)), "ps_attn_stats_pool_f32")
+    if lengths is not None:
+        require_device(lengths, "attn_stats_pool")
+        if lengths.shape != (n,):
+            raise RuntimeError("attn_stats_pool: lengths must be [N]")
+        lengths = lengths.to(torch.float32).contiguous()
+    check(lib().ps_attn_stats_pool_len_f32(ptr(logits), ptr(x), ptr(lengths), ptr(out), n, c, t, ldt, float(eps),
+                                           stream_ptr(x.device)), "ps_attn_stats_pool_len_f32")
     return out
 
 
@@ -521,6 +531,7 @@ def film_apply(x: torch.Tensor, scale_bias: torch.Tensor, t: int, out: Optional[
 
 def embed_bias(dvec: torch.Tensor, w_embed: torch.Tensor, normalize: bool) -> torch.Tensor:
     require_device(dvec, "embed_bias")
+    require_weight(w_embed, dvec, "embed_bias")
     n, e = dvec.shape
     m = w_embed.shape[0]
     out = torch.empty(n, m, dtype=torch.float32, device=dvec.device)

@@ -18,15 +18,9 @@ FUSE_PROJ_LN_MAX_FRAMES = int(os.environ.get("PS_FUSE_PROJ_LN_MAX_FRAMES", "8192
 
 # Arithmetic of the LSTM input projections (the large GEMMs of the recurrent maskers: [4H*D x C] over every frame):
 # "fp32" = v_mfma_f32 on fp32 operands, "bf16x3" = fp32-accurate 3 x bf16 split, "bf16" = operands rounded to bf16 (what
-# BASELINE.json names for the DPRNN configuration).  Same switch as ConvTasNet.set_gemm_precision, process-wide.
-RECURRENT_GEMM = {"name": os.environ.get("PS_RECURRENT_GEMM", "fp32")}
+# BASELINE.json names for the DPRNN configuration).  A per-module attribute, like TCN.gemm_precision: every PlanCache
+# module carries `gemm_precision` and hands it to the LSTM plans it builds (no process-wide switch).
 _PLANES = {"fp32": 0, "bf16": 1, "bf16x3": 3}
-
-
-def set_recurrent_gemm_precision(name: str) -> None:
-    if name not in _PLANES:
-        raise ValueError(f"gemm precision must be one of {sorted(_PLANES)}")
-    RECURRENT_GEMM["name"] = name
 
 
 def param_signature(module: nn.Module, device) -> tuple:
@@ -41,6 +35,17 @@ class PlanCache:
 
     _plan = None
     _plan_sig = None
+    gemm_precision = "fp32"  # arithmetic of the LSTM input projections built by this module (see _PLANES)
+
+    def set_gemm_precision(self, name: str):
+        """"fp32" | "bf16x3" | "bf16" for the LSTM input projections of this module and of every module below it."""
+        if name not in _PLANES:
+            raise ValueError(f"gemm precision must be one of {sorted(_PLANES)}")
+        for m in self.modules():
+            if isinstance(m, PlanCache):
+                m.gemm_precision = name
+                m._plan = None
+        return self
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -49,7 +54,7 @@ class PlanCache:
         return state
 
     def _plan_get(self, device, builder):
-        sig = param_signature(self, device)
+        sig = param_signature(self, device) + (self.gemm_precision,)
         if self._plan is None or self._plan_sig != sig:
             self._plan = builder(device)
             self._plan_sig = sig
@@ -60,7 +65,7 @@ def _f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().to(dtype=torch.float32, device=device).contiguous()
 
 
-def lstm_plan(lstm: nn.LSTM, device) -> dict:
+def lstm_plan(lstm: nn.LSTM, device, gemm: str = "fp32") -> dict:
     """nn.LSTM(num_layers=1, batch_first=True): input projection rows stacked over directions (for one
     ps_conv1x1_f32), summed biases, W_hh transposed per direction."""
     if lstm.num_layers != 1 or not lstm.batch_first or lstm.proj_size != 0 or not lstm.bias:
@@ -74,7 +79,8 @@ def lstm_plan(lstm: nn.LSTM, device) -> dict:
         whh.append(_f32(getattr(lstm, "weight_hh_l0" + suf), device).t().contiguous())
     return dict(wih=hip.pack_wt(torch.cat(wih, 0)), wih_rows=torch.cat(wih, 0).contiguous(), wih_planes={},
                 bias=torch.cat(bias).contiguous(),
-                whh_t=torch.stack(whh).contiguous(), H=hid, D=dirs, rows=dirs * 4 * hid, I=lstm.input_size)
+                whh_t=torch.stack(whh).contiguous(), H=hid, D=dirs, rows=dirs * 4 * hid, I=lstm.input_size,
+                planes=_PLANES[gemm])
 
 
 def linear_plan(lin: nn.Module, device) -> dict:
@@ -100,7 +106,7 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
     """x + LN(proj(LSTM(x))) on padded [N,C,ldt] (dprnn.py:154-172, skim.py:215-227) -> (x', final states)."""
     n, _, ldt = x.shape
     dev = x.device
-    planes = _PLANES[RECURRENT_GEMM["name"]]
+    planes = rnn["planes"]
     gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev)
     if planes and rnn["I"] >= 64:
         if planes not in rnn["wih_planes"]:

@@ -222,14 +222,37 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         cur = torch.cuda.current_stream(dev)
         pool = _side_streams(dev, lanes)
         bounds = [n * i // lanes for i in range(lanes + 1)]
+        # Plans (packed weights, prologue tables) are built by torch ops on whatever stream is current: build or
+        # re-validate them HERE, on the caller's stream, which every lane waits for -- built lazily inside lane 0 they
+        # would be read by lane 1 with no ordering.  What is still created lazily inside a lane (per-precision weight
+        # planes, identity tables) is created once: the first forked call runs its lanes one after the other.
+        self._prepare_plans(dev)
+        first = not getattr(self, "_lanes_warm", False)
+        object.__setattr__(self, "_lanes_warm", True)
         for i, s in enumerate(pool):
             s.wait_stream(cur)
+            if first and i > 0:
+                s.wait_stream(pool[i - 1])
             with torch.cuda.stream(s):
                 run(noisy[bounds[i]:bounds[i + 1]], i, out[bounds[i]:bounds[i + 1]],
                     None if enroll is None else enroll[bounds[i]:bounds[i + 1]])
         for s in pool:
             cur.wait_stream(s)
         return out
+
+    def _prepare_plans(self, dev: torch.device) -> None:
+        """Build / re-validate every kernel-side plan of the masker and the speaker branch on the current stream."""
+        from ._plans import PlanCache
+        for m in self.modules():
+            if isinstance(m, ConvTasNet):
+                if m.tcn_layer.lower() == "normal":
+                    m.block_array(dev)
+            elif isinstance(m, (TCN, GatedTCN)):
+                m.plan(dev)
+            elif isinstance(m, AttentiveStatisticsPooling):
+                m._get_plan(dev)
+            elif isinstance(m, PlanCache) and hasattr(m, "_build"):
+                m._plan_get(dev, m._build)
 
     def _align_waveform(self, enh_wav: torch.Tensor, ref_wav: torch.Tensor):
         """base_nn.py:398-412: a shorter reference is left-padded with zeros, a longer one cuts the estimate."""
@@ -299,15 +322,50 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         hip.require_device(enroll, "SoTaskWrapModule.inference_tse_embedding")
         return self._speaker_embedding(enroll.contiguous()).unsqueeze(2)
 
+    @torch.no_grad()
+    def probe_lookahead_receptive_field(self, device=None):
+        """The reference's NaN-propagation probe (base_nn.py:746-772) on the HIP path: a 10 s input whose second
+        (first) half is +inf; the first (last) NaN of the output gives the look-ahead (receptive field) in samples.
+        Returns (lookahead, receptive_field), each an int or the string "infinite" exactly as the reference prints."""
+        import numpy as np
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        hip.require_device(torch.empty(0, device=dev), "probe_lookahead_receptive_field")
+        g = torch.Generator().manual_seed(0)
+        x_spk = torch.rand(1, 10 * 16000, generator=g).to(dev)
+
+        def run(x):
+            try:
+                return self.inference(x.to(dev), x_spk).cpu().numpy()
+            except (RuntimeError, NotImplementedError, TypeError):
+                return self.inference(x.to(dev)).cpu().numpy()
+
+        x = torch.rand(1, 10 * 16000, generator=g)
+        x[..., 5 * 16000:] = float("inf")
+        first = int(np.where(np.isnan(run(x)))[-1][0])
+        lookahead = "infinite" if first == 0 else 80000 - first
+        x = torch.rand(1, 10 * 16000, generator=g)
+        x[..., :-5 * 16000] = float("inf")
+        last = int(np.where(np.isnan(run(x)))[-1][-1])
+        receptive = "infinite" if last - (80000 - 1) == 80000 else last - (80000 - 1)
+        return lookahead, receptive
+
     def _verbose(self):
-        """The reference probes look-ahead / receptive field with two 10-s CPU inferences and leaves the
-        module in train() mode (base_nn.py:740-777).  There is no CPU path here, so only the parameter
-        count is printed; the train() quirk is kept."""
+        """The reference probes look-ahead / receptive field with two 10-s inferences and leaves the module in train()
+        mode (base_nn.py:740-777).  The probe needs the parameters on a ROCm device (there is no CPU path): at
+        construction time they are on the CPU, so the numbers are printed only for a model built under a device
+        context; `probe_lookahead_receptive_field()` runs it later.  The train() quirk is kept."""
         print("---------------Verbose logging---------------")
         self.eval()
         print(f"Current training mode is: {self.training}")
         print(f"Total params: {self.overall_parameters}")
-        print("Lookahead / receptive-field probe skipped: needs a ROCm device (no CPU fallback)")
+        p = next(self.parameters(), None)
+        if p is not None and p.is_cuda:
+            lookahead, receptive = self.probe_lookahead_receptive_field()
+            print(f"Lookahead(samples): {lookahead}")
+            print(f"Receptive Fields(samples): {receptive}")
+        else:
+            print("Lookahead / receptive-field probe skipped: parameters are not on a ROCm device yet (no CPU "
+                  "fallback); call probe_lookahead_receptive_field() after .to(device)")
         self.train()
         print(f"Current training mode is: {self.training}")
         print("---------------Verbose logging---------------")

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
+from ..ops import op_module, same_shape
 from ._plans import PlanCache, layernorm_plan, linear_plan, lstm_path, lstm_plan
 from .lobe.attention import MhaSelfAttenLayer
 from .lobe.rnn import SingleRNN
@@ -31,7 +32,7 @@ class DPARNblock2D(PlanCache, nn.Module):
         if self.training and self.inter_rnn.drop.p > 0:
             raise RuntimeError("DPARNblock2D: dropout is active; the HIP path is inference only -- call .eval()")
         return dict(fc=linear_plan(self.intra_fc, device), fc_norm=layernorm_plan(self.intra_norm, device),
-                    inter=(lstm_plan(self.inter_rnn.rnn, device), linear_plan(self.inter_rnn.proj, device),
+                    inter=(lstm_plan(self.inter_rnn.rnn, device, self.gemm_precision), linear_plan(self.inter_rnn.proj, device),
                            layernorm_plan(self.inter_norm, device)))
 
     def forward_padded(self, x: torch.Tensor, t: int) -> torch.Tensor:
@@ -56,6 +57,7 @@ class DPARNblock2D(PlanCache, nn.Module):
         return hip.unpad_rows(y.reshape(n, ch * f, -1), t).view(n, ch, f, t)
 
 
+@op_module("dparn_fwd", same_shape)
 class DPARN(Unet):
     """dparn.py:110-247; constructor order as the reference (dparn.py:111-131)."""
 

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
+from ..ops import op_module, same_shape
 from ._plans import PlanCache, layernorm_plan, linear_plan, lstm_path, lstm_plan
 from .lobe.rnn import SingleRNN
 from .unet import Unet
@@ -28,9 +29,9 @@ class DPRNNblock2D(PlanCache, nn.Module):
     def _build(self, device):
         if self.training and (self.intra_rnn.drop.p > 0 or self.inter_rnn.drop.p > 0):
             raise RuntimeError("DPRNNblock2D: dropout is active; the HIP path is inference only -- call .eval()")
-        return dict(intra=(lstm_plan(self.intra_rnn.rnn, device), linear_plan(self.intra_rnn.proj, device),
+        return dict(intra=(lstm_plan(self.intra_rnn.rnn, device, self.gemm_precision), linear_plan(self.intra_rnn.proj, device),
                            layernorm_plan(self.intra_norm, device)),
-                    inter=(lstm_plan(self.inter_rnn.rnn, device), linear_plan(self.inter_rnn.proj, device),
+                    inter=(lstm_plan(self.inter_rnn.rnn, device, self.gemm_precision), linear_plan(self.inter_rnn.proj, device),
                            layernorm_plan(self.inter_norm, device)))
 
     def forward_padded(self, x: torch.Tensor, t: int) -> torch.Tensor:
@@ -52,6 +53,7 @@ class DPRNNblock2D(PlanCache, nn.Module):
         return hip.unpad_rows(y.reshape(n, ch * f, -1), t).view(n, ch, f, t)
 
 
+@op_module("dpcrn_fwd", same_shape)
 class DPCRN(Unet):
     """dpcrn.py:84-213; constructor order as the reference (dpcrn.py:85-104)."""
 

@@ -12,10 +12,16 @@ import torch
 import torch.nn as nn
 
 from .. import hip
+from ..ops import op_module
 from ._plans import PlanCache, _f32, layernorm_plan, linear_plan, lstm_path, lstm_plan
 from .lobe.trivial import FiLM
 
 
+def _out_size(ctor, x, aux, params):
+    return (x[0], ctor["output_size"], x[2])
+
+
+@op_module("dprnn_fwd", _out_size)
 class DPRNN(PlanCache, nn.Module):
     """Deep dual-path RNN (dprnn.py:10-109); constructor order as the reference (dprnn.py:27-40)."""
 
@@ -62,9 +68,9 @@ class DPRNN(PlanCache, nn.Module):
         blocks = []
         for i in range(self.n_blocks):
             blocks.append(dict(
-                intra=(lstm_plan(self.intra_rnn[i], device), linear_plan(self.intra_proj[i], device),
+                intra=(lstm_plan(self.intra_rnn[i], device, self.gemm_precision), linear_plan(self.intra_proj[i], device),
                        layernorm_plan(self.intra_norm[i], device)),
-                inter=(lstm_plan(self.inter_rnn[i], device), linear_plan(self.inter_proj[i], device),
+                inter=(lstm_plan(self.inter_rnn[i], device, self.gemm_precision), linear_plan(self.inter_proj[i], device),
                        layernorm_plan(self.inter_norm[i], device))))
         if self.output_fc[0].weight.numel() != 1:
             raise NotImplementedError("PReLU with per-channel slopes is not on the HIP path")

@@ -12,6 +12,24 @@ import torch
 import torch.nn as nn
 
 from ... import hip
+from ...ops import op_module
+
+
+class _EncoderConv(nn.Conv1d):
+    """`FreeEncDec.encoder`: the reference's nn.Conv1d (same state_dict key `weight`), forward on the HIP operator."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:  # [N,1,L] -> [N,C,T]
+        with torch.no_grad():
+            return torch.ops.puresound_amd.free_encode(x[:, 0, :], self.weight, self.stride[0], False)
+
+
+class _DecoderConvT(nn.ConvTranspose1d):
+    """`FreeEncDec.decoder`: the reference's nn.ConvTranspose1d; the recipe's export action traces this submodule on
+    its own (egs/tse/main.py:436-439)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:  # [N,C,T] -> [N,1,L]
+        with torch.no_grad():
+            return torch.ops.puresound_amd.free_decode(x, self.weight, self.stride[0]).unsqueeze(1)
 
 
 class FreeEncDec(nn.Module):
@@ -24,8 +42,8 @@ class FreeEncDec(nn.Module):
         self.hop_length = hop_length
         self.output_active = output_active
         # parameter holders with the reference's keys encoder.weight / decoder.weight ([C,1,win])
-        self.encoder = nn.Conv1d(1, laten_length, kernel_size=win_length, stride=hop_length, bias=False)
-        self.decoder = nn.ConvTranspose1d(laten_length, 1, kernel_size=win_length, stride=hop_length, bias=False)
+        self.encoder = _EncoderConv(1, laten_length, kernel_size=win_length, stride=hop_length, bias=False)
+        self.decoder = _DecoderConvT(laten_length, 1, kernel_size=win_length, stride=hop_length, bias=False)
 
     # -- padded-layout entry points used by the fused wrapper ---------------------------------
     def encode_padded(self, x: torch.Tensor, min_frames=None):
@@ -41,13 +59,13 @@ class FreeEncDec(nn.Module):
     # -- reference API -------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """[N,L] -> [N,C,T] (encoder.py:71-83)."""
-        feats, t = self.encode_padded(x)
-        return hip.unpad_rows(feats, t)
+        with torch.no_grad():
+            return torch.ops.puresound_amd.free_encode(x, self.encoder.weight, self.hop_length, self.output_active)
 
     def inverse(self, x: torch.Tensor) -> torch.Tensor:
         """[N,C,T] -> [N,L] (encoder.py:85-94)."""
-        hip.require_device(x, "FreeEncDec.inverse")
-        return self.decode_padded(hip.pad_rows(x), x.shape[-1])
+        with torch.no_grad():
+            return torch.ops.puresound_amd.free_decode(x, self.decoder.weight, self.hop_length)
 
 
 def create_fourier_kernels(n_fft: int):
@@ -58,6 +76,25 @@ def create_fourier_kernels(n_fft: int):
     return torch.sin(ang).to(torch.float32).unsqueeze(1), torch.cos(ang).to(torch.float32).unsqueeze(1)
 
 
+def _stft_shape(ctor, x, aux, params):
+    n_fft = ctor["n_fft"]
+    hop = ctor["hop_length"] if ctor.get("hop_length") else (ctor.get("win_length") or n_fft) // 4
+    bins = ctor["freq_bins"] if ctor.get("freq_bins") else n_fft // 2 + 1
+    return (x[0], bins, (x[-1] - n_fft) // hop + 1, 2)
+
+
+def _istft_shape(ctor, x, aux, params):
+    n_fft = ctor["n_fft"]
+    hop = ctor["hop_length"] if ctor.get("hop_length") else (ctor.get("win_length") or n_fft) // 4
+    return (x[0], (x[2] - 1) * hop + n_fft)
+
+
+def _stft_rebuild(a):
+    return dict(a, window_mask=torch.hann_window(a.get("win_length") or a["n_fft"]))
+
+
+@op_module("istft_decode", _istft_shape, method="_istft", rebuild=_stft_rebuild)
+@op_module("stft_encode", _stft_shape, rebuild=_stft_rebuild)
 class ConvSTFT(nn.Module):
     """Conv-STFT with trainable analysis kernels (encoder.py:275-456).  Parameter / buffer holder."""
 
@@ -97,6 +134,11 @@ class ConvSTFT(nn.Module):
             self.register_buffer("wsin", wsin)
             self.register_buffer("wcos", wcos)
         self.register_buffer("window_mask", window_mask.unsqueeze(0).unsqueeze(-1))
+
+    def _op_ctor_args(self):
+        """JSON-able constructor arguments (the window itself travels as the buffer `window_mask`)."""
+        return dict(n_fft=self.n_fft, win_length=self.win_length, freq_bins=self.freq_bins, hop_length=self.stride,
+                    iSTFT=self.iSTFT, trainable=self.trainable, output_format=self.output_format)
 
     # -- kernel-side plans (rebuilt when a table changes) -----------------------------------------------
     def _sig(self):
@@ -175,6 +217,9 @@ class ConvSTFT(nn.Module):
         assert X.dim() == 4, "Inverse iSTFT only works for complex number (batch, freq_bins, timesteps, 2)."
         if self.output_format != "Complex":
             raise NotImplementedError("Inverse only support complex input")
+        return self._istft(X)
+
+    def _istft(self, X: torch.Tensor) -> torch.Tensor:
         hip.require_device(X, "ConvSTFT.inverse")
         spec = torch.cat((X[..., 0], X[..., 1]), dim=1).contiguous()
         return self.decode_padded(hip.pad_rows(spec), X.shape[2], False)

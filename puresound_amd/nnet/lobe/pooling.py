@@ -8,9 +8,15 @@ import torch
 import torch.nn as nn
 
 from ... import hip
+from ...ops import op_module
 from ..._abi import PS_NORM_AFFINE
 
 
+def _pool_shape(ctor, x, aux, params):
+    return (x[0], 2 * x[1], 1)
+
+
+@op_module("attn_stats_pool_fwd", _pool_shape, method="_pool")
 class AttentiveStatisticsPooling(nn.Module):
     def __init__(self, channels, attention_channels=128):
         super().__init__()
@@ -45,8 +51,8 @@ class AttentiveStatisticsPooling(nn.Module):
                               b2=self.conv.bias.detach().to(**f32).contiguous(), scale=scale, shift=shift)
         return self._plan
 
-    def forward_padded(self, x_pad: torch.Tensor, t: int) -> torch.Tensor:
-        """padded [N,C,ldt] -> [N,2C] (mean ; std)."""
+    def forward_padded(self, x_pad: torch.Tensor, t: int, lengths=None) -> torch.Tensor:
+        """padded [N,C,ldt] (+ relative lengths [N]) -> [N,2C] (mean ; std)."""
         p = self._get_plan(x_pad.device)
         n, _, ldt = x_pad.shape
         h, _ = hip.conv1x1(x_pad, t, p["w1"], self.attention_channels, None, p["b1"],
@@ -55,11 +61,15 @@ class AttentiveStatisticsPooling(nn.Module):
                                 pre_relu=True, post_tanh=True)
         logits, _ = hip.conv1x1(h, t, p["w2"], self.channels, pro, p["b2"],
                                 out=torch.empty(n, self.channels, ldt, device=x_pad.device))
-        return hip.attn_stats_pool(logits, x_pad, t, self.eps)
+        return hip.attn_stats_pool(logits, x_pad, t, self.eps, lengths)
+
+    def _pool(self, x: torch.Tensor, lengths=None):
+        hip.require_device(x, "AttentiveStatisticsPooling.forward")
+        return self.forward_padded(hip.pad_rows(x), x.shape[-1], lengths).unsqueeze(2)
 
     def forward(self, x: torch.Tensor, lengths=None, return_weight: bool = False):
-        """x [N,C,L] -> [N,2C,1] (pooling.py:87-126, lengths=None)."""
-        hip.require_device(x, "AttentiveStatisticsPooling.forward")
-        if lengths is not None or return_weight:
-            raise NotImplementedError("AttentiveStatisticsPooling on HIP: lengths / return_weight are not supported")
-        return self.forward_padded(hip.pad_rows(x), x.shape[-1]).unsqueeze(2)
+        """x [N,C,L] (+ relative lengths [N]) -> [N,2C,1] (pooling.py:87-126)."""
+        if return_weight:
+            raise NotImplementedError("AttentiveStatisticsPooling on HIP: return_weight (the attention map itself) is "
+                                      "not built")
+        return self._pool(x, lengths)

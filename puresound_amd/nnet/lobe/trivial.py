@@ -10,10 +10,16 @@ import torch
 import torch.nn as nn
 
 from ... import hip
+from ...ops import op_module
 from .._plans import PlanCache, _f32, layernorm_plan
 from .norm import ChanLN
 
 
+def _magnitude_shape(ctor, x, aux, params):
+    return (x[0], x[1] // 2 - int(bool(ctor.get("drop_first", True))), x[2])
+
+
+@op_module("magnitude_fwd", _magnitude_shape)
 class Magnitude(nn.Module):
     """STFT [re; im] -> magnitude (lobe/trivial.py:21-59).  3-D input [N, 2H, T] (channel halves) only: that is what
     the wrapper hands the speaker net."""

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
+from ..ops import op_module
 from ._plans import PlanCache, _f32, layernorm_plan, linear_plan, lstm_path, lstm_plan
 from .lobe.trivial import FiLM, Gate
 
@@ -40,9 +41,9 @@ class MemLSTM(PlanCache, nn.Module):
     def _build(self, device):
         if self.training and (self.h_dropout.p > 0 or self.c_dropout.p > 0):
             raise RuntimeError("MemLSTM: dropout is active; the HIP path is inference only -- call .eval()")
-        return dict(h=(lstm_plan(self.h_net, device), linear_plan(self.h_proj, device),
+        return dict(h=(lstm_plan(self.h_net, device, self.gemm_precision), linear_plan(self.h_proj, device),
                        layernorm_plan(self.h_norm, device)),
-                    c=(lstm_plan(self.c_net, device), linear_plan(self.c_proj, device),
+                    c=(lstm_plan(self.c_net, device, self.gemm_precision), linear_plan(self.c_proj, device),
                        layernorm_plan(self.c_norm, device)))
 
     def forward_state(self, h: torch.Tensor, c: torch.Tensor, s: int, h_states=None, c_states=None,
@@ -104,7 +105,7 @@ class SegLSTM(PlanCache, nn.Module):
     def _build(self, device):
         if self.training and self.drop.p > 0:
             raise RuntimeError("SegLSTM: dropout is active; the HIP path is inference only -- call .eval()")
-        return (lstm_plan(self.lstm, device), linear_plan(self.proj, device), layernorm_plan(self.norm, device))
+        return (lstm_plan(self.lstm, device, self.gemm_precision), linear_plan(self.proj, device), layernorm_plan(self.norm, device))
 
     def step_plan(self, device):
         """Streaming step: [W_ih | W_hh] as ONE weight whose K axis is [x; h], so the gates of a frame step are a
@@ -141,6 +142,11 @@ class SegLSTM(PlanCache, nn.Module):
         return hip.unpad_rows(y, k).transpose(1, 2).contiguous(), back(hl), back(cl)
 
 
+def _out_size(ctor, x, aux, params):
+    return (x[0], ctor["output_size"], x[2])
+
+
+@op_module("skim_fwd", _out_size)
 class SkiM(PlanCache, nn.Module):
     """Skipping memory LSTM (skim.py:251-469); constructor order as the reference (skim.py:280-294)."""
 

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
+from ..ops import op_module, same_shape
 from ._plans import PlanCache, _f32
 from .conv_tasnet import TCN, GatedTCN, TcnBlock
 from .lobe.activation import activation_kind, get_activation
@@ -26,6 +27,7 @@ import os
 IMPLICIT_CONV = os.environ.get("PS_IMPLICIT_CONV", "1") == "1"
 
 
+@op_module("unet_fwd", same_shape)
 class Unet(PlanCache, nn.Module):
     """unet.py:13-296; constructor order as the reference (unet.py:35-53)."""
 
@@ -286,6 +288,7 @@ class Unet(PlanCache, nn.Module):
                 "multi_output": self.multi_output}
 
 
+@op_module("unet_tcn_fwd", same_shape)
 class UnetTcn(Unet):
     """U-Net with a (gated) TCN bottleneck (unet.py:298-557)."""
 

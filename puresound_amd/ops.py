@@ -1,0 +1,190 @@
+"""PyTorch custom-op boundary: `torch.ops.puresound_amd.*`.
+
+The reference has no FFI; its seam is the `nn.Module` contract, and one caller on the path needs more than eager
+calls: the recipe's export action traces `Sequential(encoder, *speaker_net)`, `encoder`, `encoder.decoder` and
+`masker` with `torch.jit.trace` (egs/tse/main.py:406-443).  A ctypes launch on `data_ptr()` is invisible to a tracer,
+so every reference-API `forward` / `inverse` of the mirror modules goes through an operator registered here with
+
+  * a HIP implementation (dispatch key CUDA) that calls the C ABI of libpuresound_hip.so (through `hip.py` and the
+    modules' padded-layout code),
+  * a Meta implementation that only computes the output shape (FakeTensor / meta-device tracing, shape checks on a
+    box without a GPU),
+  * a CPU registration that raises: there is no CPU fallback.
+
+Two kinds of operators:
+
+  * functional ones whose tensors are all arguments: `free_encode(wav, weight, hop, relu)`,
+    `free_decode(feats, weight, hop)`;
+  * module-backed ones, `<kind>_fwd(x, aux, params, cfg)`: `params` are the module's parameters and buffers (so a
+    traced graph holds them as inputs, not as baked constants), `cfg` the JSON of its constructor arguments.  The
+    implementation finds the live module that made the call through a weak registry keyed by (kind, cfg, data
+    pointers); when there is none -- a traced module loaded in a fresh process -- it rebuilds the module from `cfg`
+    and adopts `params` without copying.
+
+The operators are forward only: the mirror modules call them under `torch.no_grad()` (no autograd formula is registered;
+an output never requires grad).
+
+The fused wrapper path (`SoTaskWrapModule.inference`) does not go through these operators: it keeps the padded device
+layout from the encoder kernel to the decoder kernel.  The operators are the module-level API.
+"""
+from __future__ import annotations
+
+import inspect
+import json
+import weakref
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+NAMESPACE = "puresound_amd"
+_LIB = torch.library.Library(NAMESPACE, "DEF")
+_KINDS: Dict[str, dict] = {}                       # kind -> {cls, method, shape}
+_LIVE: "weakref.WeakValueDictionary" = weakref.WeakValueDictionary()   # (kind, cfg, ptrs) -> module that called
+_REBUILT: Dict[tuple, torch.nn.Module] = {}        # modules rebuilt from (cfg, params) of a loaded trace
+OP_NAMES: List[str] = []
+
+
+def _no_cpu(name: str) -> Callable:
+    def impl(*args, **kwargs):
+        raise RuntimeError(f"{NAMESPACE}::{name}: inputs must be HIP (cuda) tensors -- there is no CPU fallback")
+    return impl
+
+
+def _define(name: str, schema: str, hip_impl: Callable, meta_impl: Callable) -> None:
+    _LIB.define(f"{name}{schema}")
+    _LIB.impl(name, hip_impl, "CUDA")
+    _LIB.impl(name, meta_impl, "Meta")
+    _LIB.impl(name, _no_cpu(name), "CPU")
+    OP_NAMES.append(name)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# functional operators: learned filterbank (lobe/encoder.py:71-94 of the reference)
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_encode_hip(wav: torch.Tensor, weight: torch.Tensor, hop: int, relu: bool) -> torch.Tensor:
+    from . import hip
+    feats, t = hip.free_encode(wav, weight.detach(), hop, relu)
+    return hip.unpad_rows(feats, t)
+
+
+def _free_encode_meta(wav, weight, hop, relu):
+    n, length = wav.shape
+    c, _, win = weight.shape
+    if length < win:
+        raise RuntimeError(f"free_encode: input length {length} is shorter than the window {win}")
+    return wav.new_empty((n, c, (length - win) // hop + 1))
+
+
+def _free_decode_hip(feats: torch.Tensor, weight: torch.Tensor, hop: int) -> torch.Tensor:
+    from . import hip
+    return hip.free_decode(hip.pad_rows(feats), feats.shape[-1], weight.detach(), hop)
+
+
+def _free_decode_meta(feats, weight, hop):
+    n, _, t = feats.shape
+    return feats.new_empty((n, (t - 1) * hop + weight.shape[-1]))
+
+
+_define("free_encode", "(Tensor wav, Tensor weight, int hop, bool relu) -> Tensor", _free_encode_hip, _free_encode_meta)
+_define("free_decode", "(Tensor feats, Tensor weight, int hop) -> Tensor", _free_decode_hip, _free_decode_meta)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# module-backed operators
+# ---------------------------------------------------------------------------------------------------------------------
+def module_tensors(m: torch.nn.Module) -> List[torch.Tensor]:
+    """Parameters then buffers, in registration order (the order `adopt_tensors` assigns them back in)."""
+    return [p for _, p in m.named_parameters()] + [b for _, b in m.named_buffers()]
+
+
+def adopt_tensors(m: torch.nn.Module, tensors: Sequence[torch.Tensor]) -> None:
+    names = [k for k, _ in m.named_parameters()] + [k for k, _ in m.named_buffers()]
+    if len(names) != len(tensors):
+        raise RuntimeError(f"{type(m).__name__}: {len(tensors)} tensors for {len(names)} parameters / buffers")
+    m.load_state_dict(dict(zip(names, tensors)), strict=False, assign=True)
+
+
+def _resolve(kind: str, cfg: str, params: Sequence[torch.Tensor]) -> torch.nn.Module:
+    key = (kind, cfg, tuple(p.data_ptr() for p in params))
+    m = _LIVE.get(key)
+    if m is None:
+        m = _REBUILT.get(key)
+    if m is None:
+        info = _KINDS[kind]
+        args = json.loads(cfg)
+        if args.get("ctor") is None:
+            raise RuntimeError(f"{NAMESPACE}::{kind}: the module that recorded this call is gone and its constructor "
+                               f"arguments are not serialisable")
+        m = info["cls"](**info["rebuild"](args["ctor"])).eval()
+        adopt_tensors(m, params)
+        if len(_REBUILT) > 64:
+            _REBUILT.clear()
+        _REBUILT[key] = m
+    return m
+
+
+def op_module(kind: str, shape: Callable, method: str = "forward", rebuild: Optional[Callable] = None):
+    """Class decorator: the reference-API `method(x, aux=None)` of the class goes through
+    torch.ops.puresound_amd.<kind>; the original body stays reachable as `_hip_<method>`.
+
+    shape(ctor_args, x_shape, aux_shape) -> output shape (the Meta implementation)."""
+
+    def deco(cls):
+        body = getattr(cls, method)
+        n_in = len([p for p in inspect.signature(body).parameters.values()
+                    if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]) - 1
+        hip_name = f"_hip_{method}"
+        setattr(cls, hip_name, body)
+        if "_ctor_sig" not in cls.__dict__:
+            init = cls.__init__
+            sig = inspect.signature(init)
+
+            def __init__(self, *a, **k):
+                init(self, *a, **k)
+                try:
+                    ba = sig.bind(self, *a, **k)
+                    ba.apply_defaults()
+                    args = {n: v for n, v in list(ba.arguments.items())[1:]}
+                    json.dumps(args)
+                except (TypeError, ValueError):
+                    args = None
+                if hasattr(self, "_op_ctor_args"):
+                    args = self._op_ctor_args()
+                object.__setattr__(self, "_ctor_args", args)
+
+            __init__.__wrapped__ = init
+            cls.__init__ = __init__
+            cls._ctor_sig = sig
+
+        def hip_impl(x, aux, params, cfg):
+            m = _resolve(kind, cfg, params)
+            fn = getattr(m, hip_name)
+            return fn(x) if n_in == 1 else fn(x, aux)
+
+        def meta_impl(x, aux, params, cfg):
+            out = shape(json.loads(cfg).get("ctor") or {}, tuple(x.shape), None if aux is None else tuple(aux.shape),
+                        [tuple(p.shape) for p in params])
+            return x.new_empty(out)
+
+        _define(kind, "(Tensor x, Tensor? aux, Tensor[] params, str cfg) -> Tensor", hip_impl, meta_impl)
+        _KINDS[kind] = dict(cls=cls, method=method, shape=shape, rebuild=rebuild or (lambda a: a))
+        op = getattr(getattr(torch.ops, NAMESPACE), kind)
+
+        def routed(self, x, aux=None):
+            params = module_tensors(self)
+            cfg = json.dumps({"ctor": getattr(self, "_ctor_args", None)}, sort_keys=True)
+            if x.device.type == "cuda":
+                _LIVE[(kind, cfg, tuple(p.data_ptr() for p in params))] = self
+            with torch.no_grad():  # forward only: there is no backward kernel, outputs carry no graph
+                return op(x, aux, params, cfg)
+
+        routed.__doc__ = body.__doc__
+        routed.__name__ = method
+        setattr(cls, method, routed)
+        return cls
+
+    return deco
+
+
+def same_shape(ctor, x, aux, params):
+    return x

@@ -37,6 +37,12 @@ CASES = {
                        masker=masker_args(512, 192, True, [1, 0, 0, 0, 0, 0, 0, 0], **CTN_FULL),
                        speaker_net=dict(n_tcn=5, C=512, H=256, att=128, E=192),
                        wrap=dict(mask_constraint="ReLU"), B=2, L=4000, L_enroll=4000, seed=1234),
+    # td_tse_conv_tasnet_v0_causal verbatim (egs/tse/model.py:142-183): causal bN1d masker, the non-causal gLN speaker net
+    "cfg3_causal_short": dict(kind="wrap", enc=dict(kind="free", win=32, hop=16, C=512),
+                              masker=masker_args(512, 192, True, [1, 0, 0, 0, 0, 0, 0, 0],
+                                                 **dict(CTN_FULL, tcn_norm="bN1d", dconv_norm="bN1d", causal=True)),
+                              speaker_net=dict(n_tcn=5, C=512, H=256, att=128, E=192),
+                              wrap=dict(mask_constraint="ReLU"), B=2, L=4000, L_enroll=4000, seed=1234),
     # BASELINE config 4: DPRNN hyper-parameters of veve_dprnn_v0_causal (egs/tse/model.py:614-630) as a plain
     # separator, and the preset verbatim (embedding-free TSE: the enrolment pass seeds the inter-LSTM states)
     "cfg4_short": dict(kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
@@ -87,6 +93,25 @@ CASES = {
                             dconv_norm="gGN", causal=False)),
         speaker_net=dict(n_tcn=5, C=256, H=128, att=128, E=192, block="gated", magnitude=True),
         wrap=dict(mask_constraint="linear", drop_first_bin=True), B=2, L=4000, L_enroll=3000, seed=1234),
+    "tse_unet_tcn_v1_short": dict(   # tse_unet_tcn_v1 (egs/tse/model.py:308-369): v0 with FiLM conditioning in the gated TCN
+        kind="wrap", enc=dict(kind="stft", n_fft=512, hop=128, drop_first_bin=True),
+        masker=dict(cls="UnetTcn", args=(), oracle="unet_tcn",
+                    kw=dict(embed_dim=192, embed_norm=True, input_type="RI", input_dim=512, activation_type="PReLU",
+                            norm_type="gLN", channels=(1, 32, 64, 128, 128, 128, 128), transpose_t_size=2,
+                            transpose_delay=True, skip_conv=False, kernel_t=(2,) * 6, kernel_f=(5,) * 6,
+                            stride_t=(1,) * 6, stride_f=(2,) * 6, dilation_t=(1,) * 6, dilation_f=(1,) * 6,
+                            delay=(0,) * 6, tcn_layer="gated", tcn_kernel=3, tcn_dim=256, tcn_dilated_basic=2,
+                            per_tcn_stack=5, repeat_tcn=3, tcn_with_embed=[1, 0, 0, 0, 0], tcn_norm="gLN",
+                            dconv_norm="gGN", causal=False, tcn_use_film=True)),
+        speaker_net=dict(n_tcn=5, C=256, H=128, att=128, E=192, block="gated", magnitude=True),
+        wrap=dict(mask_constraint="linear", drop_first_bin=True), B=2, L=4000, L_enroll=3000, seed=1234),
+    "tse_skim_v0_short": dict(   # tse_skim_v0 (egs/tse/model.py:371-416): the non-causal (bidirectional) SkiM preset
+        kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
+        masker=dict(cls="SkiM", args=(128, 256, 128),
+                    kw=dict(n_blocks=4, seg_size=150, seg_overlap=False, causal=False, embed_dim=192, embed_norm=True,
+                            block_with_embed=[1, 1, 1, 1], embed_fusion="FiLM")),
+        speaker_net=dict(n_tcn=5, C=128, H=256, att=128, E=192),
+        wrap=dict(mask_constraint="ReLU"), B=2, L=4000, L_enroll=3000, seed=1234),
     # tse_skim_v2_causal (egs/tse/model.py:509-558) WITHOUT its SpecAugment layer, which draws random masks even in
     # eval mode (lobe/trivial.py:326-335) and so has no reproducible output: FbankEnc enrolment encoder + TCN speaker net
     "tse_skim_fbank_short": dict(

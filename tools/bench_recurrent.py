@@ -23,6 +23,7 @@ def cfg4(args):
     model = cases.build(PA.NS, "cfg4_short").eval()
     model.load_state_dict(det_state_dict(model))
     model.to(dev)
+    model.masker.set_gemm_precision(args.gemm)
     g = torch.Generator().manual_seed(1234)
     noisy = ((torch.rand(args.batch, 64000, generator=g) * 2 - 1) * 0.5).to(dev)
     for _ in range(args.warmup):
@@ -59,6 +60,7 @@ def dpcrn(args):
     model = cases.build(PA.NS, "ns_dpcrn_short").eval()
     model.load_state_dict(det_state_dict(model))
     model.to(dev)
+    model.masker.set_gemm_precision(args.gemm)
     g = torch.Generator().manual_seed(1234)
     noisy = ((torch.rand(args.batch, 64000, generator=g) * 2 - 1) * 0.5).to(dev)
     for _ in range(args.warmup):
@@ -133,7 +135,6 @@ if __name__ == "__main__":
     if a.flags:
         _abi.lib().ps_debug_flags(a.flags)
     from puresound_amd.nnet import _plans
-    _plans.set_recurrent_gemm_precision(a.gemm)
     if "cfg4" in a.which:
         cfg4(a)
     if "cfg5" in a.which:
