@@ -5,8 +5,13 @@ Per 16-sample hop and stream: slide a 32-sample window, encode it to one frame, 
 decode the frame back to 32 samples, average the overlapping 16 samples with the previous output.  The B windows
 are laid side by side as ONE signal [1, B*32] framed with hop = win = 32, so the encoder kernel emits the frame
 axis = stream axis layout [1][C][ldB] the streaming masker works on, and the decoder kernel (hop = win: no
-overlap) returns [1, B*32] = one 32-sample frame per stream.  encoder -> masker step -> mask -> decoder is one
-hipGraph, replayed per hop.
+overlap) returns [1, B*32] = one 32-sample frame per stream.
+
+hipGraphs: `streaming_inference` (one hop) replays one graph of encoder -> masker step -> mask -> decoder;
+`streaming_inference_chunk` replays ONE graph per chunk (BASELINE configs[4]: 320 samples = 20 hops): the window
+shifts, the 20 hop bodies, the averaging overlap-add and -- when the masker's segment counter crosses a boundary
+inside the chunk -- the Mem-LSTM update at its hop are all inside the capture.  One graph per (hops, update position);
+with 150-frame segments and 20-hop chunks that is three graphs.  The graphs are dropped when a parameter changes.
 """
 from typing import Optional
 
@@ -51,6 +56,9 @@ class DemoTseNet(nn.Module):
         """Reset the sliding windows and the masker state for `streams` concurrent streams."""
         self.queue = None
         self._graph = None
+        self._chunk_graphs = {}
+        self._tail = None
+        self._sig = None
         self._use_graph = use_graph
         self.masker.init_status(streams=streams, use_graph=False)   # this harness captures the whole hop itself
 
@@ -80,16 +88,8 @@ class DemoTseNet(nn.Module):
         self.queue[:, :self.hop_size] = self.queue[:, self.hop_size:].clone()
         self.queue[:, self.hop_size:] = chunk
         # embedding terms of the FiLM layers: refreshed in place when the embeddings change
-        key = (embed.data_ptr(), embed._version, tuple(embed.shape))
-        if key != m._embed_key:
-            if m._embed_static is None:
-                m._embed_static = embed.detach().reshape(m.streams, -1).float().clone()
-            else:
-                m._embed_static.copy_(embed.reshape(m.streams, -1))
-            m._embed_key = key
-            for f in m.seg_input_fusion:
-                if f is not None:
-                    f.set_per_frame_condition(m._embed_static, m.embed_norm)
+        self._refresh_embedding(embed)
+        self._check_parameters()
         if not self._use_graph:
             gen = self._hop_body()
         else:
@@ -116,12 +116,89 @@ class DemoTseNet(nn.Module):
             m.frames_counter = 0
         return gen.clone()
 
+    def _check_parameters(self) -> None:
+        """A captured graph replays the kernel plans' pointers: drop every graph when a parameter was updated."""
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if sig != self._sig:
+            self._graph = None
+            self._chunk_graphs = {}
+            self._sig = sig
+
+    def _refresh_embedding(self, embed: torch.Tensor) -> None:
+        m = self.masker
+        key = (embed.data_ptr(), embed._version, tuple(embed.shape))
+        if key != m._embed_key:
+            if m._embed_static is None:
+                m._embed_static = embed.detach().reshape(m.streams, -1).float().clone()
+            else:
+                m._embed_static.copy_(embed.reshape(m.streams, -1))
+            m._embed_key = key
+            for f in m.seg_input_fusion:
+                if f is not None:
+                    f.set_per_frame_condition(m._embed_static, m.embed_norm)
+
+    def _chunk_body(self, hops: int, update_at: Optional[int]):
+        """`hops` hops on the static buffers: window shift, hop body, averaging OLA; the Mem-LSTM update + block-0 reset
+        behind hop `update_at` (skim_inference.py:205-218).  Returns nothing: results are in _blocks / _tail."""
+        m, h = self.masker, self.hop_size
+        for i in range(hops):
+            self.queue[:, :h] = self.queue[:, h:].clone()
+            self.queue[:, h:] = self._chunk_in[:, i * h:(i + 1) * h]
+            frame = self._hop_body()
+            self._blocks[:, i * h:(i + 1) * h] = hip.overlap_average(self._tail, frame, self.ola_size)[:, :h]
+            self._tail.copy_(frame[:, h:])
+            if update_at == i:
+                m.update_mem_lstm()
+                m.reset_seg_lstm_status()
+
     @torch.no_grad()
     def streaming_inference_chunk(self, chunk: torch.Tensor, embed: torch.Tensor,
                                   pre_wav: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-        """chunk [B, n*16] -> the running output [B, L] (utils.py:100-118)."""
-        for i in range(chunk.shape[-1] // self.hop_size):
-            cur = self.streaming_inference(chunk[:, i * self.hop_size:(i + 1) * self.hop_size], embed)
-            if cur is not None:
-                pre_wav = overlap_add(pre_wav, cur, self.ola_size)
-        return pre_wav
+        """chunk [B, n*16] -> the running output [B, L] (utils.py:100-118).  With graphs on, a chunk after the first is
+        one graph replay; the result equals the hop-by-hop loop bit for bit."""
+        hops = chunk.shape[-1] // self.hop_size
+        m = self.masker
+        if (not getattr(self, "_use_graph", False) or self.queue is None or pre_wav is None or hops == 0
+                or pre_wav.shape[-1] < self.ola_size):
+            for i in range(hops):
+                cur = self.streaming_inference(chunk[:, i * self.hop_size:(i + 1) * self.hop_size], embed)
+                if cur is not None:
+                    pre_wav = overlap_add(pre_wav, cur, self.ola_size)
+            return pre_wav
+        hip.require_device(chunk, "DemoTseNet.streaming_inference_chunk")
+        if embed.dim() == 1:
+            embed = embed.unsqueeze(0)
+        self._check_parameters()
+        self._refresh_embedding(embed)
+        b, h = m.streams, self.hop_size
+        left = m.seg_size - m.frames_counter            # hops until the segment counter wraps
+        update_at = left - 1 if left <= hops else None
+        if self._tail is None or getattr(self, "_chunk_in", None) is None or self._chunk_in.shape != (b, hops * h):
+            dev = chunk.device
+            self._chunk_in = torch.empty(b, hops * h, dtype=torch.float32, device=dev)
+            self._blocks = torch.empty(b, hops * h, dtype=torch.float32, device=dev)
+            self._tail = torch.empty(b, self.ola_size, dtype=torch.float32, device=dev)
+            self._chunk_graphs = {}
+        self._chunk_in.copy_(chunk[:, :hops * h])
+        self._tail.copy_(pre_wav[:, pre_wav.shape[-1] - self.ola_size:])
+        key = (hops, update_at)
+        g = self._chunk_graphs.get(key)
+        if g is None:
+            state = m._seg_h + m._seg_c + [t for pair in m._mem_h + m._mem_c for t in pair] + [self.queue, self._tail]
+            saved = [t.clone() for t in state]
+            s = torch.cuda.Stream(chunk.device)
+            s.wait_stream(torch.cuda.current_stream(chunk.device))
+            with torch.cuda.stream(s):          # warm-up outside the capture: plans, per-frame embedding terms
+                self._chunk_body(hops, update_at)
+            torch.cuda.current_stream(chunk.device).wait_stream(s)
+            for t, v in zip(state, saved):
+                t.copy_(v)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._chunk_body(hops, update_at)
+            for t, v in zip(state, saved):
+                t.copy_(v)
+            self._chunk_graphs[key] = g
+        g.replay()
+        m.frames_counter = (m.frames_counter + hops) % m.seg_size
+        return torch.cat([pre_wav[:, :pre_wav.shape[-1] - self.ola_size], self._blocks, self._tail], dim=-1)

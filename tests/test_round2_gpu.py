@@ -175,3 +175,45 @@ def test_attentive_stats_pooling_with_lengths(PA, dev):
     assert got.shape == ref.shape
     assert rel_max(got.cpu().numpy(), ref.numpy()) < TOL
     assert rel_max(pool(x.to(dev)).cpu().numpy(), O.attentive_stats_pooling(x, sd, "").numpy()) < TOL
+
+
+def test_chunk_graph_equals_the_hop_loop_across_mem_lstm_updates(dev):
+    """BASELINE configs[4]: one hipGraph per 320-sample chunk.  16 chunks = 320 hops cross the 150-frame segment
+    boundary twice -- once in the middle of a chunk, once at the start of one -- so all three graph variants replay; the running output equals the eager hop-by-hop loop bit for bit and
+    the masker ends in the same state."""
+    from puresound_amd.streaming.demo import DemoTseNet
+    net = DemoTseNet().eval()
+    net.load_state_dict(det_state_dict(net))
+    net.to(dev)
+    b, n_chunks = 5, 16
+    wav = det_wave(501, b, 320 * n_chunks).to(dev)
+    emb = torch.rand(b, 192, generator=torch.Generator().manual_seed(502)).to(dev)
+    outs, states = [], []
+    for use_graph in (False, True):
+        net.init_streams(b, use_graph=use_graph)
+        pre = None
+        for i in range(n_chunks):
+            pre = net.streaming_inference_chunk(wav[:, i * 320:(i + 1) * 320], emb, pre)
+        outs.append(pre.clone())
+        states.append([t.clone() for t in net.masker._seg_h + net.masker._seg_c])
+        if use_graph:
+            # (the stream's very first hop only fills the window, so the segment counter lags the hop count by one)
+            assert set(net._chunk_graphs) == {(20, 10), (20, 0), (20, None)}
+    assert outs[0].shape == (b, 16 * (20 * n_chunks - 1) + 16)
+    assert torch.equal(outs[0], outs[1])
+    for a, c in zip(*states):
+        assert torch.equal(a[..., :b], c[..., :b])  # (columns beyond the b streams are padding)
+    # a weight update drops the graphs instead of replaying stale plans
+    sd = det_state_dict(net)
+    key = next(k for k in sd if k.endswith("weight") and sd[k].dim() > 1)
+    sd[key] = sd[key] * 1.25
+    net.load_state_dict(sd)
+    net.init_streams(b, use_graph=False)
+    ref = None
+    for i in range(3):
+        ref = net.streaming_inference_chunk(wav[:, i * 320:(i + 1) * 320], emb, ref)
+    net.init_streams(b, use_graph=True)
+    got = None
+    for i in range(3):
+        got = net.streaming_inference_chunk(wav[:, i * 320:(i + 1) * 320], emb, got)
+    assert torch.equal(got, ref) and not torch.equal(got, outs[0][:, :got.shape[1]])
