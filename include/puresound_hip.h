@@ -111,6 +111,13 @@ int ps_complex_mask_f32(const float* feats, const float* mask, float* out, int N
                         int mask_act, void* stream);
 int ps_istft_ola_f32(const float* frames, const float* window, float* out, int N, int n_fft, int hop, int T,
                      int ldt, int out_mode, void* stream);
+/* ps_polar_mask_f32: _apply_complex_mask_on_polar (base_nn.py:161-190) on [re;im] channel halves: magnitudes
+ * multiply (the mask's through tanh), phases add, back to [re;im].
+ * ps_magphase_f32: the conv-STFT's "MagPhase" output (lobe/encoder.py:384-389) from the analysis product
+ * [re ; im = -conv(x, wsin)]: rows [mags ; phase], mags = re^2 + im^2 (sqrt(. + 1e-8) when take_sqrt: trainable
+ * kernels), phase = atan2(im + 0.0, re). */
+int ps_polar_mask_f32(const float* feats, const float* mask, float* out, int N, int half, int ldt, void* stream);
+int ps_magphase_f32(const float* spec, float* out, int N, int half, int ldt, int take_sqrt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused 1x1 convolution (the Conv-TasNet channel-mixing GEMM; exact-fp32 MFMA):

@@ -168,6 +168,17 @@ def stft_encode(wav: torch.Tensor, wsin: torch.Tensor, wcos: torch.Tensor, hop: 
     return torch.stack((re, -im), dim=-1)
 
 
+def stft_magphase(wav: torch.Tensor, wsin: torch.Tensor, wcos: torch.Tensor, hop: int, trainable: bool) -> torch.Tensor:
+    """ConvSTFT.forward, output_format="MagPhase" (lobe/encoder.py:384-389): stack(mags, phase) -> [N,F,T,2];
+    mags is the power, its square root (+1e-8) when the kernels are trainable."""
+    spec = stft_encode(wav, wsin, wcos, hop)
+    re, neg_imag = spec[..., 0], spec[..., 1]
+    mags = re ** 2 + neg_imag ** 2
+    if trainable:
+        mags = torch.sqrt(mags + 1e-8)
+    return torch.stack([mags, torch.atan2(neg_imag + 0.0, re)], dim=-1)
+
+
 def window_sumsquare(window: torch.Tensor, n_frames: int, hop: int) -> torch.Tensor:
     """torch_window_sumsquare (lobe/stft.py:109-115): overlap-added window**2."""
     w2 = (window.flatten() ** 2).reshape(1, 1, -1).repeat(1, n_frames, 1)
@@ -343,11 +354,26 @@ def apply_tf_masks(tf_rep: torch.Tensor, mask: torch.Tensor, mask_type: str, f_t
     if mt == "real" and ft == "real":
         return tf_rep * mask
     if mt == "polar" and ft == "polar":
-        raise NotImplementedError("polar masks are not restated in the oracle yet")
+        # the reference stacks the mask halves on dim 1 (base_nn.py:74): [N, 2, C, T] against a [N, C, T, 2] feature, and
+        # _apply_complex_mask_on_polar then fails to broadcast for every shape
+        raise RuntimeError("apply_tf_masks(polar, polar): the reference cannot broadcast its mask (base_nn.py:74)")
     if mt == "real" and ft == "complex":
         # the reference reads `mask` before assignment here (base_nn.py:127)
         raise UnboundLocalError("local variable 'mask' referenced before assignment")
     raise NameError
+
+
+def apply_complex_mask_on_polar(tf_rep: torch.Tensor, est_mask: torch.Tensor) -> torch.Tensor:
+    """_apply_complex_mask_on_polar (base_nn.py:161-190): [N,C,T,2] x [N,C,T,2] -> [N,C,T,2]."""
+    re, im = tf_rep[..., 0], tf_rep[..., 1]
+    tf_mag = torch.sqrt(re ** 2 + im ** 2 + 1e-8)
+    tf_phase = torch.atan2(im, re)
+    mre, mim = est_mask[..., 0], est_mask[..., 1]
+    mask_mag = torch.sqrt(mre ** 2 + mim ** 2 + 1e-8)
+    mask_phase = torch.atan2(mim / (mask_mag + 1e-8), mre / (mask_mag + 1e-8))
+    est_mag = tf_mag * torch.tanh(mask_mag)
+    est_phase = tf_phase + mask_phase
+    return torch.stack([est_mag * torch.cos(est_phase), est_mag * torch.sin(est_phase)], dim=-1)
 
 
 def output_constrain(wav: torch.Tensor, mode: str) -> torch.Tensor:
@@ -403,6 +429,13 @@ def speaker_embedding(enroll_feats: torch.Tensor, sd: SD, spk: dict, p: str = "s
     if spk.get("magnitude", False):
         x = magnitude(x, drop_first=False)
         off = 1                                   # the parameter-free lobe still occupies ModuleList index 0
+    if spk.get("block") == "rnn":
+        # tse_skim_v1_causal (egs/tse/model.py:487-502): SingleRNN (lobe/rnn.py:9-55) -> ASP -> Conv1d
+        from . import dualpath_oracle as DP
+        y, _ = DP.lstm(x.transpose(1, 2), sd, f"{p}0.rnn.", spk.get("bidirectional", True))   # [N, T, D*H]
+        x = DP.linear(y, sd[f"{p}0.proj.weight"], sd[f"{p}0.proj.bias"]).transpose(1, 2)        # [N, C, T]
+        x = attentive_stats_pooling(x, sd, f"{p}1.")
+        return conv1x1(x, sd[f"{p}2.weight"]).squeeze(-1)
     n = spk["n_tcn"]
     for i in range(n):
         bp = f"{p}{i + off}."

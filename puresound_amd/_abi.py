@@ -64,6 +64,8 @@ SIGNATURES = {
     "ps_free_decode_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp] + [C.c_int] * 7 + [_vp]),
     "ps_frame_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_complex_mask_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
+    "ps_polar_mask_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 3 + [_vp]),
+    "ps_magphase_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 4 + [_vp]),
     "ps_istft_ola_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_conv1x1_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 5 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
     "ps_conv1x1_bf16_weight_bytes": (C.c_size_t, [C.c_int] * 3),

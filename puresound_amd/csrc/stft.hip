@@ -49,6 +49,53 @@ __global__ __launch_bounds__(256) void complex_mask_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(out + im) = yi;
 }
 
+// Complex mask in polar form (_apply_complex_mask_on_polar, base_nn.py:161-190), both operands as channel halves
+// [re ; im]: magnitudes multiply (the mask's through tanh), phases add.
+__global__ __launch_bounds__(256) void polar_mask_kernel(const float* __restrict__ feats, const float* __restrict__ mask,
+                                                         float* __restrict__ out, int half, int ldt) {
+  const int n = blockIdx.z, c = blockIdx.y;
+  const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t >= ldt) return;
+  const size_t re = ((size_t)n * 2 * half + c) * ldt + t, im = re + (size_t)half * ldt;
+  const f32x4 xr = *reinterpret_cast<const f32x4*>(feats + re), xi = *reinterpret_cast<const f32x4*>(feats + im);
+  const f32x4 mr = *reinterpret_cast<const f32x4*>(mask + re), mi = *reinterpret_cast<const f32x4*>(mask + im);
+  f32x4 yr, yi;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float tf_mag = sqrtf(xr[e] * xr[e] + xi[e] * xi[e] + 1e-8f);
+    const float tf_phase = atan2f(xi[e], xr[e]);
+    float mask_mag = sqrtf(mr[e] * mr[e] + mi[e] * mi[e] + 1e-8f);
+    const float mask_phase = atan2f(mi[e] / (mask_mag + 1e-8f), mr[e] / (mask_mag + 1e-8f));
+    mask_mag = tanhf(mask_mag);
+    const float est_mag = tf_mag * mask_mag, est_phase = tf_phase + mask_phase;
+    yr[e] = est_mag * cosf(est_phase);
+    yi[e] = est_mag * sinf(est_phase);
+  }
+  *reinterpret_cast<f32x4*>(out + re) = yr;
+  *reinterpret_cast<f32x4*>(out + im) = yi;
+}
+
+// "MagPhase" output of the conv-STFT (lobe/encoder.py:384-389) from the analysis product's channel halves
+// [re ; im] (im = -conv(x, wsin)): mags = re^2 + im^2, sqrt(mags + 1e-8) when the kernels are trainable;
+// phase = atan2(im + 0.0, re).  Output rows [mags ; phase].
+__global__ __launch_bounds__(256) void magphase_kernel(const float* __restrict__ spec, float* __restrict__ out, int half,
+                                                       int ldt, int take_sqrt) {
+  const int n = blockIdx.z, c = blockIdx.y;
+  const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t >= ldt) return;
+  const size_t re = ((size_t)n * 2 * half + c) * ldt + t, im = re + (size_t)half * ldt;
+  const f32x4 xr = *reinterpret_cast<const f32x4*>(spec + re), xi = *reinterpret_cast<const f32x4*>(spec + im);
+  f32x4 mg, ph;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float p = xr[e] * xr[e] + xi[e] * xi[e];
+    mg[e] = take_sqrt ? sqrtf(p + 1e-8f) : p;
+    ph[e] = atan2f(xi[e] + 0.0f, xr[e]);
+  }
+  *reinterpret_cast<f32x4*>(out + re) = mg;
+  *reinterpret_cast<f32x4*>(out + im) = ph;
+}
+
 // Real mask on real features (apply_tf_masks real/real, base_nn.py:52-54) for encoders whose decoder is not fused with
 // the mask product (the STFT front end of the tse_unet_tcn presets): y = x * act(m), rows of ldt frames.
 __global__ __launch_bounds__(256) void real_mask_kernel(const float* __restrict__ feats, const float* __restrict__ mask,
@@ -129,6 +176,29 @@ extern "C" int ps_complex_mask_f32(const float* feats, const float* mask, float*
   hipLaunchKernelGGL(complex_mask_kernel, dim3((ldt / 4 + 255) / 256, half, N), dim3(256), 0, (hipStream_t)stream,
                      feats, mask, out, half, ldt, mask_act);
   return launched("ps_complex_mask_f32");
+}
+
+extern "C" int ps_polar_mask_f32(const float* feats, const float* mask, float* out, int N, int half, int ldt,
+                                 void* stream) {
+  if (!feats || !mask || !out || N <= 0 || half <= 0 || half > 65535 || ldt <= 0 || ldt % kTileT != 0) {
+    set_error("ps_polar_mask_f32: bad argument (N=%d half=%d ldt=%d)", N, half, ldt);
+    return PS_E_INVALID;
+  }
+  LaunchTimer timer("polar_mask", (hipStream_t)stream);
+  hipLaunchKernelGGL(polar_mask_kernel, dim3((ldt / 4 + 255) / 256, half, N), dim3(256), 0, (hipStream_t)stream, feats,
+                     mask, out, half, ldt);
+  return launched("ps_polar_mask_f32");
+}
+
+extern "C" int ps_magphase_f32(const float* spec, float* out, int N, int half, int ldt, int take_sqrt, void* stream) {
+  if (!spec || !out || N <= 0 || half <= 0 || half > 65535 || ldt <= 0 || ldt % kTileT != 0) {
+    set_error("ps_magphase_f32: bad argument (N=%d half=%d ldt=%d)", N, half, ldt);
+    return PS_E_INVALID;
+  }
+  LaunchTimer timer("magphase", (hipStream_t)stream);
+  hipLaunchKernelGGL(magphase_kernel, dim3((ldt / 4 + 255) / 256, half, N), dim3(256), 0, (hipStream_t)stream, spec, out,
+                     half, ldt, take_sqrt);
+  return launched("ps_magphase_f32");
 }
 
 extern "C" int ps_real_mask_f32(const float* feats, const float* mask, float* out, int64_t rows, int ldt, int mask_act,

@@ -112,6 +112,28 @@ def complex_mask(feats: torch.Tensor, mask: torch.Tensor, mask_act: str = "linea
     return out
 
 
+def polar_mask(feats: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """[re;im] channel halves, padded [N,2H,ldt], x mask in the same layout -> polar-form product (base_nn.py:161-190)."""
+    require_device(feats, "polar_mask")
+    n, c2, ldt = feats.shape
+    if c2 % 2 or mask.shape != feats.shape:
+        raise RuntimeError("polar_mask: feats and mask must be [N, 2*half, ldt] with equal shapes")
+    out = torch.empty_like(feats)
+    check(lib().ps_polar_mask_f32(ptr(feats), ptr(mask), ptr(out), n, c2 // 2, ldt, stream_ptr(feats.device)),
+          "ps_polar_mask_f32")
+    return out
+
+
+def magphase(spec: torch.Tensor, take_sqrt: bool) -> torch.Tensor:
+    """analysis product [re;im] padded [N,2H,ldt] -> [mags;phase] in the same layout (lobe/encoder.py:384-389)."""
+    require_device(spec, "magphase")
+    n, c2, ldt = spec.shape
+    out = torch.empty_like(spec)
+    check(lib().ps_magphase_f32(ptr(spec), ptr(out), n, c2 // 2, ldt, int(take_sqrt), stream_ptr(spec.device)),
+          "ps_magphase_f32")
+    return out
+
+
 def istft_ola(frames: torch.Tensor, t: int, window: torch.Tensor, hop: int, out_mode: str = "none") -> torch.Tensor:
     """synthesis frames padded [N,n_fft,ldt] -> waveform [N,(T-1)*hop+n_fft] (window, /n_fft, OLA, /window-sum)."""
     require_device(frames, "istft_ola")

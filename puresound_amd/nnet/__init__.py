@@ -13,6 +13,7 @@ from .unet import Unet, UnetTcn
 from .dpcrn import DPCRN, DPRNNblock2D
 from .dparn import DPARN, DPARNblock2D
 from .lobe.attention import MhaSelfAttenLayer
+from .lobe.rnn import SingleRNN
 
 # the class namespace the parity tests hand to tests/golden/cases.build()
 class _Namespace(SimpleNamespace):
@@ -27,4 +28,4 @@ NS = _Namespace(SoTaskWrapModule=SoTaskWrapModule, SiMoTaskWrapModule=SiMoTaskWr
                      ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                      AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM, MemLSTM=MemLSTM, Unet=Unet, UnetTcn=UnetTcn,
                 DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, DPARN=DPARN, DPARNblock2D=DPARNblock2D,
-                MhaSelfAttenLayer=MhaSelfAttenLayer, Magnitude=Magnitude, FbankEnc=FbankEnc, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate)
+                MhaSelfAttenLayer=MhaSelfAttenLayer, SingleRNN=SingleRNN, Magnitude=Magnitude, FbankEnc=FbankEnc, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate)

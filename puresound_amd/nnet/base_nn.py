@@ -20,6 +20,7 @@ from .skim import SkiM
 from .unet import Unet
 from .lobe.encoder import ConvEncDec, FbankEnc, FreeEncDec
 from .lobe.pooling import AttentiveStatisticsPooling
+from .lobe.rnn import SingleRNN
 
 _MASK_ACTS = ("linear", "relu", "sigmoid")
 _STREAMS = {}
@@ -76,6 +77,62 @@ class EncDecMaskerBaseModel(BaseModel):
             # the reference reads `mask` before assignment here (base_nn.py:127)
             raise UnboundLocalError("local variable 'mask' referenced before assignment")
         raise NameError  # base_nn.py:78-79
+
+
+    # -- the reference's own functions (base_nn.py:41-190) on device tensors -----------------------------------------
+    def get_mask(self, mask: torch.Tensor, mask_constraint: str = "linear") -> torch.Tensor:
+        """base_nn.py:81-95, [N, C, T] -> [N, C, T]."""
+        c = self.check_mask_constraint(mask_constraint)
+        hip.require_device(mask, "get_mask")
+        if c == "linear":
+            return mask
+        t = mask.shape[-1]
+        ones = torch.ones_like(mask)  # act(mask) = 1 * act(mask): the mask kernel applies the constraint
+        return hip.unpad_rows(hip.real_mask(hip.pad_rows(ones), hip.pad_rows(mask), c), t)
+
+    def apply_tf_masks(self, tf_rep: torch.Tensor, est_masks: torch.Tensor, mask_type: str, f_type: str) -> torch.Tensor:
+        """base_nn.py:41-79 on [N, C, T] / [N, 2C, T] device tensors.  (complex, complex) -> [N, C, T, 2];
+        (real, real) -> [N, C, T]; (real, complex) fails as the reference does (it reads `mask` before assignment,
+        :127); (polar, polar) fails as the reference does too: it stacks the mask halves on dim 1 (:74) and the
+        broadcast in _apply_complex_mask_on_polar then raises RuntimeError for every shape."""
+        pairing = self.check_mask_pairing(mask_type, f_type)
+        hip.require_device(tf_rep, "apply_tf_masks")
+        t = tf_rep.shape[-1]
+        if pairing == "real":
+            return self._apply_mag_mask_on_mag(tf_rep, est_masks)
+        if pairing == "polar":
+            raise RuntimeError("The size of tensor a must match the size of tensor b: apply_tf_masks(polar, polar) "
+                               "stacks the mask on dim 1 in the reference (base_nn.py:74) and cannot broadcast; call "
+                               "_apply_complex_mask_on_polar with [N, C, T, 2] operands")
+        y = hip.unpad_rows(hip.complex_mask(hip.pad_rows(tf_rep), hip.pad_rows(est_masks), "linear"), t)
+        half = y.shape[1] // 2
+        return torch.stack((y[:, :half], y[:, half:]), dim=-1)
+
+    def _apply_mag_mask_on_mag(self, tf_rep: torch.Tensor, est_masks: torch.Tensor) -> torch.Tensor:
+        """base_nn.py:146-159: tf_rep * est_masks on [N, C, T]."""
+        hip.require_device(tf_rep, "_apply_mag_mask_on_mag")
+        t = tf_rep.shape[-1]
+        return hip.unpad_rows(hip.real_mask(hip.pad_rows(tf_rep), hip.pad_rows(est_masks), "linear"), t)
+
+    def _apply_complex_mask_on_reim(self, tf_rep: torch.Tensor, est_masks: torch.Tensor) -> torch.Tensor:
+        """base_nn.py:131-144 (_mul_c, :97-112): [N, C, T, 2] x [N, C, T, 2] -> [N, C, T, 2]."""
+        return self._pairwise4(tf_rep, est_masks, lambda a, b: hip.complex_mask(a, b, "linear"))
+
+    def _apply_complex_mask_on_polar(self, tf_rep: torch.Tensor, est_mask: torch.Tensor) -> torch.Tensor:
+        """base_nn.py:161-190: [N, C, T, 2] x [N, C, T, 2] -> [N, C, T, 2]."""
+        return self._pairwise4(tf_rep, est_mask, hip.polar_mask)
+
+    @staticmethod
+    def _pairwise4(a4: torch.Tensor, b4: torch.Tensor, fn) -> torch.Tensor:
+        hip.require_device(a4, "mask application")
+        if a4.dim() != 4 or a4.shape[-1] != 2 or a4.shape != b4.shape:
+            raise RuntimeError("expected two [N, C, T, 2] tensors")
+        t = a4.shape[2]
+        a = torch.cat((a4[..., 0], a4[..., 1]), dim=1).contiguous()
+        b = torch.cat((b4[..., 0], b4[..., 1]), dim=1).contiguous()
+        y = hip.unpad_rows(fn(hip.pad_rows(a), hip.pad_rows(b)), t)
+        half = y.shape[1] // 2
+        return torch.stack((y[:, :half], y[:, half:]), dim=-1)
 
 
 class SoTaskWrapModule(EncDecMaskerBaseModel):
@@ -154,6 +211,10 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         if out_mode not in ("linear", "sigmoid"):
             raise NameError("Non support type.")  # base_nn.py:421-422
         stft = isinstance(self.encoder, ConvEncDec)
+        if pairing == "polar":
+            # the reference's apply_tf_masks stacks the polar mask on dim 1 (base_nn.py:74) and then fails to broadcast
+            raise RuntimeError("The size of tensor a must match the size of tensor b (apply_tf_masks with polar masks, "
+                               "as in the reference: base_nn.py:70-76)")
         if stft:
             if pairing not in ("complex", "real"):
                 raise NotImplementedError("HIP inference path with an STFT encoder: (complex, complex) or (real, real)")
@@ -294,6 +355,9 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
                         x = m.forward_padded_staged(x, t, None)
             elif isinstance(lay, GatedTCN):
                 x = lay.forward_padded(x, t, None)
+                i += 1
+            elif isinstance(lay, SingleRNN):                                    # tse_skim_v1_causal
+                x = lay.forward_padded(x, t)
                 i += 1
             elif isinstance(lay, AttentiveStatisticsPooling):
                 pooled = lay.forward_padded(x, t)                                # [N, 2C]

@@ -202,10 +202,13 @@ class ConvSTFT(nn.Module):
 
     # -- reference API ----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """[N,1,L] -> [N,F,T,2] = stack(real, -imag) (encoder.py:358-391)."""
-        if self.output_format != "Complex":
-            raise NotImplementedError("only output_format='Complex' is on the HIP path")
+        """[N,1,L] -> [N,F,T,2] = stack(real, -imag) ("Complex") or stack(mags, phase) ("MagPhase")
+        (encoder.py:358-391)."""
+        if self.output_format not in ("Complex", "MagPhase"):
+            raise NotImplementedError
         y, t = self.encode_padded(x[:, 0, :] if x.dim() == 3 else x, False)
+        if self.output_format == "MagPhase":
+            y = hip.magphase(y, bool(self.trainable))
         bins = y.shape[1] // 2
         y = hip.unpad_rows(y, t)
         return torch.stack((y[:, :bins], y[:, bins:]), dim=-1)

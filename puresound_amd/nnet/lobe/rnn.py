@@ -1,10 +1,17 @@
 """Recurrent lobes (mirror of puresound/nnet/lobe/rnn.py:9-55): SingleRNN holds an nn.LSTM and its projection under
-the reference's keys (`rnn.*`, `proj.*`); the dual-path blocks drive it through ps_lstm_f32."""
+the reference's keys (`rnn.*`, `proj.*`).  The dual-path blocks of DPCRN / DPARN drive its LSTM through ps_lstm_f32
+with their own strided walks; as a layer of its own (the speaker net of tse_skim_v1_causal, egs/tse/model.py:487-495)
+it runs one sequence per utterance over the frame axis: input projection GEMM, ps_lstm_f32, output projection GEMM."""
 import torch
 import torch.nn as nn
 
+from ... import hip
+from ...ops import op_module, same_shape
+from .._plans import PlanCache, linear_plan, lstm_plan
 
-class SingleRNN(nn.Module):
+
+@op_module("single_rnn_fwd", same_shape)
+class SingleRNN(PlanCache, nn.Module):
     def __init__(self, rnn_type: str, input_size: int, hidden_size: int, bidirectional: bool = False,
                  dropout: float = 0.0):
         super().__init__()
@@ -18,5 +25,33 @@ class SingleRNN(nn.Module):
         self.drop = nn.Dropout(p=dropout)
         self.proj = nn.Linear(hidden_size * self.num_direction, input_size)
 
+    def _build(self, device):
+        if self.rnn_type != "LSTM":
+            raise NotImplementedError("SingleRNN on HIP: LSTM cells only (every recipe's setting)")
+        if self.training and self.drop.p > 0:
+            raise RuntimeError("SingleRNN: dropout is active; the HIP path is inference only -- call .eval()")
+        return dict(rnn=lstm_plan(self.rnn, device, self.gemm_precision), proj=linear_plan(self.proj, device))
+
+    def forward_padded(self, x: torch.Tensor, t: int) -> torch.Tensor:
+        """padded [N, C, ldt] -> [N, C, ldt]: proj(LSTM(x)) over the t frames of each utterance (lobe/rnn.py:37-55)."""
+        p = self._plan_get(x.device, self._build)
+        rnn, proj = p["rnn"], p["proj"]
+        n, _, ldt = x.shape
+        gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=x.device)
+        if rnn["planes"] and rnn["I"] >= 64:
+            if rnn["planes"] not in rnn["wih_planes"]:
+                rnn["wih_planes"][rnn["planes"]] = hip.pack_wt_bf16(rnn["wih_rows"], rnn["planes"])
+            hip.conv1x1_bf16(x, t, rnn["wih_planes"][rnn["planes"]], rnn["rows"], None, rnn["bias"], out=gx)
+        else:
+            hip.conv1x1(x, t, rnn["wih"], rnn["rows"], None, rnn["bias"], out=gx)
+        # one sequence per utterance: q = 1, the steps walk the frame axis
+        hseq, _ = hip.lstm(gx, rnn["whh_t"], rnn["H"], rnn["D"], 1, ldt, t, 1)
+        y, _ = hip.conv1x1(hseq, t, proj["wt"], proj["M"], None, proj["bias"],
+                           out=torch.empty(n, proj["M"], ldt, dtype=torch.float32, device=x.device))
+        return y
+
     def forward(self, x: torch.Tensor):
-        raise NotImplementedError("SingleRNN runs inside DPRNNblock2D on the HIP path (ps_lstm_f32); LSTM cells only")
+        """x [N, C, T] -> [N, C, T]."""
+        hip.require_device(x, "SingleRNN.forward")
+        t = x.shape[-1]
+        return hip.unpad_rows(self.forward_padded(hip.pad_rows(x), t), t)

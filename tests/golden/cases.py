@@ -105,6 +105,13 @@ CASES = {
                             dconv_norm="gGN", causal=False, tcn_use_film=True)),
         speaker_net=dict(n_tcn=5, C=256, H=128, att=128, E=192, block="gated", magnitude=True),
         wrap=dict(mask_constraint="linear", drop_first_bin=True), B=2, L=4000, L_enroll=3000, seed=1234),
+    "tse_skim_v1_short": dict(   # tse_skim_v1_causal (egs/tse/model.py:465-507): a bidirectional SingleRNN as the speaker net
+        kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
+        masker=dict(cls="SkiM", args=(128, 256, 128),
+                    kw=dict(n_blocks=4, seg_size=150, seg_overlap=False, causal=True, embed_dim=192, embed_norm=True,
+                            block_with_embed=[1, 1, 1, 1], embed_fusion="FiLM")),
+        speaker_net=dict(block="rnn", C=128, H=192, att=128, E=192, bidirectional=True),
+        wrap=dict(mask_constraint="ReLU"), B=2, L=4000, L_enroll=3000, seed=1234),
     "tse_skim_v0_short": dict(   # tse_skim_v0 (egs/tse/model.py:371-416): the non-causal (bidirectional) SkiM preset
         kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
         masker=dict(cls="SkiM", args=(128, 256, 128),
@@ -288,6 +295,9 @@ CASES = {
                      B=2, L=400, seed=18),
     # ---- signal scores (loss/sdr.py) and the multi-output wrapper (base_nn.py:780-939), SURVEY 8(f) row 4 ----
     "loss_sdr_modes": dict(kind="loss", B=5, M=3, L=4000, seed=71),
+    # mask application functions (base_nn.py:41-190) on their own, and the conv-STFT's "MagPhase" output
+    # (lobe/encoder.py:384-389) with trainable (sqrt) and fixed (power) kernels
+    "mask_functions": dict(kind="func", B=2, C=7, T=41, n_fft=64, hop=16, L=400, seed=81),
     "simo_free": dict(kind="simo", enc=dict(kind="free", win=16, hop=8, C=24), heads=2,
                       masker=masker_args(24, 0, False, [0, 0], tcn_kernel=3, tcn_dim=12, repeat_tcn=2,
                                          tcn_dilated_basic=2, per_tcn_stack=2),
@@ -340,6 +350,11 @@ def build_simo_masker(ns, c):
 
 def build_speaker_net(ns, s):
     import torch.nn as nn
+    if s.get("block") == "rnn":
+        return nn.ModuleList([ns.SingleRNN(rnn_type="LSTM", input_size=s["C"], hidden_size=s["H"],
+                                           bidirectional=s.get("bidirectional", True), dropout=0.05),
+                              ns.AttentiveStatisticsPooling(s["C"], s["att"]),
+                              nn.Conv1d(s["C"] * 2, s["E"], 1, bias=False)])
     if s.get("block") == "gated":
         return nn.ModuleList(
             ([ns.Magnitude(drop_first=False)] if s.get("magnitude") else [])
@@ -349,6 +364,16 @@ def build_speaker_net(ns, s):
         [ns.TCN(s["C"], s["H"], 3, dilation=2 ** i, causal=False, tcn_norm="gLN", dconv_norm="gGN")
          for i in range(s["n_tcn"])]
         + [ns.AttentiveStatisticsPooling(s["C"], s["att"]), nn.Conv1d(s["C"] * 2, s["E"], 1, bias=False)])
+
+
+def func_inputs(c):
+    """tf_rep / mask as [N, 2C, T] channel halves (the layout apply_tf_masks takes) and a waveform."""
+    from detweights import det_wave
+    n, ch, t = c["B"], c["C"], c["T"]
+    tf_rep = det_wave(c["seed"], n * 2 * ch, t).reshape(n, 2 * ch, t) * 2.0
+    mask = det_wave(c["seed"] + 1, n * 2 * ch, t).reshape(n, 2 * ch, t) * 3.0
+    wav = det_wave(c["seed"] + 2, n, c["L"])
+    return tf_rep, mask, wav
 
 
 def build(ns, name):
@@ -430,7 +455,7 @@ def oracle_cfg(name):
         cfg["encoder_spk"] = dict(hop=c["enc_spk"]["kw"].get("hop_length", 128),
                                   trainable=c["enc_spk"]["kw"].get("trainable", True))
     if "speaker_net" in c:
-        cfg["speaker_net"] = {k: v for k, v in c["speaker_net"].items() if k in ("n_tcn", "block", "magnitude")}
+        cfg["speaker_net"] = {k: v for k, v in c["speaker_net"].items() if k in ("n_tcn", "block", "magnitude", "bidirectional")}
     return cfg
 
 

@@ -41,6 +41,7 @@ from puresound.nnet.unet import Unet, UnetTcn  # noqa: E402
 from puresound.nnet.dpcrn import DPCRN  # noqa: E402
 from puresound.nnet.dparn import DPARN  # noqa: E402
 from puresound.nnet.lobe.trivial import Magnitude  # noqa: E402
+from puresound.nnet.lobe.rnn import SingleRNN  # noqa: E402
 
 import cases  # noqa: E402
 from detweights import det_state_dict, det_wave  # noqa: E402
@@ -49,7 +50,7 @@ REF = cases.namespace(SoTaskWrapModule=SoTaskWrapModule, SiMoTaskWrapModule=SiMo
                       ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                       AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM,
                       StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN, DPARN=DPARN,
-                      Magnitude=Magnitude, FbankEnc=FbankEnc)
+                      Magnitude=Magnitude, FbankEnc=FbankEnc, SingleRNN=SingleRNN)
 
 
 def sub(x: torch.Tensor, cs: int = 7, ts: int = 5) -> np.ndarray:
@@ -256,12 +257,35 @@ def run_simo(name, c):
     return {"wav": wav.numpy(), "loss": loss.numpy(), "loss_all_active": loss_all_active.numpy()}
 
 
+@torch.no_grad()
+def run_func(name, c):
+    """apply_tf_masks / get_mask / the _apply_* helpers called directly on the reference's base class, and
+    ConvEncDec(output_format="MagPhase").forward."""
+    from puresound.nnet.base_nn import EncDecMaskerBaseModel
+    m = EncDecMaskerBaseModel()
+    tf_rep, mask, wav = cases.func_inputs(c)
+    out = {}
+    for con in ("linear", "relu", "sigmoid"):
+        out["get_mask_" + con] = m.get_mask(mask.clone(), con).numpy()
+    out["complex_complex"] = m.apply_tf_masks(tf_rep.clone(), mask.clone(), "complex", "complex").numpy()   # [N,C,T,2]
+    out["real_real"] = m.apply_tf_masks(tf_rep.clone(), mask.clone(), "real", "real").numpy()
+    re, im = torch.chunk(tf_rep, 2, dim=1)
+    mre, mim = torch.chunk(mask, 2, dim=1)
+    out["polar"] = m._apply_complex_mask_on_polar(torch.stack([re, im], -1), torch.stack([mre, mim], -1)).numpy()
+    for tr in (True, False):
+        enc = ConvEncDec(fft_length=c["n_fft"], win_type="hann", win_length=c["n_fft"], hop_length=c["hop"],
+                         trainable=tr, output_format="MagPhase").eval()
+        enc.load_state_dict(det_state_dict(enc))
+        out["magphase_trainable" if tr else "magphase_fixed"] = enc(wav.clone()).numpy()
+    return out
+
+
 def dump_state_dict_keys():
     """Key -> shape of every reference state_dict the mirror modules must reproduce (drop-in checkpoints)."""
     import json
     out = {}
     for name, c in cases.CASES.items():
-        if c["kind"] == "loss":  # functions of two waveforms, no parameters
+        if c["kind"] in ("loss", "func"):  # functions of tensors, no parameters
             continue
         model = cases.build(REF, name)
         out[name] = {k: list(v.shape) for k, v in model.state_dict().items()}
@@ -277,7 +301,7 @@ def main():
     dump_state_dict_keys()
     for name, c in cases.CASES.items():
         fn = {"wrap": run_wrap, "masker": run_masker, "encdec": run_encdec, "rnn": run_rnn,
-              "stream": run_stream, "unet": run_unet, "fbank": run_fbank, "loss": run_loss, "simo": run_simo}[c["kind"]]
+              "stream": run_stream, "unet": run_unet, "fbank": run_fbank, "loss": run_loss, "simo": run_simo, "func": run_func}[c["kind"]]
         if only and name not in only:
             continue
         out = fn(name, c)

@@ -994,7 +994,7 @@ def test_ns_dpcrn_preset_matches_reference_golden(PA, dev, golden_dir, name):
 
 @pytest.mark.parametrize("name", ["tse_unet_tcn_causal_short", "tse_unet_tcn_short", "tse_skim_causal_short",
                                   "tse_skim_fbank_short", "tse_skim_vad_short", "cfg3_causal_short",
-                                  "tse_unet_tcn_v1_short", "tse_skim_v0_short"])
+                                  "tse_unet_tcn_v1_short", "tse_skim_v0_short", "tse_skim_v1_short"])
 def test_more_tse_presets_match_reference_golden(PA, dev, golden_dir, name):
     """egs/tse presets verbatim: tse_unet_tcn_v0_causal (STFT + UnetTcn with causal gated bN1d TCN + speaker net
     Magnitude -> 5 x GatedTCN -> ASP -> 1x1, real mask on the STFT) and tse_skim_v0_causal (FreeEncDec + SkiM/FiLM +

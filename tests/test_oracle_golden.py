@@ -281,3 +281,33 @@ def test_simo_wrapper_matches_reference(golden_dir, name):
     np.testing.assert_allclose(LO.simo_forward(noisy, ref_clean, sd, cfg, labels).numpy(), g["loss"], atol=DB_TOL, rtol=0)
     np.testing.assert_allclose(LO.simo_forward(noisy, ref_clean, sd, cfg, torch.zeros_like(labels)).numpy(),
                                g["loss_all_active"], atol=DB_TOL, rtol=0)
+
+
+def test_mask_functions_and_magphase_match_reference(golden_dir):
+    """apply_tf_masks / get_mask / _apply_complex_mask_on_polar (base_nn.py:41-190) and the conv-STFT's "MagPhase"
+    output (lobe/encoder.py:384-389): the oracle's restatements against the imported reference's values."""
+    import torch.nn as nn
+    import puresound_amd.nnet as PA
+    c = cases.CASES["mask_functions"]
+    g = _load(golden_dir, "mask_functions")
+    tf_rep, mask, wav = cases.func_inputs(c)
+    for con in ("linear", "relu", "sigmoid"):
+        assert rel_max(O.get_mask(mask, con).numpy(), g["get_mask_" + con]) < TOL
+    assert rel_max(O.apply_tf_masks(tf_rep, mask, "complex", "complex").numpy(), g["complex_complex"]) < TOL
+    assert rel_max(O.apply_tf_masks(tf_rep, mask, "real", "real").numpy(), g["real_real"]) < TOL
+    re, im = torch.chunk(tf_rep, 2, dim=1)
+    mre, mim = torch.chunk(mask, 2, dim=1)
+    got = O.apply_complex_mask_on_polar(torch.stack([re, im], -1), torch.stack([mre, mim], -1))
+    assert rel_max(got.numpy(), g["polar"]) < TOL
+    with pytest.raises(RuntimeError):
+        O.apply_tf_masks(tf_rep, mask, "polar", "polar")
+    for tr in (True, False):
+        enc = PA.ConvEncDec(fft_length=c["n_fft"], win_type="hann", win_length=c["n_fft"], hop_length=c["hop"],
+                            trainable=tr, output_format="MagPhase")
+        sd = det_state_dict(enc)
+        got = O.stft_magphase(wav, sd["encoder.wsin"], sd["encoder.wcos"], c["hop"], tr).numpy()
+        want = g["magphase_trainable" if tr else "magphase_fixed"]
+        assert rel_max(got[..., 0], want[..., 0]) < TOL
+        # phases: compare on the unit circle (atan2 is discontinuous at +-pi) where the bin is not numerically empty
+        big = want[..., 0] > 1e-3 * want[..., 0].max()
+        assert np.abs(np.exp(1j * got[..., 1]) - np.exp(1j * want[..., 1]))[big].max() < 1e-3

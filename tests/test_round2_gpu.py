@@ -217,3 +217,37 @@ def test_chunk_graph_equals_the_hop_loop_across_mem_lstm_updates(dev):
     for i in range(3):
         got = net.streaming_inference_chunk(wav[:, i * 320:(i + 1) * 320], emb, got)
     assert torch.equal(got, ref) and not torch.equal(got, outs[0][:, :got.shape[1]])
+
+
+def test_mask_functions_and_magphase_on_the_device(PA, dev, golden_dir):
+    """The reference's mask functions (base_nn.py:41-190) and the "MagPhase" STFT output (lobe/encoder.py:384-389) as
+    HIP kernels against the reference's golden values; the pairings the reference itself cannot run fail the same way."""
+    c = cases.CASES["mask_functions"]
+    g = np.load(f"{golden_dir}/mask_functions.npz")
+    tf_rep, mask, wav = cases.func_inputs(c)
+    m = PA.SoTaskWrapModule.__mro__[1]()  # EncDecMaskerBaseModel
+    x, k = tf_rep.to(dev), mask.to(dev)
+    for con in ("linear", "relu", "sigmoid"):
+        assert rel_max(m.get_mask(k, con).cpu().numpy(), g["get_mask_" + con]) < TOL
+    assert rel_max(m.apply_tf_masks(x, k, "complex", "complex").cpu().numpy(), g["complex_complex"]) < TOL
+    assert rel_max(m.apply_tf_masks(x, k, "real", "real").cpu().numpy(), g["real_real"]) < TOL
+    re, im = torch.chunk(x, 2, dim=1)
+    mre, mim = torch.chunk(k, 2, dim=1)
+    got = m._apply_complex_mask_on_polar(torch.stack([re, im], -1), torch.stack([mre, mim], -1))
+    assert rel_max(got.cpu().numpy(), g["polar"]) < TOL
+    with pytest.raises(RuntimeError):
+        m.apply_tf_masks(x, k, "polar", "polar")
+    with pytest.raises(UnboundLocalError):
+        m.apply_tf_masks(x, k, "real", "complex")
+    with pytest.raises(NotImplementedError):
+        m.get_mask(k, "softmax")
+    for tr in (True, False):
+        enc = PA.ConvEncDec(fft_length=c["n_fft"], win_type="hann", win_length=c["n_fft"], hop_length=c["hop"],
+                            trainable=tr, output_format="MagPhase").eval()
+        enc.load_state_dict(det_state_dict(enc))
+        got = enc.to(dev)(wav.to(dev)).cpu().numpy()
+        want = g["magphase_trainable" if tr else "magphase_fixed"]
+        assert got.shape == want.shape
+        assert rel_max(got[..., 0], want[..., 0]) < TOL
+        big = want[..., 0] > 1e-3 * want[..., 0].max()
+        assert np.abs(np.exp(1j * got[..., 1]) - np.exp(1j * want[..., 1]))[big].max() < 1e-3
