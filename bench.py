@@ -26,14 +26,33 @@ B_PER_GPU, L, SR = 32, 64000, 16000
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, dense bf16 matrix peak; the 3-way split spends 6 bf16 products per fp32 one
 SPLIT_PRODUCTS = 6
-# HBM bytes per ps_conv1x1_bf16_f32 launch (planes = 3) at 16 utterances, from the PMC passes committed as
-# profiles/r01_pmc_hbm_traffic_bf16x3.txt (same recipe as below): in_conv + pointwise + out_conv.
-PMC_BF16X3_BYTES_PER_LAUNCH = 2 * (207.9e6 + 137.9e6 + 348.9e6) / 3  # algorithmic: 2 * (207.6 + 138.4 + 346.0) / 3 MB
-# HBM bytes per ps_conv1x1_f32 launch at 32 utterances, averaged over the three GEMM shapes, from the PMC
-# passes committed as profiles/r01_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-# runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): (207.4 + 149.4 + 388.4) / 3 MB per
-# 16-utterance launch.  Algorithmic bytes of the same launches: (207.6 + 138.4 + 346.0) / 3 MB.
-PMC_CONV1X1_BYTES_PER_LAUNCH = 2 * (207.4e6 + 149.4e6 + 388.4e6) / 3
+# roofline.traffic (HBM bytes per launch of the dominant kernel) cannot be collected inside this run -- PMC counters
+# need their own rocprofv3 passes -- so it is READ from the summary of those passes committed under profiles/
+# (tools/pmc_summary.py; same command line as this benchmark, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+# gfx950) and labelled with the file it came from.  It never enters `frac`.
+PMC_FILES = {"bf16x3": "profiles/r02_pmc_hbm_traffic_bf16x3.json", "fp32": "profiles/r02_pmc_hbm_traffic_fp32.json"}
+
+
+def pmc_traffic(gemm, prefix):
+    """(average HBM bytes per launch over the kernels whose name starts with `prefix`, source file) or (None, None)."""
+    path = os.path.join(ROOT, PMC_FILES.get(gemm, ""))
+    if not os.path.isfile(path):
+        return None, None
+    ks = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(prefix)}
+    n = sum(v["launches"] for v in ks.values())
+    if not n:
+        return None, None
+    return sum(v["total_bytes"] * v["launches"] for v in ks.values()) / n, PMC_FILES[gemm]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def build_model(dev):
@@ -75,20 +94,27 @@ def cpu_baseline(seconds_budget=25.0):
     sd = {k: v.float() for k, v in det_state_dict(model).items()}
     cfg = cases.oracle_cfg("cfg2_full")
     nb = 4
-    torch.set_num_threads(host_cores())
     x = det_wave(1234, nb, L)
+    out = {}
     with torch.no_grad():
-        O.inference(x[:1], sd, cfg)  # warm-up (thread pools, allocator)
-        t0 = time.perf_counter()
-        reps = 0
-        while True:
-            O.inference(x, sd, cfg)
-            reps += 1
-            if time.perf_counter() - t0 > seconds_budget * 0.6 or reps >= 3:
-                break
-        dt = (time.perf_counter() - t0) / reps
-    return {"value": nb * L / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} x batch {nb} x 4 s of the same config (oracle/separator_oracle.py, fp32, torch CPU)"}
+        for threads, batch, budget in ((host_cores(), nb, seconds_budget * 0.6), (1, 1, seconds_budget * 0.4)):
+            torch.set_num_threads(threads)
+            O.inference(x[:1, :16000], sd, cfg)  # warm-up (thread pools, allocator)
+            t0 = time.perf_counter()
+            reps = 0
+            while True:
+                O.inference(x[:batch], sd, cfg)
+                reps += 1
+                if time.perf_counter() - t0 > budget or reps >= 3:
+                    break
+            dt = (time.perf_counter() - t0) / reps
+            out[threads] = (batch * L / dt, reps, batch)
+    full = max(out)
+    return {"value": out[full][0], "unit": "samples/s", "cores": full, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"{out[full][1]} x batch {out[full][2]} x 4 s of the same config (oracle/separator_oracle.py, fp32, "
+                      f"torch CPU, {full} threads)",
+            "single_thread": {"value": out[1][0], "unit": "samples/s", "cores": 1,
+                              "sample": f"{out[1][1]} x batch {out[1][2]} x 4 s, torch.set_num_threads(1)"}}
 
 
 def main():
@@ -98,8 +124,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--streams", type=int, default=None,
-                    help="HIP streams the batch is split over inside one GPU (default: the model's own default)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the batch is split over inside one GPU.  Default 1: every launch covers the whole "
+                         "batch, so the timed path, the per-kernel hipEvents and a rocprofv3 kernel trace of this "
+                         "command describe the same launches (two streams bring the split GEMM nothing: 13.5 vs 13.7 ms)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="multi-GPU: uneven shards (rank r owns 32 - r utterances) through "
+                         "puresound_amd.batch_shard.sharded_inference's ragged gather instead of equal shards")
     ap.add_argument("--gemm", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
                     help="arithmetic of the 1x1-conv GEMMs.  bf16x3 (default): every fp32 operand split into three "
                          "bf16 terms, six products on the bf16 MFMA pipe, fp32 accumulation -- the result carries "
@@ -113,26 +144,38 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE = {world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} (one rank per GPU)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
     from puresound_amd import _abi
-    from puresound_amd.batch_shard import gather_utterances
+    from puresound_amd.batch_shard import gather_utterances, sharded_inference
     lib = _abi.lib()  # no HIP extension, no benchmark
     model = build_model(dev)
     model.masker.set_gemm_precision(args.gemm)
     if args.streams is not None:
         model.hip_streams = args.streams
 
-    g = torch.Generator().manual_seed(1234 + rank)
-    noisy = ((torch.rand(B_PER_GPU, L, generator=g) * 2 - 1) * 0.5).to(dev)  # synthetic 16 kHz waveforms
-    total_b = B_PER_GPU * world
+    ragged = args.ragged and world > 1
+    total_b = B_PER_GPU * world - (1 if ragged else 0)
+    if ragged:
+        # every rank holds the whole (synthetic) batch and runs its balanced contiguous share: the shards differ by one
+        # utterance, the gather pads to the largest shard
+        g = torch.Generator().manual_seed(1234)
+        full = ((torch.rand(total_b, L, generator=g) * 2 - 1) * 0.5).to(dev)
+        from puresound_amd.batch_shard import shard_bounds
+        lo, hi = shard_bounds(total_b, world, rank)
+        noisy = full[lo:hi]
+    else:
+        g = torch.Generator().manual_seed(1234 + rank)
+        noisy = ((torch.rand(B_PER_GPU, L, generator=g) * 2 - 1) * 0.5).to(dev)  # synthetic 16 kHz waveforms
 
     def step():
+        if ragged:
+            return sharded_inference(model.inference, full)
         out = model.inference(noisy)
         if world > 1:
             out = gather_utterances(out, total_b)
@@ -152,10 +195,13 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = torch.empty(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, mine)
+        rank_ms = [float(v) / args.steps * 1e3 for v in every.tolist()]
+        elapsed = float(every.max().item())
     ms_per_step = elapsed / args.steps * 1e3
     value = total_b * L * args.steps / elapsed
 
@@ -173,7 +219,13 @@ def main():
                                "batch=32x4 s fp32 per GPU (BASELINE configs[1])",
                    "global_batch": total_b, "samples_per_utt": L, "parallelism": f"dp{world}",
                    "hip_streams_per_gpu": int(getattr(model, "hip_streams", 2)),
+                   "shards": "ragged (balanced contiguous split of 32*N-1 utterances)" if ragged else "equal",
                    "x_realtime": value / SR},
+        # what the collective layer actually saw (the driver's scaling run checks it against --gpus)
+        "distributed": {"world_size": dist.get_world_size() if world > 1 else 1,
+                        "backend": dist.get_backend() if world > 1 else None,
+                        "collective": "all_gather_into_tensor of [B/N, L] fp32 inside the timed step" if world > 1 else None,
+                        "ms_per_step_by_rank": rank_ms},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -193,6 +245,12 @@ def main():
         model.hip_streams = streams_kept
         import ctypes
         fams = {}
+        c_ch, h_ch = model.masker.input_dim, model.masker.tcn_dim
+        # algorithmic HBM bytes per launch of the HBM-bound kernels (fp32): dwconv reads and writes [32][H][T];
+        # the encoder writes [32][C][T] (+ the waveform in); the decoder reads feats and mask [32][C][T] (+ waveform out)
+        hbm_bytes = {"dwconv": 2.0 * B_PER_GPU * h_ch * t * 4,
+                     "free_encode": B_PER_GPU * (c_ch * t + L) * 4.0,
+                     "free_decode": B_PER_GPU * (2.0 * c_ch * t + L) * 4.0}
         for fam in ("dwconv", "free_encode", "free_decode"):
             ms, cnt = ctypes.c_double(), ctypes.c_int()
             _abi.check(lib.ps_profile_read(fam.encode(), ctypes.byref(ms), ctypes.byref(cnt)), "ps_profile_read")
@@ -206,28 +264,39 @@ def main():
         assert conv_cnt == launches * args.steps, (conv_cnt, launches, args.steps)
         avg_ms = conv_ms / conv_cnt
         achieved = (flops / launches) / (avg_ms * 1e-3) / 1e12
+        streams_note = ("kernel durations: hipEvents on the launch stream (ps_profile_enable) over the same K steps, one "
+                        "stream; the timed region ran %d stream(s)" % int(streams_kept))
         common = {"bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "avg_launch_ms": avg_ms,
-                  "note": "kernel durations from a single-stream pass; value/ms_per_step from the product path "
-                          "(2 sub-batch streams)",
+                  "note": streams_note,
                   "flop_per_launch": flops / launches, "launches_per_step": launches,
-                  "kernel_ms_per_step": {k: v[0] / args.steps for k, v in fams.items()}}
+                  "kernel_ms_per_step": {k: v[0] / args.steps for k, v in fams.items()},
+                  # HBM-bound kernels: algorithmic bytes / average launch duration, against the 8 TB/s peak
+                  "hbm_bound_kernels": {k: {"avg_launch_ms": fams[k][0] / max(fams[k][1], 1),
+                                            "algorithmic_bytes": hbm_bytes[k],
+                                            "GBps": hbm_bytes[k] / (fams[k][0] / max(fams[k][1], 1) * 1e-3) / 1e9,
+                                            "frac_of_8TBps": hbm_bytes[k] / (fams[k][0] / max(fams[k][1], 1) * 1e-3) / 8e12}
+                                        for k in hbm_bytes if fams[k][1]}}
         if args.gemm == "fp32":
+            traffic, src = pmc_traffic("fp32", "ps::conv1x1_")
             result["roofline"] = dict(common, peak=F32_MFMA_PEAK_TFLOPS, frac=achieved / F32_MFMA_PEAK_TFLOPS,
-                                      traffic=PMC_CONV1X1_BYTES_PER_LAUNCH, kernel="ps::conv1x1_* (ps_conv1x1_f32)",
-                                      traffic_note="bytes per launch from the committed PMC passes "
-                                                   "(profiles/r01_pmc_hbm_traffic.txt), not re-measured in this run")
+                                      traffic=traffic, kernel="ps::conv1x1_* (ps_conv1x1_f32)",
+                                      traffic_note=f"HBM bytes per launch read from {src} (separate rocprofv3 --pmc "
+                                                   f"passes of this command), not measured in this run" if src else
+                                                   "no PMC summary committed for this arithmetic")
         else:
             planes_products = SPLIT_PRODUCTS if args.gemm == "bf16x3" else 1
             peak = BF16_MFMA_PEAK_TFLOPS / planes_products
+            traffic, src = pmc_traffic(args.gemm, "ps::conv1x1_bf16_")
             result["roofline"] = dict(
-                common, peak=peak, frac=achieved / peak, traffic=PMC_BF16X3_BYTES_PER_LAUNCH if args.gemm == "bf16x3" else None,
-                kernel="ps::conv1x1_bf16_pp_kernel (ps_conv1x1_bf16_f32)",
+                common, peak=peak, frac=achieved / peak, traffic=traffic,
+                kernel="ps::conv1x1_bf16_il_kernel (ps_conv1x1_bf16_f32)",
                 peak_note=f"algorithmic fp32 FLOP (2*M*K*T*N per launch) against the dense bf16 MFMA peak "
                           f"{BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {planes_products} bf16 products per multiply-add; "
                           f"the same FLOP against the fp32 MFMA peak {F32_MFMA_PEAK_TFLOPS} TFLOP/s = "
                           f"{achieved / F32_MFMA_PEAK_TFLOPS:.2f}",
-                traffic_note="bytes per launch from the committed PMC passes "
-                             "(profiles/r01_pmc_hbm_traffic_bf16x3.txt), not re-measured in this run")
+                algorithmic_bytes_per_launch=B_PER_GPU * t * 4.0 * (3 * c_ch + 5 * h_ch) / 3,
+                traffic_note=f"HBM bytes per launch read from {src} (separate rocprofv3 --pmc passes of this command), "
+                             f"not measured in this run" if src else "no PMC summary committed for this arithmetic")
     if rank == 0 and world == 1 and args.gemm == "bf16x3" and not args.no_roofline:
         # the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32 on fp32 operands) timed beside it, same inputs, same K steps
         model.masker.set_gemm_precision("fp32")

@@ -36,3 +36,15 @@ def test_bench_line(gemm):
     if gemm == "bf16x3":
         assert d["fp32_mfma_path"]["ms_per_step"] > d["ms_per_step"]  # the exact-fp32 MFMA path, timed beside it
     assert "cpu_baseline" not in d  # (--no-cpu-baseline)
+    assert "profiles/" in r["traffic_note"] and r["kernel"].startswith("ps::conv1x1")
+    assert d["config"]["hip_streams_per_gpu"] == 1  # timed path, events and a kernel trace describe the same launches
+    assert d["distributed"] == {"world_size": 1, "backend": None, "collective": None,
+                                "ms_per_step_by_rank": [d["ms_per_step"]]}
+    for k in ("dwconv", "free_encode", "free_decode"):
+        assert 0.05 < r["hbm_bound_kernels"][k]["frac_of_8TBps"] < 1.0
+
+
+def test_gpus_flag_must_match_the_launch():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
