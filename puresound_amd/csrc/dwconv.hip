@@ -11,6 +11,8 @@
 // transforms.  (A register-only version re-loaded and re-transformed every element once per tap: 26 VALU per
 // output frame and 0.43-0.6 of the achievable bandwidth.)  DW_RB rows are in flight per thread to cover the
 // HBM latency at the per-CU bandwidth share.
+#include <type_traits>
+
 #include "ps_common.h"
 
 namespace ps {
@@ -19,8 +21,9 @@ constexpr int DW_ROWS = 16;
 constexpr int DW_FRAMES = 1024;  // 256 threads x 4
 constexpr int DW_MAXP = 8;
 constexpr int DW_RB = 4;          // rows staged together
-constexpr int DW_MAXHALO = 1024;  // (P-1)*dilation frames of halo the LDS image can hold
-constexpr int DW_SEG = DW_FRAMES + DW_MAXHALO;
+constexpr int DW_MAXHALO = 1024;  // (P-1)*dilation frames of halo the LDS image can hold ...
+constexpr int DW_SMALLHALO = 288;  // ... and in the small-halo build (P = 3, dilation <= 128: 21 KiB of LDS instead of
+                                   // 32, i.e. seven resident workgroups per CU instead of four)
 
 struct DwArgs {
   const float* x;
@@ -33,8 +36,9 @@ struct DwArgs {
 };
 
 // P > 0: compile-time tap count; P == 0: run-time taps.  ALIGNED: every tap offset is a multiple of 4 frames.
-template <int P, bool ALIGNED>
+template <int P, bool ALIGNED, int HALO = DW_MAXHALO>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
+  constexpr int DW_SEG = DW_FRAMES + HALO;
   __shared__ __attribute__((aligned(16))) float seg[DW_RB][DW_SEG];
   __shared__ double red[8];
   const int tid = threadIdx.x;
@@ -51,33 +55,56 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
   const int nvec = DW_FRAMES / 4 + (lpad + halo - a.left + 3) / 4 + 0;  // vectors that can be touched
   (void)halo4;
 
-  const NormScalars ns = load_norm_scalars(a.pro, n, red);
   const bool has_norm = a.pro.norm != PS_NORM_NONE;
   const bool has_prelu = a.pro.prelu != 0;
   const float slope = has_prelu ? a.pro.slope[0] : 1.f;
+  const bool slope01 = slope >= 0.f && slope <= 1.f;
 
   float fsum = 0.f, fsq = 0.f;
   const int t = t0 + tid * 4;
-  for (int r0 = 0; r0 < DW_ROWS; r0 += DW_RB) {
-    if (h0 + r0 >= a.H) break;  // uniform
-    // ---- stage DW_RB row segments: load, transform once, zero outside [0,T), write LDS ----------------
-    f32x4 v[DW_RB][2];
-    const int i1 = tid + 256;  // second vector index (halo part): only the first (nvec - 256) threads
+  const int i1 = tid + 256;  // second vector index (halo part): only the first (nvec - 256) threads
+  // The row batches are software pipelined: the loads of batch b+1 are issued before batch b is transformed, written
+  // to LDS and consumed, so a workgroup always has a batch of HBM loads in flight behind its LDS phase (without it
+  // every batch paid the full load latency between its two barriers: 4.0 TB/s).
+  f32x4 v[2][DW_RB][2];
+  auto load_batch = [&](int r0, auto q_c) {
+    constexpr int q = decltype(q_c)::value;
 #pragma unroll
     for (int r = 0; r < DW_RB; ++r) {
       const int h = h0 + r0 + r;
       const float* xr = a.x + ((size_t)n * a.H + (h < a.H ? h : a.H - 1)) * a.ldt;
       const int f0 = org + tid * 4, f1 = org + i1 * 4;
-      v[r][0] = (f0 >= 0 && f0 < a.T) ? *reinterpret_cast<const f32x4*>(xr + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
-      v[r][1] = (i1 < nvec && f1 >= 0 && f1 < a.T) ? *reinterpret_cast<const f32x4*>(xr + f1)
-                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[q][r][0] = (f0 >= 0 && f0 < a.T) ? *reinterpret_cast<const f32x4*>(xr + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[q][r][1] = (i1 < nvec && f1 >= 0 && f1 < a.T) ? *reinterpret_cast<const f32x4*>(xr + f1)
+                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  static_assert(DW_ROWS / DW_RB == 4, "four row batches, unrolled below");
+  using q0 = std::integral_constant<int, 0>;
+  using q1 = std::integral_constant<int, 1>;
+  const int nb = (a.H - h0 + DW_RB - 1) / DW_RB;  // batches that hold rows (uniform)
+  load_batch(0, q0{});
+  if (nb > 1) load_batch(DW_RB, q1{});
+  // (the reduction of the producer's partial statistics -- two barriers and an fp64 butterfly -- runs behind the first
+  //  loads instead of in front of them: it cost 11 % of the launch)
+  // per-row scale / shift of all DW_ROWS rows up front: their gamma / beta loads are in flight together (fetched per
+  // batch, each batch stalled on them between its barriers: 8-10 us of a 62 us launch)
+  float gam[DW_ROWS], bet[DW_ROWS];
+#pragma unroll
+  for (int r = 0; r < DW_ROWS; ++r) {
+    const int hc = h0 + r < a.H ? h0 + r : a.H - 1;
+    gam[r] = has_norm ? a.pro.gamma[hc] : 1.f;
+    bet[r] = has_norm ? a.pro.beta[hc] : 0.f;
+  }
+  const NormScalars ns = load_norm_scalars(a.pro, n, red);
+  auto process_batch = [&](auto r0_c, auto q_c) {
+    constexpr int r0 = decltype(r0_c)::value;
+    constexpr int qb = decltype(q_c)::value;
+    // ---- transform once, zero outside [0,T), write LDS ------------------------------------------------
 #pragma unroll
     for (int r = 0; r < DW_RB; ++r) {
-      const int h = h0 + r0 + r;
-      const int hc = h < a.H ? h : a.H - 1;
-      const float sc = has_norm ? a.pro.gamma[hc] * ns.rstd : 1.f;
-      const float sh = (has_norm ? a.pro.beta[hc] : 0.f) - ns.mean * sc;
+      const float sc = has_norm ? gam[r0 + r] * ns.rstd : 1.f;
+      const float sh = bet[r0 + r] - ns.mean * sc;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int idx = q == 0 ? tid : i1;
@@ -86,9 +113,14 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
         f32x4 u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float z = v[r][q][e] * sc + sh;
-          if (has_prelu) z = prelu(z, slope);
-          u[e] = (f + e >= 0 && f + e < a.T) ? z : 0.f;  // the conv's zero padding is applied AFTER norm+PReLU
+          float z = v[qb][r][q][e] * sc + sh;
+          // PReLU as max(z, slope z) when 0 <= slope <= 1 (two instructions instead of compare / select / multiply)
+          if (has_prelu) z = slope01 ? fmaxf(z, slope * z) : prelu(z, slope);
+          u[e] = z;
+        }
+        if (!(f >= 0 && f + 3 < a.T)) {  // edge vectors only: the conv's zero padding, applied AFTER norm + PReLU
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u[e] = (f + e >= 0 && f + e < a.T) ? u[e] : 0.f;
         }
         *reinterpret_cast<f32x4*>(&seg[r][idx * 4]) = u;
       }
@@ -124,17 +156,36 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
               for (int e = 0; e < 4; ++e) out[e] += wj * sp[j * a.dilation + e];
             }
           }
+          if (t + 3 < a.T) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (t + e < a.T) {
+            for (int e = 0; e < 4; ++e) {
               fsum += out[e];
               fsq += out[e] * out[e];
             }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (t + e < a.T) {
+                fsum += out[e];
+                fsq += out[e] * out[e];
+              }
+          }
           *reinterpret_cast<f32x4*>(a.y + ((size_t)n * a.H + h) * a.ldt + t) = out;
         }
       }
     }
     __syncthreads();  // the next batch overwrites the LDS image
+  };
+  using ic = std::integral_constant<int, 0>;
+  process_batch(ic{}, q0{});
+  if (nb > 1) {
+    if (nb > 2) load_batch(2 * DW_RB, q0{});
+    process_batch(std::integral_constant<int, DW_RB>{}, q1{});
+    if (nb > 2) {
+      if (nb > 3) load_batch(3 * DW_RB, q1{});
+      process_batch(std::integral_constant<int, 2 * DW_RB>{}, q0{});
+      if (nb > 3) process_batch(std::integral_constant<int, 3 * DW_RB>{}, q1{});
+    }
   }
   if (a.ostats) {
     double s = fsum, q = fsq;
@@ -210,7 +261,12 @@ extern "C" int ps_dwconv_f32(const float* x, const float* w, const float* b, flo
   {
     LaunchTimer timer("dwconv", (hipStream_t)stream);
     hipStream_t st = (hipStream_t)stream;
-    if (P == 3 && aligned)
+    const bool small = (P - 1) * dilation + 8 <= DW_SMALLHALO;
+    if (P == 3 && aligned && small)
+      hipLaunchKernelGGL((dwconv_kernel<3, true, DW_SMALLHALO>), grid, dim3(256), 0, st, a);
+    else if (P == 3 && small)
+      hipLaunchKernelGGL((dwconv_kernel<3, false, DW_SMALLHALO>), grid, dim3(256), 0, st, a);
+    else if (P == 3 && aligned)
       hipLaunchKernelGGL((dwconv_kernel<3, true>), grid, dim3(256), 0, st, a);
     else if (P == 3)
       hipLaunchKernelGGL((dwconv_kernel<3, false>), grid, dim3(256), 0, st, a);
