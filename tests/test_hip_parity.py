@@ -306,8 +306,11 @@ def test_attentive_stats_pooling_module_matches_oracle(PA, dev):
     out = pool(x.to(dev))
     assert out.shape == ref.shape == (3, 96, 1)
     assert rel_max(out.cpu().numpy(), ref.numpy()) < 2e-5
+    assert torch.equal(pool(x.to(dev), lengths=torch.ones(3, device=dev)), out)  # (lengths: tests/test_round2_gpu.py)
     with pytest.raises(NotImplementedError):
-        pool(x.to(dev), lengths=torch.ones(3))
+        pool(x.to(dev), return_weight=True)
+    with pytest.raises(RuntimeError):
+        pool(x.to(dev), lengths=torch.ones(3))  # a CPU tensor
     with pytest.raises(RuntimeError):
         pool.train()(x.to(dev))
 
