@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 4
+#define PS_ABI_VERSION 5
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -381,7 +381,20 @@ typedef struct ps_tcn_block {
    * 1 / 3 = ps_conv1x1_bf16_f32 with that many planes over the plane-packed weights below */
   int gemm_planes;
   const void *in_wb, *pw_wb, *out_wb;
+  /* with gemm_planes = 1 (BASELINE's "bf16" configurations): keep the block's three hidden maps -- workspace only,
+   * never visible to the caller -- as bf16 rows: written by the GEMM epilogue / the depthwise kernel, read by the next
+   * prologue; statistics, bias, accumulation and the block's input / output (the residual stream) stay fp32 */
+  int hidden_bf16;
 } ps_tcn_block;
+
+/* ps_conv1x1_bf16_f32 / ps_dwconv_f32 with bf16 activation rows (x_bf16 / y_bf16 != 0: the buffer holds
+ * [N][channels][ldt] bf16 instead of fp32; planes must be 1, the residual stays fp32 and excludes y_bf16; the depthwise
+ * form is built for P = 3).  Used inside ps_conv_tasnet_f32 for the hidden maps of a block with hidden_bf16. */
+int ps_conv1x1_bf16_io(const void* x, int x_bf16, const void* wt_planes, void* y, int y_bf16, int N, int K, int M, int T,
+                       int ldt, int planes, const ps_prologue* pro, const float* bias, const float* bias_n,
+                       const float* res, double* ostats, void* stream);
+int ps_dwconv_io(const void* x, int x_bf16, const float* w, const float* b, void* y, int y_bf16, int N, int H, int T,
+                 int ldt, int P, int dilation, int left, const ps_prologue* pro, double* ostats, void* stream);
 
 /* bytes of scratch ps_conv_tasnet_f32 needs for a batch (3 hidden maps + stats + embed bias) */
 size_t ps_conv_tasnet_workspace_bytes(int N, int C, int H, int T);

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -43,7 +43,7 @@ class TcnBlock(C.Structure):
                 ("dw_w", _vp), ("dw_b", _vp), ("dw_gamma", _vp), ("dw_beta", _vp), ("dw_slope", _vp),
                 ("pw_wt", _vp), ("pw_b", _vp), ("pw_gamma", _vp), ("pw_beta", _vp), ("pw_slope", _vp),
                 ("out_wt", _vp), ("out_b", _vp),
-                ("gemm_planes", C.c_int), ("in_wb", _vp), ("pw_wb", _vp), ("out_wb", _vp)]
+                ("gemm_planes", C.c_int), ("in_wb", _vp), ("pw_wb", _vp), ("out_wb", _vp), ("hidden_bf16", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/puresound_hip.h declares
@@ -71,6 +71,8 @@ SIGNATURES = {
     "ps_conv1x1_bf16_weight_bytes": (C.c_size_t, [C.c_int] * 3),
     "ps_conv1x1_bf16_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 6 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
     "ps_dwconv_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp]),
+    "ps_dwconv_io": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 8 + [C.POINTER(Prologue), _vp, _vp]),
+    "ps_conv1x1_bf16_io": (C.c_int, [_vp, C.c_int, _vp, _vp] + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
     "ps_attn_stats_pool_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
     "ps_attn_stats_pool_len_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
     "ps_lstm_f32": (C.c_int, [C.POINTER(LstmArgs), _vp]),
@@ -139,12 +141,12 @@ def stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def require_device(t: torch.Tensor, what: str) -> None:
+def require_device(t: torch.Tensor, what: str, allow_bf16: bool = False) -> None:
     """The product path is HIP only: refuse CPU tensors loudly instead of falling back."""
     if not t.is_cuda:
         raise RuntimeError(f"{what}: puresound_amd runs on a ROCm device only (got a {t.device} tensor); "
                            f"there is no CPU fallback")
-    if t.dtype != torch.float32:
+    if t.dtype != torch.float32 and not (allow_bf16 and t.dtype == torch.bfloat16):
         raise RuntimeError(f"{what}: fp32 tensors only (got {t.dtype})")
 
 

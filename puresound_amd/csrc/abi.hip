@@ -178,16 +178,19 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
     bias_n = w.bias_n;
   }
   // the three GEMMs: exact fp32 MFMA, or the bf16 pipe with 1 / 3 operand planes
-  auto gemm = [&](const float* x, const float* wt, const void* wb, float* y, int K, int M, const ps_prologue* pro,
-                  const float* bias, const float* bn, const float* res, double* st) {
+  // hidden_bf16 (with gemm_planes = 1): y1, y2, y3 -- which never leave this workspace -- are bf16 rows; the block's
+  // input and output (the residual stream) stay fp32
+  const int hb = (b.hidden_bf16 && b.gemm_planes == 1) ? 1 : 0;
+  auto gemm = [&](const float* x, int xb, const float* wt, const void* wb, float* y, int yb, int K, int M,
+                  const ps_prologue* pro, const float* bias, const float* bn, const float* res, double* st) {
     if (b.gemm_planes == 0) return ps_conv1x1_f32(x, wt, y, N, K, M, T, ldt, pro, bias, bn, res, st, stream);
-    return ps_conv1x1_bf16_f32(x, wb, y, N, K, M, T, ldt, b.gemm_planes, pro, bias, bn, res, st, stream);
+    return ps_conv1x1_bf16_io(x, xb, wb, y, yb, N, K, M, T, ldt, b.gemm_planes, pro, bias, bn, res, st, stream);
   };
   if (b.gemm_planes != 0 && (!b.in_wb || !b.pw_wb || !b.out_wb)) {
     set_error("ps_conv_tasnet_f32: gemm_planes=%d needs the plane-packed weights in_wb / pw_wb / out_wb", b.gemm_planes);
     return PS_E_INVALID;
   }
-  rc = gemm(x_in, b.in_wt, b.in_wb, w.y1, b.C, b.H, nullptr, nullptr, bias_n, nullptr,
+  rc = gemm(x_in, 0, b.in_wt, b.in_wb, w.y1, hb, b.C, b.H, nullptr, nullptr, bias_n, nullptr,
             b.in_norm == PS_NORM_GLOBAL ? w.s1 : nullptr);
   if (rc) return rc;
 
@@ -203,8 +206,8 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
   p1.beta = b.in_beta;
   p1.slope = b.in_slope;
   const int left = b.causal ? (b.P - 1) * b.dilation : ((b.P - 1) / 2) * b.dilation;
-  rc = ps_dwconv_f32(w.y1, b.dw_w, b.dw_b, w.y2, N, b.H, T, ldt, b.P, b.dilation, left, &p1,
-                     b.dw_norm == PS_NORM_GLOBAL ? w.s2 : nullptr, stream);
+  rc = ps_dwconv_io(w.y1, hb, b.dw_w, b.dw_b, w.y2, hb, N, b.H, T, ldt, b.P, b.dilation, left, &p1,
+                    b.dw_norm == PS_NORM_GLOBAL ? w.s2 : nullptr, stream);
   if (rc) return rc;
 
   // 3) pointwise: prologue = depthwise norm + PReLU; stats of y3
@@ -218,7 +221,7 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
   p2.gamma = b.dw_gamma;
   p2.beta = b.dw_beta;
   p2.slope = b.dw_slope;
-  rc = gemm(w.y2, b.pw_wt, b.pw_wb, w.y3, b.H, b.H, &p2, b.pw_b, nullptr, nullptr,
+  rc = gemm(w.y2, hb, b.pw_wt, b.pw_wb, w.y3, hb, b.H, b.H, &p2, b.pw_b, nullptr, nullptr,
             b.pw_norm == PS_NORM_GLOBAL ? w.s3 : nullptr);
   if (rc) return rc;
 
@@ -233,7 +236,7 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
   p3.gamma = b.pw_gamma;
   p3.beta = b.pw_beta;
   p3.slope = b.pw_slope;
-  return gemm(w.y3, b.out_wt, b.out_wb, x_out, b.H, b.C, &p3, b.out_b, nullptr, x_in, nullptr);
+  return gemm(w.y3, hb, b.out_wt, b.out_wb, x_out, 0, b.H, b.C, &p3, b.out_b, nullptr, x_in, nullptr);
 }
 
 extern "C" int ps_conv_tasnet_f32(const ps_tcn_block* blocks, int n_blocks, const float* x_in, float* x_out,

@@ -48,6 +48,7 @@ struct BfArgs {
   int K, M, T, ldt, ksteps, tiles_t, tiles_m, N;
   unsigned long long* stamps;  // ps_debug_buffer(): 6 x u64 per workgroup (s_memtime buckets), diagnostics only
   int ablate;  // profiling only (ps_debug_flags bits 24..26): 1 = no MFMA, 2 = no epilogue, 4 = no activation split
+  int x_bf16, y_bf16;  // the rows of x / y are bf16 in HBM (PLANES = 1 only; bias, residual, statistics stay fp32 / fp64)
 };
 
 // TT = frames per workgroup tile: 128 (2 x 2 waves of 128 x 64) or 32 (4 x 1 waves of 64 x 32 -- the small-grid
@@ -61,8 +62,10 @@ struct BfLds {
   static constexpr int TOTAL = 2 * SLOT + 2 * KTAB * 4 + 64;  // PLANES = 3: 76 KiB -> two workgroups per CU
 };
 
-template <int PLANES, bool TR, bool STATS, bool RES, int TT = XB_T>
+template <int PLANES, bool TR, bool STATS, bool RES, int TT = XB_T, bool XB = false, bool YB = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
+  static_assert(!(XB || YB) || PLANES == 1, "bf16 rows go with bf16 products");
+  constexpr int XE = XB ? 2 : 4, YE = YB ? 2 : 4;
   using L = BfLds<PLANES, TT>;
   constexpr bool NARROW = TT != XB_T;
   constexpr int MI = NARROW ? 2 : 4, TI = NARROW ? 1 : 2;  // 32 x 32 MFMA tiles per wave
@@ -114,14 +117,20 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
   // activation loads go through a buffer descriptor over this utterance's [K][ldt] slab: rows k >= K and K-steps
   // past the end read 0.0f, so the loads carry no predicate (a predicated load made hipcc wait on each one)
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x) + (size_t)n * a.K * a.ldt, 0, a.K * a.ldt * 4, 0x00020000);
-  const int xb_voff = (8 * bh * a.ldt + t0 + bt) * 4;
+      reinterpret_cast<unsigned char*>(const_cast<float*>(a.x)) + (size_t)n * a.K * a.ldt * XE, 0, a.K * a.ldt * XE,
+      0x00020000);
+  const int xb_voff = (8 * bh * a.ldt + t0 + bt) * XE;
   auto load_b = [&](int ks, auto q_c) {
     constexpr int q = decltype(q_c)::value;
-    const int soff = ks * XB_K * a.ldt * 4;
+    const int soff = ks * XB_K * a.ldt * XE;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      breg[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, xb_voff, soff + j * a.ldt * 4, 0));
+    for (int j = 0; j < 8; ++j) {
+      if constexpr (XB)
+        breg[q][j] = __builtin_bit_cast(
+            float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xr, xb_voff, soff + j * a.ldt * XE, 0) << 16);
+      else
+        breg[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, xb_voff, soff + j * a.ldt * 4, 0));
+    }
     (void)b_active;  // idle threads load in-range duplicates (tid % TT) and skip the LDS write
   };
   auto store_step = [&](int ks, int slot, auto q_c) {
@@ -265,10 +274,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
   if (a.ablate & 2) return;
   float fsum = 0.f, fsq = 0.f;
   const int slab = a.M * a.ldt * 4;
-  const __amdgpu_buffer_rsrc_t yr =
-      __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)n * a.M * a.ldt, 0, slab, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<unsigned char*>(a.y) + (size_t)n * a.M * a.ldt * YE, 0, a.M * a.ldt * YE, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(RES ? a.res : a.y) + (size_t)n * a.M * a.ldt, 0, slab, 0x00020000);
+      const_cast<float*>(RES ? a.res : a.x) + (size_t)n * a.M * a.ldt, 0, RES ? slab : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.bias ? a.bias : a.x), 0, a.bias ? a.M * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t bnr = __builtin_amdgcn_make_buffer_rsrc(
@@ -306,8 +315,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
           fsq += vm * vm;
         }
         if constexpr (RES) v += rv[ti][r];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, lane_off,
-                                              tile_off + rc * a.ldt * 4 + ti * 128, 0);
+        if constexpr (YB)
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), yr, lane_off >> 1,
+                                                (tile_off + rc * a.ldt * 4 + ti * 128) >> 1, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, lane_off,
+                                                tile_off + rc * a.ldt * 4 + ti * 128, 0);
       }
     }
   }
@@ -1344,7 +1357,7 @@ static int bf16_cus() {
   return cus;
 }
 
-template <int PLANES>
+template <int PLANES, bool XB = false, bool YB = false>
 static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
   const bool stats = a.ostats != nullptr, res = a.res != nullptr;
   // The ping-pong kernel needs enough supertiles to give every CU work, K-steps to pipeline over, and a bounded
@@ -1362,7 +1375,7 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
   const long long ntiles_all = (long long)a.tiles_t * a.tiles_m * N;
   const int Gs = (int)(ntiles_all < cus ? ntiles_all : cus);
   const long long per_wg_s = (ntiles_all + Gs - 1) / Gs, per_utt_s = (long long)a.tiles_t * a.tiles_m;
-  const bool solo = (g_debug_flags & (1 << 30)) && a.ksteps >= 4 && a.ksteps % 2 == 0 && ntiles_all >= cus &&
+  const bool solo = !XB && !YB && (g_debug_flags & (1 << 30)) && a.ksteps >= 4 && a.ksteps % 2 == 0 && ntiles_all >= cus &&
                     (per_wg_s + per_utt_s - 2) / per_utt_s + 1 <= PP_MAXU;
   if (solo) {
 #define PS_SOLO(TRV, STV, RSV) \
@@ -1384,7 +1397,7 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
   const bool plain_tr = !a.pro.pre_relu && !a.pro.post_tanh;
   if (pp && plain_tr && !(g_debug_flags & 32)) {
 #define PS_IL(TRV, STV, RSV) \
-  hipLaunchKernelGGL((conv1x1_bf16_il_kernel<PLANES, TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)
+  hipLaunchKernelGGL((conv1x1_bf16_il_kernel<PLANES, TRV, STV, RSV, XB, (YB && !RSV)>), dim3(G, 1), dim3(512), 0, stream, a)
     if (tr) {
       if (stats) PS_IL(true, true, false);
       else if (res) PS_IL(true, false, true);
@@ -1397,7 +1410,7 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
 #undef PS_IL
     return;
   }
-  if (pp) {
+  if (pp && !XB && !YB) {  // (bf16 rows: the interleaved kernel or the simple one)
 #define PS_PP(TRV, STV, RSV) \
   hipLaunchKernelGGL((conv1x1_bf16_pp_kernel<PLANES, TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)
     if (tr) {
@@ -1416,12 +1429,12 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
   // the workgroups, a quarter of the staging and MFMA work each (ps_debug_flags bit 29 keeps the wide tile)
   const bool narrow = 2 * (long long)a.tiles_t * a.tiles_m * N <= cus && !(g_debug_flags & (1 << 29));
   dim3 grid(narrow ? a.tiles_t * 4 : a.tiles_t, a.tiles_m, N);
-#define PS_BF(TRV, STV, RSV)                                                                                        \
-  do {                                                                                                              \
-    if (narrow)                                                                                                     \
-      hipLaunchKernelGGL((conv1x1_bf16_kernel<PLANES, TRV, STV, RSV, 32>), grid, dim3(256), 0, stream, a);          \
-    else                                                                                                            \
-      hipLaunchKernelGGL((conv1x1_bf16_kernel<PLANES, TRV, STV, RSV, XB_T>), grid, dim3(256), 0, stream, a);        \
+#define PS_BF(TRV, STV, RSV)                                                                                          \
+  do {                                                                                                                \
+    if (narrow)                                                                                                       \
+      hipLaunchKernelGGL((conv1x1_bf16_kernel<PLANES, TRV, STV, RSV, 32, XB, YB>), grid, dim3(256), 0, stream, a);    \
+    else                                                                                                              \
+      hipLaunchKernelGGL((conv1x1_bf16_kernel<PLANES, TRV, STV, RSV, XB_T, XB, YB>), grid, dim3(256), 0, stream, a);  \
   } while (0)
   if (tr) {
     if (stats) PS_BF(true, true, false);
@@ -1448,6 +1461,22 @@ extern "C" size_t ps_conv1x1_bf16_weight_bytes(int M, int K, int planes) {
 extern "C" int ps_conv1x1_bf16_f32(const float* x, const void* wt_planes, float* y, int N, int K, int M, int T, int ldt,
                                    int planes, const ps_prologue* pro, const float* bias, const float* bias_n,
                                    const float* res, double* ostats, void* stream) {
+  return ps_conv1x1_bf16_io(x, 0, wt_planes, y, 0, N, K, M, T, ldt, planes, pro, bias, bias_n, res, ostats, stream);
+}
+
+extern "C" int ps_conv1x1_bf16_io(const void* x_any, int x_bf16, const void* wt_planes, void* y_any, int y_bf16, int N,
+                                  int K, int M, int T, int ldt, int planes, const ps_prologue* pro, const float* bias,
+                                  const float* bias_n, const float* res, double* ostats, void* stream) {
+  const float* x = (const float*)x_any;
+  float* y = (float*)y_any;
+  if ((x_bf16 || y_bf16) && planes != 1) {
+    set_error("ps_conv1x1_bf16_io: bf16 activation rows go with planes = 1 (got %d)", planes);
+    return PS_E_UNSUPPORTED;
+  }
+  if (y_bf16 && res) {
+    set_error("ps_conv1x1_bf16_io: a bf16 output cannot take the fp32 residual");
+    return PS_E_UNSUPPORTED;
+  }
   if (!x || !wt_planes || !y || N <= 0 || K <= 0 || M <= 0 || T <= 0 || N > 65535) {
     set_error("ps_conv1x1_bf16_f32: null pointer or non-positive size (N=%d K=%d M=%d T=%d)", N, K, M, T);
     return PS_E_INVALID;
@@ -1503,12 +1532,21 @@ extern "C" int ps_conv1x1_bf16_f32(const float* x, const void* wt_planes, float*
   a.N = N;
   a.ablate = (g_debug_flags >> 24) & 15;
   a.stamps = (unsigned long long*)g_debug_buffer;
+  a.x_bf16 = x_bf16 != 0;
+  a.y_bf16 = y_bf16 != 0;
   {
     LaunchTimer timer("conv1x1_bf16", (hipStream_t)stream);
-    if (planes == 1)
-      bf16_launch<1>(a, N, tr, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (planes == 3)
+      bf16_launch<3>(a, N, tr, st);
+    else if (a.x_bf16 && a.y_bf16)
+      bf16_launch<1, true, true>(a, N, tr, st);
+    else if (a.x_bf16)
+      bf16_launch<1, true, false>(a, N, tr, st);
+    else if (a.y_bf16)
+      bf16_launch<1, false, true>(a, N, tr, st);
     else
-      bf16_launch<3>(a, N, tr, (hipStream_t)stream);
+      bf16_launch<1>(a, N, tr, st);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -36,7 +36,24 @@ struct DwArgs {
 };
 
 // P > 0: compile-time tap count; P == 0: run-time taps.  ALIGNED: every tap offset is a multiple of 4 frames.
-template <int P, bool ALIGNED, int HALO = DW_MAXHALO>
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+template <bool B16>
+__device__ __forceinline__ f32x4 dw_load4(const void* base, size_t elem) {
+  if constexpr (B16) {
+    const u16x4 h = *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(base) + elem);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, (unsigned)h[e] << 16);
+    return v;
+  } else {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + elem);
+  }
+}
+
+// XB / YB: the rows of x / y are bf16 in HBM (hidden maps of a TCN block in the "bf16" arithmetic); LDS image,
+// taps, bias and statistics stay fp32.
+template <int P, bool ALIGNED, int HALO = DW_MAXHALO, bool XB = false, bool YB = false>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
   constexpr int DW_SEG = DW_FRAMES + HALO;
   __shared__ __attribute__((aligned(16))) float seg[DW_RB][DW_SEG];
@@ -72,11 +89,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
 #pragma unroll
     for (int r = 0; r < DW_RB; ++r) {
       const int h = h0 + r0 + r;
-      const float* xr = a.x + ((size_t)n * a.H + (h < a.H ? h : a.H - 1)) * a.ldt;
+      const size_t row = ((size_t)n * a.H + (h < a.H ? h : a.H - 1)) * a.ldt;
       const int f0 = org + tid * 4, f1 = org + i1 * 4;
-      v[q][r][0] = (f0 >= 0 && f0 < a.T) ? *reinterpret_cast<const f32x4*>(xr + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
-      v[q][r][1] = (i1 < nvec && f1 >= 0 && f1 < a.T) ? *reinterpret_cast<const f32x4*>(xr + f1)
-                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[q][r][0] = (f0 >= 0 && f0 < a.T) ? dw_load4<XB>(a.x, row + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[q][r][1] = (i1 < nvec && f1 >= 0 && f1 < a.T) ? dw_load4<XB>(a.x, row + f1) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   static_assert(DW_ROWS / DW_RB == 4, "four row batches, unrolled below");
@@ -170,7 +186,14 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
                 fsq += out[e] * out[e];
               }
           }
-          *reinterpret_cast<f32x4*>(a.y + ((size_t)n * a.H + h) * a.ldt + t) = out;
+          if constexpr (YB) {
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __builtin_bit_cast(unsigned short, (__bf16)out[e]);
+            *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(a.y) + ((size_t)n * a.H + h) * a.ldt + t) = o;
+          } else {
+            *reinterpret_cast<f32x4*>(a.y + ((size_t)n * a.H + h) * a.ldt + t) = out;
+          }
         }
       }
     }
@@ -209,7 +232,15 @@ extern "C" int ps_dwconv_stats_parts(int H, int T) {
 extern "C" int ps_dwconv_f32(const float* x, const float* w, const float* b, float* y, int N, int H, int T,
                              int ldt, int P, int dilation, int left, const ps_prologue* pro, double* ostats,
                              void* stream) {
+  return ps_dwconv_io(x, 0, w, b, y, 0, N, H, T, ldt, P, dilation, left, pro, ostats, stream);
+}
+
+extern "C" int ps_dwconv_io(const void* x_any, int x_bf16, const float* w, const float* b, void* y_any, int y_bf16, int N,
+                            int H, int T, int ldt, int P, int dilation, int left, const ps_prologue* pro, double* ostats,
+                            void* stream) {
   using namespace ps;
+  const float* x = (const float*)x_any;
+  float* y = (float*)y_any;
   if (!x || !w || !y || N <= 0 || H <= 0 || T <= 0 || P <= 0 || P > DW_MAXP || dilation <= 0 || left < 0) {
     set_error("ps_dwconv_f32: bad argument (N=%d H=%d T=%d P=%d dilation=%d left=%d)", N, H, T, P, dilation, left);
     return PS_E_INVALID;
@@ -262,7 +293,23 @@ extern "C" int ps_dwconv_f32(const float* x, const float* w, const float* b, flo
     LaunchTimer timer("dwconv", (hipStream_t)stream);
     hipStream_t st = (hipStream_t)stream;
     const bool small = (P - 1) * dilation + 8 <= DW_SMALLHALO;
-    if (P == 3 && aligned && small)
+    if (x_bf16 || y_bf16) {
+      if (P != 3 || !small) {
+        set_error("ps_dwconv_io: bf16 rows are built for P = 3 with (P-1)*dilation <= %d", DW_SMALLHALO - 8);
+        return PS_E_UNSUPPORTED;
+      }
+#define PS_DW(AL, XBV, YBV) hipLaunchKernelGGL((dwconv_kernel<3, AL, DW_SMALLHALO, XBV, YBV>), grid, dim3(256), 0, st, a)
+      if (aligned) {
+        if (x_bf16 && y_bf16) PS_DW(true, true, true);
+        else if (x_bf16) PS_DW(true, true, false);
+        else PS_DW(true, false, true);
+      } else {
+        if (x_bf16 && y_bf16) PS_DW(false, true, true);
+        else if (x_bf16) PS_DW(false, true, false);
+        else PS_DW(false, false, true);
+      }
+#undef PS_DW
+    } else if (P == 3 && aligned && small)
       hipLaunchKernelGGL((dwconv_kernel<3, true, DW_SMALLHALO>), grid, dim3(256), 0, st, a);
     else if (P == 3 && small)
       hipLaunchKernelGGL((dwconv_kernel<3, false, DW_SMALLHALO>), grid, dim3(256), 0, st, a);

@@ -194,36 +194,41 @@ def pack_wt_bf16(w: torch.Tensor, planes: int) -> torch.Tensor:
 def conv1x1_bf16(x: torch.Tensor, t: int, wt_planes: torch.Tensor, m: int, pro: Optional[Prologue] = None,
                  bias: Optional[torch.Tensor] = None, bias_n: Optional[torch.Tensor] = None,
                  res: Optional[torch.Tensor] = None, want_stats: bool = False,
-                 out: Optional[torch.Tensor] = None) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """ps_conv1x1_f32's contract on the bf16 matrix pipe; the plane count is read off wt_planes (pack_wt_bf16)."""
-    require_device(x, "conv1x1_bf16")
+                 out: Optional[torch.Tensor] = None,
+                 out_dtype: torch.dtype = torch.float32) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """ps_conv1x1_f32's contract on the bf16 matrix pipe; the plane count is read off wt_planes (pack_wt_bf16).
+    A torch.bfloat16 `x` / `out` (or out_dtype) selects bf16 activation rows (ps_conv1x1_bf16_io, planes = 1)."""
+    require_device(x, "conv1x1_bf16", allow_bf16=True)
     n, k, ldt = x.shape
     planes = wt_planes.shape[2]
-    y = out if out is not None else torch.empty(n, m, ldt, dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty(n, m, ldt, dtype=out_dtype, device=x.device)
     stats = None
     if want_stats:
         parts = lib().ps_conv1x1_stats_parts(m, t)
         stats = torch.zeros(n, parts, 2, dtype=torch.float64, device=x.device)
-    check(lib().ps_conv1x1_bf16_f32(ptr(x), ptr(wt_planes), ptr(y), n, k, m, t, ldt, planes,
-                                    C.byref(pro) if pro is not None else None, ptr(bias), ptr(bias_n), ptr(res),
-                                    ptr(stats), stream_ptr(x.device)), "ps_conv1x1_bf16_f32")
+    check(lib().ps_conv1x1_bf16_io(ptr(x), int(x.dtype == torch.bfloat16), ptr(wt_planes), ptr(y),
+                                   int(y.dtype == torch.bfloat16), n, k, m, t, ldt, planes,
+                                   C.byref(pro) if pro is not None else None, ptr(bias), ptr(bias_n), ptr(res),
+                                   ptr(stats), stream_ptr(x.device)), "ps_conv1x1_bf16_io")
     return y, stats
 
 
 def dwconv(x: torch.Tensor, t: int, w: torch.Tensor, b: Optional[torch.Tensor], dilation: int, left: int,
-           pro: Optional[Prologue] = None, want_stats: bool = False) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """x padded [N,H,ldt], w [H,1,P] -> y padded [N,H,ldt] (+ partial stats)."""
-    require_device(x, "dwconv")
+           pro: Optional[Prologue] = None, want_stats: bool = False,
+           out_dtype: Optional[torch.dtype] = None) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """x padded [N,H,ldt] (fp32 or bf16 rows), w [H,1,P] -> y padded [N,H,ldt] (+ partial stats)."""
+    require_device(x, "dwconv", allow_bf16=True)
     n, h, ldt = x.shape
     p = w.shape[-1]
-    y = torch.zeros_like(x)
+    y = torch.zeros(n, h, ldt, dtype=out_dtype or x.dtype, device=x.device)
     stats = None
     if want_stats:
         parts = lib().ps_dwconv_stats_parts(h, t)
         stats = torch.zeros(n, parts, 2, dtype=torch.float64, device=x.device)
-    check(lib().ps_dwconv_f32(ptr(x), ptr(w), ptr(b), ptr(y), n, h, t, ldt, p, dilation, left,
-                              C.byref(pro) if pro is not None else None, ptr(stats), stream_ptr(x.device)),
-          "ps_dwconv_f32")
+    check(lib().ps_dwconv_io(ptr(x), int(x.dtype == torch.bfloat16), ptr(w), ptr(b), ptr(y),
+                             int(y.dtype == torch.bfloat16), n, h, t, ldt, p, dilation, left,
+                             C.byref(pro) if pro is not None else None, ptr(stats), stream_ptr(x.device)),
+          "ps_dwconv_io")
     return y, stats
 
 

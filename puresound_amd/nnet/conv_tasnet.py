@@ -78,12 +78,16 @@ class TCN(_PlanCache, nn.Module):
     #: bit-identical whatever batch it is part of) or "bf16" (operands rounded to bf16: what BASELINE.json names for its
     #: bf16 configurations; not an fp32 result)
     gemm_precision = "bf16x3"
+    #: with gemm_precision "bf16": keep the block's hidden maps (y1, y2, y3 inside the fused driver's workspace) as
+    #: bf16 rows -- BASELINE's "bf16" configurations name bf16 storage with fp32 accumulation.  False: fp32 rows.
+    hidden_bf16 = True
 
     def plan(self, device: torch.device) -> dict:
         planes = GEMM_PLANES[self.gemm_precision]
         if max(self.in_channels, self.hid_channels) > 512:
             planes = 0  # ps_conv1x1_bf16_f32 keeps prologue tables for up to 512 input channels: wider blocks run fp32
-        sig = (_param_signature(self), str(device), planes)
+        hb = bool(self.hidden_bf16) and planes == 1 and self.kernel == 3 and 2 * self.dilation + 8 <= 288
+        sig = (_param_signature(self), str(device), planes, hb)
         if self._plan is not None and self._plan_sig == sig:
             return self._plan
         if self.training and self.dconv[1].p > 0:
@@ -124,6 +128,7 @@ class TCN(_PlanCache, nn.Module):
         b.in_norm, b.dw_norm, b.pw_norm = [kinds[k] if fused else 0 for k in ("in", "dw", "pw")]
         b.E = self.emb_dim
         b.gemm_planes = planes
+        b.hidden_bf16 = int(hb)
         if planes:
             t["in_wb"] = hip.pack_wt_bf16(w_in[:, :c, 0], planes)
             t["pw_wb"] = hip.pack_wt_bf16(dsc.pointwise[0].weight.detach().to(**f32), planes)

@@ -251,3 +251,91 @@ def test_mask_functions_and_magphase_on_the_device(PA, dev, golden_dir):
         assert rel_max(got[..., 0], want[..., 0]) < TOL
         big = want[..., 0] > 1e-3 * want[..., 0].max()
         assert np.abs(np.exp(1j * got[..., 1]) - np.exp(1j * want[..., 1]))[big].max() < 1e-3
+
+
+# ---- bf16 activation rows (BASELINE "bf16" configurations: bf16 storage, fp32 accumulation) ---------------------------
+@pytest.mark.parametrize("flags", [0, 1 << 28, 1 << 27])
+@pytest.mark.parametrize("n,k,m,t,mode,xb,yb", [(8, 512, 256, 3999, "stats", False, True),
+                                                (8, 256, 256, 3999, "norm_stats", True, True),
+                                                (8, 256, 512, 3999, "norm_res", True, False),
+                                                (3, 256, 256, 500, "norm_stats", True, True),
+                                                (2, 64, 300, 257, "plain", True, True)])
+def test_conv1x1_bf16_rows_equal_the_fp32_row_kernel_on_rounded_data(dev, flags, n, k, m, t, mode, xb, yb):
+    """ps_conv1x1_bf16_io with bf16 x / y rows against the same kernel on fp32 rows holding the bf16-rounded values:
+    the accumulation is the same instruction stream, so the fp32 result rounded to bf16 is reproduced bit for bit and
+    the statistics (taken from the fp32 values) agree."""
+    from puresound_amd import hip as H, _abi
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand(n, k, t, generator=g) * 2 - 0.8).bfloat16().float()
+    w, b = (torch.rand(m, k, generator=g) - 0.5) * 0.4, torch.rand(m, generator=g) - 0.5
+    gamma, beta, slope = torch.rand(k, generator=g) + 0.5, (torch.rand(k, generator=g) - 0.5) * 0.4, torch.tensor([0.2])
+    pro, keep = None, None
+    if mode.startswith("norm"):
+        stats = torch.stack([x.double().sum((1, 2)), (x.double() ** 2).sum((1, 2))], -1).reshape(n, 1, 2).to(dev)
+        keep = (stats, gamma.to(dev), beta.to(dev), slope.to(dev))
+        pro = H.make_prologue(_abi.PS_NORM_GLOBAL, True, keep[0], k * t, 1e-8, keep[1], keep[2], keep[3])
+    res = H.pad_rows((torch.rand(n, m, t, generator=g) - 0.5).to(dev)) if mode == "norm_res" else None
+    want = mode in ("norm_stats", "stats")
+    wb = H.pack_wt_bf16(w.to(dev), 1)
+    xp = H.pad_rows(x.to(dev))
+    old = _abi.lib().ps_debug_flags(flags)
+    try:
+        y_ref, st_ref = H.conv1x1_bf16(xp, t, wb, m, pro, b.to(dev), None, res, want_stats=want)
+        y, st = H.conv1x1_bf16(xp.bfloat16() if xb else xp, t, wb, m, pro, b.to(dev), None, res, want_stats=want,
+                               out_dtype=torch.bfloat16 if yb else torch.float32)
+        torch.cuda.synchronize()
+    finally:
+        _abi.lib().ps_debug_flags(old)
+    assert y.dtype == (torch.bfloat16 if yb else torch.float32)
+    want_y = y_ref[..., :t].bfloat16() if yb else y_ref[..., :t]
+    assert torch.equal(y[..., :t], want_y)
+    if want:
+        np.testing.assert_allclose(st.sum(1).cpu().numpy(), st_ref.sum(1).cpu().numpy(), rtol=1e-9)
+
+
+@pytest.mark.parametrize("dil,causal", [(1, False), (2, True), (8, False), (128, False), (128, True)])
+def test_dwconv_bf16_rows(dev, dil, causal):
+    from puresound_amd import hip as H, _abi
+    g = torch.Generator().manual_seed(9)
+    n, h, t = 3, 40, 1500
+    x = (torch.rand(n, h, t, generator=g) * 2 - 1).bfloat16().float()
+    w, b = torch.rand(h, 1, 3, generator=g) - 0.5, torch.rand(h, generator=g) - 0.5
+    gamma, beta, slope = torch.rand(h, generator=g) + 0.5, (torch.rand(h, generator=g) - 0.5) * 0.4, torch.tensor([0.3])
+    stats = torch.stack([x.double().sum((1, 2)), (x.double() ** 2).sum((1, 2))], -1).reshape(n, 1, 2).to(dev)
+    keep = (stats, gamma.to(dev), beta.to(dev), slope.to(dev))
+    pro = H.make_prologue(_abi.PS_NORM_GLOBAL, True, keep[0], h * t, 1e-8, keep[1], keep[2], keep[3])
+    left = 2 * dil if causal else dil
+    xp = H.pad_rows(x.to(dev))
+    y_ref, st_ref = H.dwconv(xp, t, w.to(dev), b.to(dev), dil, left, pro, True)
+    for xb, yb in ((True, True), (True, False), (False, True)):
+        y, st = H.dwconv(xp.bfloat16() if xb else xp, t, w.to(dev), b.to(dev), dil, left, pro, True,
+                         out_dtype=torch.bfloat16 if yb else torch.float32)
+        # (the instantiations may contract their multiply-adds differently: equal to one fp32 rounding, i.e. the bf16
+        #  results differ in at most the last bit of a few elements)
+        if yb:
+            diff = (y[..., :t].float() - y_ref[..., :t].bfloat16().float()).abs()
+            assert float(diff.max()) <= 2.0 ** -7 * float(y_ref.abs().max()), (xb, yb)
+            assert float((diff > 0).float().mean()) < 1e-2, (xb, yb)
+        else:
+            assert torch.allclose(y[..., :t], y_ref[..., :t], rtol=1e-6, atol=1e-6), (xb, yb)
+        np.testing.assert_allclose(st.sum(1).cpu().numpy(), st_ref.sum(1).cpu().numpy(), rtol=1e-6)
+
+
+def test_bf16_hidden_maps_stay_inside_the_bf16_acceptance(PA, dev):
+    """Config 3 in the "bf16" arithmetic with the TCN blocks' hidden maps stored as bf16 rows (the default of that
+    mode) against fp32 rows: both inside the 3e-2 l2-rel acceptance against the fp32 oracle, and close to each other."""
+    name = "cfg3_short"
+    model, sd = _build(PA, name, dev)
+    model.masker.set_gemm_precision("bf16")
+    c = cases.CASES[name]
+    noisy, enroll = det_wave(c["seed"], 4, 16000), det_wave(c["seed"] + 1, 4, 12000)
+    ref = O.inference(noisy, sd, cases.oracle_cfg(name), enroll)
+    outs = {}
+    for hb in (True, False):
+        for m in model.masker.modules():
+            if hasattr(m, "hidden_bf16"):
+                m.hidden_bf16 = hb
+        outs[hb] = model.inference(noisy.to(dev), enroll.to(dev)).cpu().numpy()
+        assert _l2rel(outs[hb], ref.numpy()) < 3e-2, hb
+    assert not np.array_equal(outs[True], outs[False])
+    assert _l2rel(outs[True], outs[False]) < 2e-2
