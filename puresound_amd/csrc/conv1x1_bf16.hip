@@ -49,6 +49,7 @@ struct BfArgs {
   unsigned long long* stamps;  // ps_debug_buffer(): 6 x u64 per workgroup (s_memtime buckets), diagnostics only
   int ablate;  // profiling only (ps_debug_flags bits 24..26): 1 = no MFMA, 2 = no epilogue, 4 = no activation split
   int x_bf16, y_bf16;  // the rows of x / y are bf16 in HBM (PLANES = 1 only; bias, residual, statistics stay fp32 / fp64)
+  int delay, groups;   // interleaved kernel: start offset (cycles) between the `groups` phases of workgroups
 };
 
 // TT = frames per workgroup tile: 128 (2 x 2 waves of 128 x 64) or 32 (4 x 1 waves of 64 x 32 -- the small-grid
@@ -1396,6 +1397,12 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
   // scale / shift + PReLU only.
   const bool plain_tr = !a.pro.pre_relu && !a.pro.post_tanh;
   if (pp && plain_tr && !(g_debug_flags & 32)) {
+    // out_conv at a full batch: every CU reaches a tile's drain (128 KiB of residual in, 128 KiB out per half) at the
+    // same time and the drains run at what HBM gives the whole chip at once (39 k cycles); four phases of workgroups
+    // 16 k cycles apart shorten them by more than the offset costs at the end of the launch (248 -> 221 us at 32
+    // utterances; the in / pointwise drains are issue-bound and gain nothing)
+    const_cast<BfArgs&>(a).delay = (PLANES == 3 && res && per_wg >= 4) ? 16000 : 0;
+    const_cast<BfArgs&>(a).groups = 4;
 #define PS_IL(TRV, STV, RSV) \
   hipLaunchKernelGGL((conv1x1_bf16_il_kernel<PLANES, TRV, STV, RSV, XB, (YB && !RSV)>), dim3(G, 1), dim3(512), 0, stream, a)
     if (tr) {
