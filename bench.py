@@ -25,12 +25,14 @@ import torch  # noqa: E402
 B_PER_GPU, L, SR = 32, 64000, 16000
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, dense bf16 matrix peak; the 3-way split spends 6 bf16 products per fp32 one
-SPLIT_PRODUCTS = 6
+SPLIT_PRODUCTS = {"bf16x3": 6, "fp16x2": 3, "bf16": 1}  # 16-bit MFMA products per fp32 multiply-add
+HBM_PEAK_GBPS = 8000.0  # same guide: HBM3E, ~8 TB/s
 # roofline.traffic (HBM bytes per launch of the dominant kernel) cannot be collected inside this run -- PMC counters
 # need their own rocprofv3 passes -- so it is READ from the summary of those passes committed under profiles/
 # (tools/pmc_summary.py; same command line as this benchmark, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
 # gfx950) and labelled with the file it came from.  It never enters `frac`.
-PMC_FILES = {"bf16x3": "profiles/r02_pmc_hbm_traffic_bf16x3.json", "fp32": "profiles/r02_pmc_hbm_traffic_fp32.json"}
+PMC_FILES = {"fp16x2": "profiles/r02_pmc_hbm_traffic_fp16x2.json", "bf16x3": "profiles/r02_pmc_hbm_traffic_bf16x3.json",
+             "fp32": "profiles/r02_pmc_hbm_traffic_fp32.json"}
 
 
 def pmc_traffic(gemm, prefix):
@@ -131,12 +133,15 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="multi-GPU: uneven shards (rank r owns 32 - r utterances) through "
                          "puresound_amd.batch_shard.sharded_inference's ragged gather instead of equal shards")
-    ap.add_argument("--gemm", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
-                    help="arithmetic of the 1x1-conv GEMMs.  bf16x3 (default): every fp32 operand split into three "
-                         "bf16 terms, six products on the bf16 MFMA pipe, fp32 accumulation -- the result carries "
-                         "the same error against the reference as the exact fp32 MFMA path (9.8e-7 vs 1.13e-6 "
-                         "max-rel on the config-2 golden vector; tests/test_hip_parity.py).  fp32: v_mfma_f32_* on "
-                         "fp32 operands.  bf16: operands rounded to bf16 (NOT an fp32 result; experiment only).")
+    ap.add_argument("--gemm", default="fp16x2", choices=["fp32", "bf16x3", "fp16x2", "bf16"],
+                    help="arithmetic of the 1x1-conv GEMMs; tensors and accumulation are fp32 in every case.  fp16x2 "
+                         "(default): every fp32 operand as two fp16 terms, three products on the fp16 MFMA pipe, "
+                         "operands scaled into fp16's range by powers of two -- against fp64 products and against the "
+                         "reference's golden vectors its error is that of the exact fp32 MFMA path (config 2, pre-clamp "
+                         "max-rel: 9.8e-7 vs 1.03e-6; tests/test_fp16x2.py).  bf16x3: three bf16 terms, six products, "
+                         "fp32-accurate by construction.  fp32: v_mfma_f32_* on fp32 operands.  The default run times "
+                         "the other two as well and reports them in the same line.  bf16 (rounded operands) is not an "
+                         "fp32 result and is labelled an experiment.")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -210,6 +215,8 @@ def main():
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "f32",
+                  "fp16x2": "f32 (GEMM products issued as 2xfp16 split terms, 3 products, fp32 accumulate; measured error "
+                            "against the reference equals the exact-fp32 MFMA path's)",
                   "bf16x3": "f32 (GEMM products issued as 3xbf16 split terms, fp32 accumulate; result error equals the "
                             "exact-fp32 MFMA path's)",
                   "bf16": "f32 storage/accumulate, bf16 products (EXPERIMENT, not an fp32 result)"}[args.gemm],
@@ -251,7 +258,7 @@ def main():
         hbm_bytes = {"dwconv": 2.0 * B_PER_GPU * h_ch * t * 4,
                      "free_encode": B_PER_GPU * (c_ch * t + L) * 4.0,
                      "free_decode": B_PER_GPU * (2.0 * c_ch * t + L) * 4.0}
-        for fam in ("dwconv", "free_encode", "free_decode"):
+        for fam in ("dwconv", "free_encode", "free_decode") + (("absmax",) if args.gemm == "fp16x2" else ()):
             ms, cnt = ctypes.c_double(), ctypes.c_int()
             _abi.check(lib.ps_profile_read(fam.encode(), ctypes.byref(ms), ctypes.byref(cnt)), "ps_profile_read")
             fams[fam] = (ms.value, cnt.value)
@@ -284,34 +291,51 @@ def main():
                                                    f"passes of this command), not measured in this run" if src else
                                                    "no PMC summary committed for this arithmetic")
         else:
-            planes_products = SPLIT_PRODUCTS if args.gemm == "bf16x3" else 1
+            planes_products = SPLIT_PRODUCTS[args.gemm]
             peak = BF16_MFMA_PEAK_TFLOPS / planes_products
             traffic, src = pmc_traffic(args.gemm, "ps::conv1x1_bf16_")
-            result["roofline"] = dict(
-                common, peak=peak, frac=achieved / peak, traffic=traffic,
-                kernel="ps::conv1x1_bf16_il_kernel (ps_conv1x1_bf16_f32)",
-                peak_note=f"algorithmic fp32 FLOP (2*M*K*T*N per launch) against the dense bf16 MFMA peak "
-                          f"{BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {planes_products} bf16 products per multiply-add; "
-                          f"the same FLOP against the fp32 MFMA peak {F32_MFMA_PEAK_TFLOPS} TFLOP/s = "
-                          f"{achieved / F32_MFMA_PEAK_TFLOPS:.2f}",
-                algorithmic_bytes_per_launch=B_PER_GPU * t * 4.0 * (3 * c_ch + 5 * h_ch) / 3,
-                traffic_note=f"HBM bytes per launch read from {src} (separate rocprofv3 --pmc passes of this command), "
-                             f"not measured in this run" if src else "no PMC summary committed for this arithmetic")
-    if rank == 0 and world == 1 and args.gemm == "bf16x3" and not args.no_roofline:
-        # the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32 on fp32 operands) timed beside it, same inputs, same K steps
-        model.masker.set_gemm_precision("fp32")
-        for _ in range(max(2, args.warmup)):
-            model.inference(noisy)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            model.inference(noisy)
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-        model.masker.set_gemm_precision(args.gemm)
-        result["fp32_mfma_path"] = {"value": B_PER_GPU * L * args.steps / dt, "unit": "samples/s",
-                                    "ms_per_step": dt / args.steps * 1e3,
-                                    "note": "python bench.py --gemm fp32: the same step with v_mfma_f32 on fp32 operands"}
+            alg_bytes = B_PER_GPU * t * 4.0 * (3 * c_ch + 5 * h_ch) / 3  # x in + y out (+ residual in) of in / pw / out
+            mfma_side = {"achieved_TFLOPs": achieved, "peak_TFLOPs": peak, "frac": achieved / peak,
+                         "floor_ms": (flops / launches) / (peak * 1e12) * 1e3,
+                         "note": f"algorithmic fp32 FLOP (2*M*K*T*N per launch) against the dense 16-bit MFMA peak "
+                                 f"{BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {planes_products} products per multiply-add; the "
+                                 f"same FLOP against the fp32 MFMA peak {F32_MFMA_PEAK_TFLOPS} TFLOP/s = "
+                                 f"{achieved / F32_MFMA_PEAK_TFLOPS:.2f}"}
+            hbm_gbps = alg_bytes / (avg_ms * 1e-3) / 1e9
+            hbm_side = {"achieved_GBps": hbm_gbps, "peak_GBps": HBM_PEAK_GBPS, "frac": hbm_gbps / HBM_PEAK_GBPS,
+                        "floor_ms": alg_bytes / (HBM_PEAK_GBPS * 1e9) * 1e3}
+            tnote = (f"HBM bytes per launch read from {src} (separate rocprofv3 --pmc passes of this command), not "
+                     f"measured in this run" if src else "no PMC summary committed for this arithmetic")
+            kern = "ps::conv1x1_bf16_il_kernel (%s)" % ("ps_conv1x1_f16x2_f32" if args.gemm == "fp16x2" else "ps_conv1x1_bf16_f32")
+            # the binding roofline is the one with the larger floor for the average launch: the six-product split is
+            # matrix-pipe bound (67 us against 60), the three-product split HBM bound (34 us against 60)
+            if hbm_side["floor_ms"] > mfma_side["floor_ms"]:
+                result["roofline"] = dict(common, bound="hbm", achieved=hbm_gbps, unit="GB/s", peak=HBM_PEAK_GBPS,
+                                          frac=hbm_gbps / HBM_PEAK_GBPS, traffic=traffic, kernel=kern,
+                                          algorithmic_bytes_per_launch=alg_bytes, mfma_side=mfma_side, traffic_note=tnote)
+            else:
+                result["roofline"] = dict(common, peak=peak, frac=achieved / peak, traffic=traffic, kernel=kern,
+                                          peak_note=mfma_side["note"], algorithmic_bytes_per_launch=alg_bytes,
+                                          hbm_side=hbm_side, traffic_note=tnote)
+    if rank == 0 and world == 1 and args.gemm in ("fp16x2", "bf16x3") and not args.no_roofline:
+        # the other fp32-class arithmetics timed beside it, same inputs, same K steps: the exact-fp32 MFMA path
+        # (v_mfma_f32_32x32x2_f32 on fp32 operands) and the six-product bf16 split
+        def timed(gemm):
+            model.masker.set_gemm_precision(gemm)
+            for _ in range(max(2, args.warmup)):
+                model.inference(noisy)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                model.inference(noisy)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            model.masker.set_gemm_precision(args.gemm)
+            return {"value": B_PER_GPU * L * args.steps / dt, "unit": "samples/s", "ms_per_step": dt / args.steps * 1e3}
+        result["fp32_mfma_path"] = dict(timed("fp32"), note="python bench.py --gemm fp32: the same step with v_mfma_f32 "
+                                                            "on fp32 operands")
+        other = "bf16x3" if args.gemm == "fp16x2" else "fp16x2"
+        result[other + "_path"] = dict(timed(other), note=f"python bench.py --gemm {other}")
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:

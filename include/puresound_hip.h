@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 5
+#define PS_ABI_VERSION 6
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -378,13 +378,19 @@ typedef struct ps_tcn_block {
   const float *pw_wt, *pw_b, *pw_gamma, *pw_beta, *pw_slope; /* pw_wt: kernel layout */
   const float *out_wt, *out_b;                                /* out_wt: kernel layout */
   /* matrix-pipe arithmetic of the three 1x1 convs: 0 = exact fp32 MFMA (the *_wt pointers above);
-   * 1 / 3 = ps_conv1x1_bf16_f32 with that many planes over the plane-packed weights below */
+   * 1 / 3 = ps_conv1x1_bf16_f32 with that many planes over the plane-packed weights below; 2 = fp16x2 (see the end) */
   int gemm_planes;
   const void *in_wb, *pw_wb, *out_wb;
   /* with gemm_planes = 1 (BASELINE's "bf16" configurations): keep the block's three hidden maps -- workspace only,
    * never visible to the caller -- as bf16 rows: written by the GEMM epilogue / the depthwise kernel, read by the next
    * prologue; statistics, bias, accumulation and the block's input / output (the residual stream) stay fp32 */
   int hidden_bf16;
+  /* gemm_planes = 2 ("fp16x2", ps_conv1x1_f16x2_f32): in_wb / pw_wb / out_wb hold the two-plane fp16 images of
+   * 2^w_exp[i] * W (i = 0 / 1 / 2: in, pointwise, out); dw_* / pw_* = max |gamma|, max |beta| of the norms in front of
+   * the pointwise and output convs (both PS_NORM_GLOBAL: the bound on the normalised values gives the activation scale);
+   * the residual stream's range travels from out_conv to the next in_conv as partial maxima inside the workspace */
+  int w_exp[3];
+  float dw_gmax, dw_bmax, pw_gmax, pw_bmax;
 } ps_tcn_block;
 
 /* ps_conv1x1_bf16_f32 / ps_dwconv_f32 with bf16 activation rows (x_bf16 / y_bf16 != 0: the buffer holds
@@ -395,6 +401,34 @@ int ps_conv1x1_bf16_io(const void* x, int x_bf16, const void* wt_planes, void* y
                        const float* res, double* ostats, void* stream);
 int ps_dwconv_io(const void* x, int x_bf16, const float* w, const float* b, void* y, int y_bf16, int N, int H, int T,
                  int ldt, int P, int dilation, int left, const ps_prologue* pro, double* ostats, void* stream);
+
+/* ps_conv1x1_f32's contract in the "fp16x2" arithmetic: every operand as two fp16 terms (22 significant bits), three
+ * products W0x0 + W0x1 + W1x0 on v_mfma_f32_32x32x16_f16, fp32 accumulation: half the matrix-pipe work of the
+ * three-plane bf16 split at <= 3 * 2^-22 relative error per product.  fp16 has five exponent bits, so both operands
+ * are brought into its range by powers of two (undone exactly in the epilogue):
+ *   weights      wt_planes = the two-plane image of 2^w_exp * W ([ceil(M/256)][ceil(K/16)][2][256][16] fp16,
+ *                ps_conv1x1_bf16_weight_bytes(M, K, 2) bytes); the packer picks w_exp so that max |2^w_exp W| lies in
+ *                [2^13, 2^14);
+ *   activations  x_bound > 0: a host-known bound on |f(x)| (behind a global norm: max|gamma| sqrt(count) + max|beta|),
+ *                the kernel scales by the power of two that puts it below 2^15;
+ *                else x_amax != NULL: [N][x_amax_parts] partial maxima of |x| left by the producer (y_amax of the
+ *                launch before, or ps_absmax_f32): per utterance, max |x| goes to [2^14, 2^15);
+ *                else 2^-2 behind a normalising prologue and 2^-4 otherwise (|values| beyond 2.6e5 / 1e6 overflow to
+ *                inf / NaN in y; small inputs lose relative precision: absolute resolution 2^-23 / 2^-21).
+ *   y_amax       optional, [N][ps_conv1x1_stats_parts(M, T)]: partial maxima of |y| over the valid frames. */
+typedef struct ps_f16x2_range {
+  int w_exp;
+  float x_bound;
+  const float* x_amax;
+  int x_amax_parts;
+  float* y_amax;
+} ps_f16x2_range;
+int ps_conv1x1_f16x2_f32(const float* x, const void* wt_planes, const ps_f16x2_range* rng, float* y, int N, int K, int M,
+                         int T, int ldt, const ps_prologue* pro, const float* bias, const float* bias_n,
+                         const float* res, double* ostats, void* stream);
+/* partial maxima of |x| over the valid frames: amax [N][ps_absmax_parts()] */
+int ps_absmax_parts(void);
+int ps_absmax_f32(const float* x, float* amax, int N, int C, int T, int ldt, void* stream);
 
 /* bytes of scratch ps_conv_tasnet_f32 needs for a batch (3 hidden maps + stats + embed bias) */
 size_t ps_conv_tasnet_workspace_bytes(int N, int C, int H, int T);

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -29,6 +29,10 @@ class Prologue(C.Structure):
                 ("pre_relu", C.c_int), ("post_tanh", C.c_int)]
 
 
+class F16x2Range(C.Structure):
+    _fields_ = [("w_exp", C.c_int), ("x_bound", C.c_float), ("x_amax", _vp), ("x_amax_parts", C.c_int), ("y_amax", _vp)]
+
+
 class LstmArgs(C.Structure):
     _fields_ = [("gx", _vp), ("whh_t", _vp), ("h0", _vp), ("c0", _vp), ("hout", _vp), ("h_last", _vp),
                 ("c_last", _vp)] + [(k, C.c_int) for k in ("N", "H", "D", "Q", "q_stride", "steps", "step_stride",
@@ -43,7 +47,9 @@ class TcnBlock(C.Structure):
                 ("dw_w", _vp), ("dw_b", _vp), ("dw_gamma", _vp), ("dw_beta", _vp), ("dw_slope", _vp),
                 ("pw_wt", _vp), ("pw_b", _vp), ("pw_gamma", _vp), ("pw_beta", _vp), ("pw_slope", _vp),
                 ("out_wt", _vp), ("out_b", _vp),
-                ("gemm_planes", C.c_int), ("in_wb", _vp), ("pw_wb", _vp), ("out_wb", _vp), ("hidden_bf16", C.c_int)]
+                ("gemm_planes", C.c_int), ("in_wb", _vp), ("pw_wb", _vp), ("out_wb", _vp), ("hidden_bf16", C.c_int),
+                ("w_exp", C.c_int * 3), ("dw_gmax", C.c_float), ("dw_bmax", C.c_float), ("pw_gmax", C.c_float),
+                ("pw_bmax", C.c_float)]
 
 
 # name -> (restype, argtypes); every symbol include/puresound_hip.h declares
@@ -73,6 +79,9 @@ SIGNATURES = {
     "ps_dwconv_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp]),
     "ps_dwconv_io": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 8 + [C.POINTER(Prologue), _vp, _vp]),
     "ps_conv1x1_bf16_io": (C.c_int, [_vp, C.c_int, _vp, _vp] + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
+    "ps_conv1x1_f16x2_f32": (C.c_int, [_vp, _vp, C.POINTER(F16x2Range), _vp] + [C.c_int] * 5 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
+    "ps_absmax_parts": (C.c_int, []),
+    "ps_absmax_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 4 + [_vp]),
     "ps_attn_stats_pool_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
     "ps_attn_stats_pool_len_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
     "ps_lstm_f32": (C.c_int, [C.POINTER(LstmArgs), _vp]),

@@ -125,14 +125,17 @@ extern "C" int ps_stats_parts(int channels, int frames) {
 //   y1, y2, y3 : 3 x [N][H][ldt] fp32
 //   stats      : 3 x [N][parts][2] fp64
 //   bias_n     : [N][H] fp32 (only with an embedding)
+//   amax       : 2 x [N][amax_parts] fp32 partial maxima of the residual stream (gemm_planes = 2: the range the next
+//                block's in_conv scales its input by; written by out_conv's epilogue, or by ps_absmax_f32 for block 0)
 struct TasnetWs {
   float *y1, *y2, *y3, *bias_n;
+  float* amax[2];
   double *s1, *s2, *s3;
-  int parts;
+  int parts, amax_parts;
   size_t bytes;
 };
 
-static TasnetWs carve(void* base, int N, int H, int T) {
+static TasnetWs carve(void* base, int N, int C, int H, int T) {
   TasnetWs w{};
   const int ldt = ps_padded_frames(T);
   // parts must cover producers with up to max(C,H) channels; H is what every stats producer emits
@@ -140,6 +143,9 @@ static TasnetWs carve(void* base, int N, int H, int T) {
   const size_t map = align_up((size_t)N * H * ldt * sizeof(float), 256);
   const size_t st = align_up((size_t)N * w.parts * 2 * sizeof(double), 256);
   const size_t bn = align_up((size_t)N * H * sizeof(float), 256);
+  w.amax_parts = ps_conv1x1_stats_parts(C > 0 ? C : H, T);
+  if (w.amax_parts < ps_absmax_parts()) w.amax_parts = ps_absmax_parts();
+  const size_t am = align_up((size_t)N * w.amax_parts * sizeof(float), 256);
   char* p = (char*)base;
   w.y1 = (float*)p; p += map;
   w.y2 = (float*)p; p += map;
@@ -148,18 +154,21 @@ static TasnetWs carve(void* base, int N, int H, int T) {
   w.s2 = (double*)p; p += st;
   w.s3 = (double*)p; p += st;
   w.bias_n = (float*)p; p += bn;
+  w.amax[0] = (float*)p; p += am;
+  w.amax[1] = (float*)p; p += am;
   w.bytes = (size_t)(p - (char*)base);
   return w;
 }
 
 extern "C" size_t ps_conv_tasnet_workspace_bytes(int N, int C, int H, int T) {
-  (void)C;
-  if (N <= 0 || H <= 0 || T <= 0) return 0;
-  return carve(nullptr, N, H, T).bytes;
+  if (N <= 0 || C <= 0 || H <= 0 || T <= 0) return 0;
+  return carve(nullptr, N, C, H, T).bytes;
 }
 
+// x_amax / x_amax_parts: partial maxima of |x_in| (gemm_planes = 2); y_amax: where out_conv leaves those of x_out
 static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, const float* dvec, int embed_norm,
-                     int N, int T, int ldt, const TasnetWs& w, void* stream) {
+                     int N, int T, int ldt, const TasnetWs& w, const float* x_amax, int x_amax_parts, float* y_amax,
+                     void* stream) {
   int rc;
   const float eps = 1e-8f;  // GlobLN.eps and gGN's eps (lobe/norm.py:10,96); folded BN carries its own
   const double count = (double)b.H * (double)T;
@@ -181,16 +190,37 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
   // hidden_bf16 (with gemm_planes = 1): y1, y2, y3 -- which never leave this workspace -- are bf16 rows; the block's
   // input and output (the residual stream) stay fp32
   const int hb = (b.hidden_bf16 && b.gemm_planes == 1) ? 1 : 0;
-  auto gemm = [&](const float* x, int xb, const float* wt, const void* wb, float* y, int yb, int K, int M,
+  // `which` = 0 / 1 / 2: in_conv, pointwise, out_conv (gemm_planes = 2: each has its own range descriptor)
+  auto gemm = [&](int which, const float* x, int xb, const float* wt, const void* wb, float* y, int yb, int K, int M,
                   const ps_prologue* pro, const float* bias, const float* bn, const float* res, double* st) {
     if (b.gemm_planes == 0) return ps_conv1x1_f32(x, wt, y, N, K, M, T, ldt, pro, bias, bn, res, st, stream);
+    if (b.gemm_planes == 2) {
+      ps_f16x2_range rng{};
+      rng.w_exp = b.w_exp[which];
+      if (which == 0) {
+        rng.x_amax = x_amax;
+        rng.x_amax_parts = x_amax_parts;
+      } else {
+        // behind a global norm |z| <= sqrt(count - 1), so |gamma z + beta| <= max|gamma| sqrt(count) + max|beta|
+        const float gmax = which == 1 ? b.dw_gmax : b.pw_gmax, bmax = which == 1 ? b.dw_bmax : b.pw_bmax;
+        rng.x_bound = gmax * (float)sqrt(count) + bmax;
+        if (!(rng.x_bound > 0.f)) rng.x_bound = 1.f;  // (gamma = beta = 0: every value is 0)
+      }
+      if (which == 2) rng.y_amax = y_amax;
+      return ps_conv1x1_f16x2_f32(x, wb, &rng, y, N, K, M, T, ldt, pro, bias, bn, res, st, stream);
+    }
     return ps_conv1x1_bf16_io(x, xb, wb, y, yb, N, K, M, T, ldt, b.gemm_planes, pro, bias, bn, res, st, stream);
   };
+  if (b.gemm_planes == 2 && (b.dw_norm != PS_NORM_GLOBAL || b.pw_norm != PS_NORM_GLOBAL || !x_amax)) {
+    set_error("ps_conv_tasnet_f32: gemm_planes=2 (fp16x2) needs global norms in front of the pointwise and output convs "
+              "(their bound on the normalised values is what scales the activations into fp16's range)");
+    return PS_E_UNSUPPORTED;
+  }
   if (b.gemm_planes != 0 && (!b.in_wb || !b.pw_wb || !b.out_wb)) {
     set_error("ps_conv_tasnet_f32: gemm_planes=%d needs the plane-packed weights in_wb / pw_wb / out_wb", b.gemm_planes);
     return PS_E_INVALID;
   }
-  rc = gemm(x_in, 0, b.in_wt, b.in_wb, w.y1, hb, b.C, b.H, nullptr, nullptr, bias_n, nullptr,
+  rc = gemm(0, x_in, 0, b.in_wt, b.in_wb, w.y1, hb, b.C, b.H, nullptr, nullptr, bias_n, nullptr,
             b.in_norm == PS_NORM_GLOBAL ? w.s1 : nullptr);
   if (rc) return rc;
 
@@ -221,7 +251,7 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
   p2.gamma = b.dw_gamma;
   p2.beta = b.dw_beta;
   p2.slope = b.dw_slope;
-  rc = gemm(w.y2, hb, b.pw_wt, b.pw_wb, w.y3, hb, b.H, b.H, &p2, b.pw_b, nullptr, nullptr,
+  rc = gemm(1, w.y2, hb, b.pw_wt, b.pw_wb, w.y3, hb, b.H, b.H, &p2, b.pw_b, nullptr, nullptr,
             b.pw_norm == PS_NORM_GLOBAL ? w.s3 : nullptr);
   if (rc) return rc;
 
@@ -236,7 +266,7 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
   p3.gamma = b.pw_gamma;
   p3.beta = b.pw_beta;
   p3.slope = b.pw_slope;
-  return gemm(w.y3, hb, b.out_wt, b.out_wb, x_out, 0, b.H, b.C, &p3, b.out_b, nullptr, x_in, nullptr);
+  return gemm(2, w.y3, hb, b.out_wt, b.out_wb, x_out, 0, b.H, b.C, &p3, b.out_b, nullptr, x_in, nullptr);
 }
 
 extern "C" int ps_conv_tasnet_f32(const ps_tcn_block* blocks, int n_blocks, const float* x_in, float* x_out,
@@ -277,12 +307,23 @@ extern "C" int ps_conv_tasnet_f32(const ps_tcn_block* blocks, int n_blocks, cons
     set_error("ps_conv_tasnet_f32: workspace must be 256-byte aligned");
     return PS_E_ALIGN;
   }
-  const TasnetWs w = carve(workspace, N, H, T);
+  const TasnetWs w = carve(workspace, N, C, H, T);
   // block 0 reads the caller's input and writes x_out; later blocks update x_out in place (each
   // workgroup reads exactly the residual elements it overwrites).
+  int have_parts = 0;  // partial maxima of the current residual stream in w.amax[i & 1] (fp16x2 blocks only)
+  const int out_parts = ps_conv1x1_stats_parts(C, T);
   for (int i = 0; i < n_blocks; ++i) {
-    const int rc = run_block(blocks[i], i == 0 ? x_in : x_out, x_out, dvec, embed_norm, N, T, ldt, w, stream);
+    const float* xi = i == 0 ? x_in : x_out;
+    const bool f16 = blocks[i].gemm_planes == 2;
+    if (f16 && !have_parts) {  // first fp16x2 block (or one behind a block of another arithmetic): one pass over its input
+      const int rc = ps_absmax_f32(xi, w.amax[i & 1], N, C, T, ldt, stream);
+      if (rc) return rc;
+      have_parts = ps_absmax_parts();
+    }
+    const int rc = run_block(blocks[i], xi, x_out, dvec, embed_norm, N, T, ldt, w, f16 ? w.amax[i & 1] : nullptr,
+                             have_parts, f16 ? w.amax[(i + 1) & 1] : nullptr, stream);
     if (rc) return rc;
+    have_parts = f16 ? out_parts : 0;
   }
   return 0;
 }

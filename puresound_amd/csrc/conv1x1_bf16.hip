@@ -10,6 +10,14 @@
 //             result is fp32-accurate (measured on the full config-2 forward: the deviation from the reference equals
 //             the reference's own fp32 reordering noise) at 6 bf16 MFMAs = 0.375 of the cost of the
 //             fp32 MFMA per k.
+// PLANES = 2: "fp16x2": two fp16 terms per operand (x = x0 + x1, 22 significant bits: x0 = fp16(x), x1 = fp16(x - x0))
+//             and three products W0x0, W0x1, W1x0 on v_mfma_f32_32x32x16_f16 -- half the matrix-pipe work of PLANES = 3
+//             at <= 3 * 2^-22 relative error per product (PLANES = 3 / fp32: 2^-24).  fp16 has 5 exponent bits, so both
+//             operands are brought into its range by powers of two: the packer scales the weight matrix to max |w| in
+//             [2^13, 2^14) (BfArgs::oscale undoes it in the epilogue), activations are scaled by 2^-2 behind a
+//             normalising prologue (|u| <= 2.6e5 representable; below 0.5 the low term is subnormal: absolute
+//             resolution 2^-23 of a unit-variance row) and by 2^-4 when raw (|x| <= 1e6).  Beyond that range the
+//             product overflows to inf / NaN in the output -- loudly, not silently.
 //
 // v_mfma_f32_32x32x16_bf16: A fragment = 8 consecutive k of one row, B fragment = 8 consecutive k of one column, so
 // both operand tiles live in LDS k-innermost ([row][16 k] bf16 = 32 B per row, read with ds_read_b128, conflict free).
@@ -31,8 +39,28 @@ namespace ps {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+// operand element type and MFMA of an arithmetic (PLANES = 1 / 3: bf16 terms, PLANES = 2: fp16 terms)
+template <int PLANES>
+struct Arith {
+  using x8 = bf16x8;
+  using x2 = bf16x2;
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Arith<2> {
+  using x8 = f16x8;
+  using x2 = f16x2;
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
 
 constexpr int XB_M = 256, XB_T = 128, XB_K = 16;
 
@@ -50,7 +78,31 @@ struct BfArgs {
   int ablate;  // profiling only (ps_debug_flags bits 24..26): 1 = no MFMA, 2 = no epilogue, 4 = no activation split
   int x_bf16, y_bf16;  // the rows of x / y are bf16 in HBM (PLANES = 1 only; bias, residual, statistics stay fp32 / fp64)
   int delay, groups;   // interleaved kernel: start offset (cycles) between the `groups` phases of workgroups
+  // PLANES = 2: activations are multiplied by a power of two before the fp16 split, accumulators by
+  // winv / (that power) in the epilogue (winv = 2^-w_exp undoes the packer's weight scale).  The power is `xscale` (the
+  // host's choice: from a bound on |f(x)|, or a default), or -- x_amax given -- per utterance from the producer's partial
+  // maxima of |x| ([N][x_amax_parts]).  y_amax: [N][tiles_m * tiles_t * 4] partial maxima of |y| for the next consumer.
+  float xscale, winv;
+  const float* x_amax;
+  int x_amax_parts;
+  float* y_amax;
 };
+
+// PLANES = 2: the scale pair of utterance n (every lane of the calling wave gets the same values)
+__device__ __forceinline__ void f16_scales(const BfArgs& a, int n, int lane, float& xs, float& os) {
+  xs = a.xscale;
+  if (a.x_amax) {
+    float m = 0.f;
+    const float* src = a.x_amax + (size_t)n * a.x_amax_parts;
+    for (int i = lane; i < a.x_amax_parts; i += 64) m = fmaxf(m, src[i]);
+    m = wave_max(m);
+    // max |x| in [2^e, 2^(e+1)) goes to [2^14, 2^15) (fp16 holds up to 65504); an all-zero utterance keeps 1
+    int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255) - 127;
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    xs = m > 0.f ? ldexpf(1.f, 14 - e) : 1.f;
+  }
+  os = a.winv / xs;  // (powers of two: exact)
+}
 
 // TT = frames per workgroup tile: 128 (2 x 2 waves of 128 x 64) or 32 (4 x 1 waves of 64 x 32 -- the small-grid
 // variant: four times the workgroups for launches that cannot fill the chip, e.g. one utterance at a time)
@@ -68,6 +120,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
   static_assert(!(XB || YB) || PLANES == 1, "bf16 rows go with bf16 products");
   constexpr int XE = XB ? 2 : 4, YE = YB ? 2 : 4;
   using L = BfLds<PLANES, TT>;
+  using AR = Arith<PLANES>;
+  using x8 = typename AR::x8;
+  using x2 = typename AR::x2;
   constexpr bool NARROW = TT != XB_T;
   constexpr int MI = NARROW ? 2 : 4, TI = NARROW ? 1 : 2;  // 32 x 32 MFMA tiles per wave
   constexpr int WROWS = MI * 32;                            // rows per wave
@@ -98,6 +153,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
     }
     __syncthreads();
   }
+
+  [[maybe_unused]] float xs = 1.f, os = 1.f;
+  if constexpr (PLANES == 2) f16_scales(a, n, lane, xs, os);
 
   // ---- staging ------------------------------------------------------------------------------------------------
   constexpr int A_PIECES = 2 * PLANES;  // 16-byte pieces per thread per K-step
@@ -152,15 +210,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
         if (a.pro.post_tanh) u = tanhf(u);
         if (k >= a.K) u = 0.f;
       }
+      if constexpr (PLANES == 2) u *= xs;
       v[j] = u;
     }
     unsigned char* sb = sa + L::A_BYTES;
 #pragma unroll
     for (int p = 0; p < PLANES; ++p) {
-      bf16x8 piece;
+      x8 piece;
 #pragma unroll
       for (int j = 0; j < 8; j += 2) {
-        const bf16x2 h = __builtin_convertvector(f32x2v{v[j], v[j + 1]}, bf16x2);
+        const x2 h = __builtin_convertvector(f32x2v{v[j], v[j + 1]}, x2);
         piece[j] = h[0];
         piece[j + 1] = h[1];
         if (p + 1 < PLANES) {
@@ -169,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
           v[j + 1] -= back[1];
         }
       }
-      *reinterpret_cast<bf16x8*>(sb + ((p * TT + bt) * XB_K + 8 * bh) * 2) = piece;
+      *reinterpret_cast<x8*>(sb + ((p * TT + bt) * XB_K + 8 * bh) * 2) = piece;
     }
   };
 
@@ -185,29 +244,33 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
     if (a.ablate & 1) return;
     const unsigned char* sa = smem + slot * L::SLOT;
     const unsigned char* sb = sa + L::A_BYTES;
-    bf16x8 bf[PLANES][TI];
+    x8 bf[PLANES][TI];
 #pragma unroll
     for (int p = 0; p < PLANES; ++p)
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti)
-        bf[p][ti] = *reinterpret_cast<const bf16x8*>(sb + ((p * TT + wt * 64 + ti * 32 + lr) * XB_K + 8 * lh) * 2);
+        bf[p][ti] = *reinterpret_cast<const x8*>(sb + ((p * TT + wt * 64 + ti * 32 + lr) * XB_K + 8 * lh) * 2);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      bf16x8 af[PLANES];
+      x8 af[PLANES];
 #pragma unroll
       for (int p = 0; p < PLANES; ++p)
-        af[p] = *reinterpret_cast<const bf16x8*>(sa + ((p * XB_M + wm * WROWS + mi * 32 + lr) * XB_K + 8 * lh) * 2);
+        af[p] = *reinterpret_cast<const x8*>(sa + ((p * XB_M + wm * WROWS + mi * 32 + lr) * XB_K + 8 * lh) * 2);
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) {
         if constexpr (PLANES == 3) {
           // smallest terms first
-          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][ti], acc[mi][ti], 0, 0, 0);
-          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0][ti], acc[mi][ti], 0, 0, 0);
-          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2][ti], acc[mi][ti], 0, 0, 0);
-          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0][ti], acc[mi][ti], 0, 0, 0);
-          acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1][ti], acc[mi][ti], 0, 0, 0);
+          acc[mi][ti] = AR::mfma(af[1], bf[1][ti], acc[mi][ti]);
+          acc[mi][ti] = AR::mfma(af[2], bf[0][ti], acc[mi][ti]);
+          acc[mi][ti] = AR::mfma(af[0], bf[2][ti], acc[mi][ti]);
+          acc[mi][ti] = AR::mfma(af[1], bf[0][ti], acc[mi][ti]);
+          acc[mi][ti] = AR::mfma(af[0], bf[1][ti], acc[mi][ti]);
         }
-        acc[mi][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0][ti], acc[mi][ti], 0, 0, 0);
+        if constexpr (PLANES == 2) {
+          acc[mi][ti] = AR::mfma(af[1], bf[0][ti], acc[mi][ti]);
+          acc[mi][ti] = AR::mfma(af[0], bf[1][ti], acc[mi][ti]);
+        }
+        acc[mi][ti] = AR::mfma(af[0], bf[0][ti], acc[mi][ti]);
       }
     }
   };
@@ -274,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
   // branches; the 32 residual values of a row block are in flight together before the first add.
   if (a.ablate & 2) return;
   float fsum = 0.f, fsq = 0.f;
+  [[maybe_unused]] float amx2[TI] = {};  // per column block; the pad-frame mask is applied once at the end
   const int slab = a.M * a.ldt * 4;
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<unsigned char*>(a.y) + (size_t)n * a.M * a.ldt * YE, 0, a.M * a.ldt * YE, 0x00020000);
@@ -309,13 +373,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
       const int rc = mi * 32 + (r & 3) + 8 * (r >> 2);
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) {
-        float v = acc[mi][ti][r] + bsum[r];
+        float v = PLANES == 2 ? acc[mi][ti][r] * os + bsum[r] : acc[mi][ti][r] + bsum[r];
         if constexpr (STATS) {
           const float vm = cm[ti] ? v : 0.f;
           fsum += vm;
           fsq += vm * vm;
         }
         if constexpr (RES) v += rv[ti][r];
+        if constexpr (PLANES == 2) amx2[ti] = fmaxf(amx2[ti], fabsf(v));
         if constexpr (YB)
           __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), yr, lane_off >> 1,
                                                 (tile_off + rc * a.ldt * 4 + ti * 128) >> 1, 0);
@@ -335,6 +400,27 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
     d[3] = st_b;
     d[4] = now - st_loop_end;  // epilogue
     d[5] = now;
+  }
+  if constexpr (PLANES == 2) {
+    if (a.y_amax) {  // partial maxima of |y|: same slots as the statistics (narrow tiles: the waves of a slot take turns,
+      float amx = 0.f;      // which is why narrow launches go through LDS below)
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) amx = fmaxf(amx, cm[ti] ? amx2[ti] : 0.f);
+      amx = wave_max(amx);
+      const int parts = a.tiles_m * a.tiles_t * 4;
+      if constexpr (NARROW) {
+        float* redf = reinterpret_cast<float*>(red);
+        __syncthreads();
+        if (lane == 0) redf[wave] = amx;
+        __syncthreads();
+        if (tid == 0)
+          a.y_amax[(size_t)n * parts + (mt * a.tiles_t + (blockIdx.x >> 2)) * 4 + (blockIdx.x & 3)] =
+              fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+        __syncthreads();
+      } else if (lane == 0) {
+        a.y_amax[(size_t)n * parts + (mt * a.tiles_t + blockIdx.x) * 4 + wave] = amx;
+      }
+    }
   }
   if constexpr (STATS) {
     double s = wave_sum((double)fsum), q = wave_sum((double)fsq);
@@ -1376,9 +1462,9 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
   const long long ntiles_all = (long long)a.tiles_t * a.tiles_m * N;
   const int Gs = (int)(ntiles_all < cus ? ntiles_all : cus);
   const long long per_wg_s = (ntiles_all + Gs - 1) / Gs, per_utt_s = (long long)a.tiles_t * a.tiles_m;
-  const bool solo = !XB && !YB && (g_debug_flags & (1 << 30)) && a.ksteps >= 4 && a.ksteps % 2 == 0 && ntiles_all >= cus &&
+  const bool solo = PLANES != 2 && !XB && !YB && (g_debug_flags & (1 << 30)) && a.ksteps >= 4 && a.ksteps % 2 == 0 && ntiles_all >= cus &&
                     (per_wg_s + per_utt_s - 2) / per_utt_s + 1 <= PP_MAXU;
-  if (solo) {
+  if constexpr (PLANES != 2) if (solo) {
 #define PS_SOLO(TRV, STV, RSV) \
   hipLaunchKernelGGL((conv1x1_bf16_solo_kernel<PLANES, TRV, STV, RSV>), dim3(Gs, 1), dim3(256), 0, stream, a)
     if (tr) {
@@ -1401,7 +1487,7 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
     // same time and the drains run at what HBM gives the whole chip at once (39 k cycles); four phases of workgroups
     // 16 k cycles apart shorten them by more than the offset costs at the end of the launch (248 -> 221 us at 32
     // utterances; the in / pointwise drains are issue-bound and gain nothing)
-    const_cast<BfArgs&>(a).delay = (PLANES == 3 && res && per_wg >= 4) ? 16000 : 0;
+    const_cast<BfArgs&>(a).delay = (PLANES >= 2 && res && per_wg >= 4) ? 16000 : 0;
     const_cast<BfArgs&>(a).groups = 4;
 #define PS_IL(TRV, STV, RSV) \
   hipLaunchKernelGGL((conv1x1_bf16_il_kernel<PLANES, TRV, STV, RSV, XB, (YB && !RSV)>), dim3(G, 1), dim3(512), 0, stream, a)
@@ -1417,7 +1503,7 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
 #undef PS_IL
     return;
   }
-  if (pp && !XB && !YB) {  // (bf16 rows: the interleaved kernel or the simple one)
+  if constexpr (PLANES != 2) if (pp && !XB && !YB) {  // (bf16 rows, fp16 terms: the interleaved kernel or the simple one)
 #define PS_PP(TRV, STV, RSV) \
   hipLaunchKernelGGL((conv1x1_bf16_pp_kernel<PLANES, TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)
     if (tr) {
@@ -1460,7 +1546,7 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
 using namespace ps;
 
 extern "C" size_t ps_conv1x1_bf16_weight_bytes(int M, int K, int planes) {
-  if (M <= 0 || K <= 0 || (planes != 1 && planes != 3)) return 0;
+  if (M <= 0 || K <= 0 || planes < 1 || planes > 3) return 0;
   const size_t tiles_m = (M + XB_M - 1) / XB_M, ksteps = (K + XB_K - 1) / XB_K;
   return tiles_m * ksteps * planes * XB_M * XB_K * 2;
 }
@@ -1471,9 +1557,75 @@ extern "C" int ps_conv1x1_bf16_f32(const float* x, const void* wt_planes, float*
   return ps_conv1x1_bf16_io(x, 0, wt_planes, y, 0, N, K, M, T, ldt, planes, pro, bias, bias_n, res, ostats, stream);
 }
 
+static int split_gemm(const void* x_any, int x_bf16, const void* wt_planes, const ps_f16x2_range* rng, void* y_any,
+                      int y_bf16, int N, int K, int M, int T, int ldt, int planes, const ps_prologue* pro,
+                      const float* bias, const float* bias_n, const float* res, double* ostats, void* stream);
+
 extern "C" int ps_conv1x1_bf16_io(const void* x_any, int x_bf16, const void* wt_planes, void* y_any, int y_bf16, int N,
                                   int K, int M, int T, int ldt, int planes, const ps_prologue* pro, const float* bias,
                                   const float* bias_n, const float* res, double* ostats, void* stream) {
+  if (planes != 1 && planes != 3) {
+    set_error("ps_conv1x1_bf16_f32: planes must be 1 (bf16 products) or 3 (fp32-accurate 3-way split), got %d", planes);
+    return PS_E_INVALID;
+  }
+  return split_gemm(x_any, x_bf16, wt_planes, nullptr, y_any, y_bf16, N, K, M, T, ldt, planes, pro, bias, bias_n, res,
+                    ostats, stream);
+}
+
+extern "C" int ps_conv1x1_f16x2_f32(const float* x, const void* wt_planes, const ps_f16x2_range* rng, float* y, int N,
+                                    int K, int M, int T, int ldt, const ps_prologue* pro, const float* bias,
+                                    const float* bias_n, const float* res, double* ostats, void* stream) {
+  if (!rng || rng->w_exp < -100 || rng->w_exp > 100 || rng->x_bound < 0.f || (rng->x_amax && rng->x_amax_parts <= 0)) {
+    set_error("ps_conv1x1_f16x2_f32: range descriptor missing or out of range (w_exp within +-100, x_bound >= 0)");
+    return PS_E_INVALID;
+  }
+  return split_gemm(x, 0, wt_planes, rng, y, 0, N, K, M, T, ldt, 2, pro, bias, bias_n, res, ostats, stream);
+}
+
+// partial maxima of |x| per utterance for the fp16x2 GEMM's range: [N][PS_ABSMAX_PARTS]
+constexpr int kAbsmaxParts = 64;
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T,
+                                                     int ldt) {
+  const int p = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const float* base = x + (size_t)n * C * ldt;
+  float m = 0.f;
+  for (int c = p; c < C; c += kAbsmaxParts) {
+    const float* row = base + (size_t)c * ldt;
+    for (int t = tid * 4; t < T; t += 1024) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row + t);  // (rows are padded to a multiple of 128 frames)
+      m = fmaxf(m, fabsf(v[0]));
+      if (t + 1 < T) m = fmaxf(m, fabsf(v[1]));
+      if (t + 2 < T) m = fmaxf(m, fabsf(v[2]));
+      if (t + 3 < T) m = fmaxf(m, fabsf(v[3]));
+    }
+  }
+  __shared__ float red[4];
+  m = wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) out[(size_t)n * kAbsmaxParts + p] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+extern "C" int ps_absmax_parts(void) { return kAbsmaxParts; }
+
+extern "C" int ps_absmax_f32(const float* x, float* amax, int N, int C, int T, int ldt, void* stream) {
+  if (!x || !amax || N <= 0 || C <= 0 || T <= 0 || N > 65535 || ldt < T || ldt % kTileT != 0) {
+    set_error("ps_absmax_f32: null pointer, non-positive size or ldt=%d not a multiple of %d >= T=%d", ldt, kTileT, T);
+    return PS_E_INVALID;
+  }
+  LaunchTimer timer("absmax", (hipStream_t)stream);
+  hipLaunchKernelGGL(absmax_kernel, dim3(kAbsmaxParts, N), dim3(256), 0, (hipStream_t)stream, x, amax, C, T, ldt);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("ps_absmax_f32: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+static int split_gemm(const void* x_any, int x_bf16, const void* wt_planes, const ps_f16x2_range* rng, void* y_any,
+                      int y_bf16, int N, int K, int M, int T, int ldt, int planes, const ps_prologue* pro,
+                      const float* bias, const float* bias_n, const float* res, double* ostats, void* stream) {
   const float* x = (const float*)x_any;
   float* y = (float*)y_any;
   if ((x_bf16 || y_bf16) && planes != 1) {
@@ -1486,10 +1638,6 @@ extern "C" int ps_conv1x1_bf16_io(const void* x_any, int x_bf16, const void* wt_
   }
   if (!x || !wt_planes || !y || N <= 0 || K <= 0 || M <= 0 || T <= 0 || N > 65535) {
     set_error("ps_conv1x1_bf16_f32: null pointer or non-positive size (N=%d K=%d M=%d T=%d)", N, K, M, T);
-    return PS_E_INVALID;
-  }
-  if (planes != 1 && planes != 3) {
-    set_error("ps_conv1x1_bf16_f32: planes must be 1 (bf16 products) or 3 (fp32-accurate 3-way split), got %d", planes);
     return PS_E_INVALID;
   }
   if (ldt < T || ldt % kTileT != 0 || ((uintptr_t)wt_planes & 15)) {
@@ -1544,7 +1692,22 @@ extern "C" int ps_conv1x1_bf16_io(const void* x_any, int x_bf16, const void* wt_
   {
     LaunchTimer timer("conv1x1_bf16", (hipStream_t)stream);
     hipStream_t st = (hipStream_t)stream;
-    if (planes == 3)
+    if (planes == 2) {
+      // range of the activations (see the header): a host-side bound, the producer's maxima, or the defaults
+      int x_exp = (tr && a.pro.norm != PS_NORM_NONE) ? -2 : -4;
+      if (rng->x_bound > 0.f) {
+        int e;
+        frexpf(rng->x_bound, &e);  // bound < 2^e  ->  scaled below 2^15
+        x_exp = 15 - e;
+        x_exp = x_exp < -100 ? -100 : (x_exp > 100 ? 100 : x_exp);
+      }
+      a.xscale = ldexpf(1.f, x_exp);
+      a.winv = ldexpf(1.f, -rng->w_exp);
+      a.x_amax = rng->x_bound > 0.f ? nullptr : rng->x_amax;
+      a.x_amax_parts = rng->x_amax_parts;
+      a.y_amax = rng->y_amax;
+      bf16_launch<2>(a, N, tr, st);
+    } else if (planes == 3)
       bf16_launch<3>(a, N, tr, st);
     else if (a.x_bf16 && a.y_bf16)
       bf16_launch<1, true, true>(a, N, tr, st);

@@ -38,6 +38,13 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// 64-lane butterfly maximum (fmaxf: a NaN lane is ignored)
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+
 // Sum (a, b) over a 256-thread workgroup; every thread receives the totals.  `red` holds 8 doubles.
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
   a = wave_sum(a);

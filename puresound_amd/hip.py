@@ -10,7 +10,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _abi
-from ._abi import (LstmArgs, Prologue, TcnBlock, check, lib, padded_frames, ptr, require_device, require_weight,
+from ._abi import (F16x2Range, LstmArgs, Prologue, TcnBlock, check, lib, padded_frames, ptr, require_device, require_weight,
                    stream_ptr)
 
 
@@ -189,6 +189,66 @@ def pack_wt_bf16(w: torch.Tensor, planes: int) -> torch.Tensor:
         out[:, :, p] = h.reshape(mt, 256, ks, 16).permute(0, 2, 1, 3)
         rest = rest - h.float()
     return out.contiguous()
+
+
+def pack_wt_f16x2(w: torch.Tensor) -> tuple[torch.Tensor, int]:
+    """[M,K] (or [M,K,1]) fp32 weight -> (two-plane fp16 image [ceil(M/256)][ceil(K/16)][2][256][16] of 2^w_exp * W, w_exp)
+    for ps_conv1x1_f16x2_f32: plane 0 = fp16(w'), plane 1 = fp16(w' - plane 0); w_exp puts max |w'| into [2^13, 2^14).
+    (Reads the maximum back to the host: plan-build time only.)"""
+    if w.dim() == 3:
+        w = w[:, :, 0]
+    m, k = w.shape
+    wmax = float(w.detach().abs().max())
+    if not (wmax < float("inf")):
+        raise ValueError("pack_wt_f16x2: the weight holds inf / NaN")
+    import math
+    w_exp = 13 - math.frexp(wmax)[1] + 1 if wmax > 0 else 0  # frexp: wmax = f * 2^e, f in [0.5, 1)
+    mt, ks = (m + 255) // 256, (k + 15) // 16
+    rest = torch.zeros(mt * 256, ks * 16, dtype=torch.float32, device=w.device)
+    rest[:m, :k] = torch.ldexp(w.detach().float(), torch.tensor(w_exp, device=w.device))
+    out = torch.empty(mt, ks, 2, 256, 16, dtype=torch.float16, device=w.device)
+    for p in range(2):
+        h = rest.to(torch.float16)
+        out[:, :, p] = h.reshape(mt, 256, ks, 16).permute(0, 2, 1, 3)
+        rest = rest - h.float()
+    return out.contiguous(), w_exp
+
+
+def conv1x1_f16x2(x: torch.Tensor, t: int, wt_planes: torch.Tensor, w_exp: int, m: int,
+                  pro: Optional[Prologue] = None, bias: Optional[torch.Tensor] = None,
+                  bias_n: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+                  want_stats: bool = False, out: Optional[torch.Tensor] = None, x_bound: float = 0.0,
+                  x_amax: Optional[torch.Tensor] = None, want_amax: bool = False):
+    """ps_conv1x1_f32's contract in the fp16x2 arithmetic (ps_conv1x1_f16x2_f32; weights from pack_wt_f16x2).
+    x_bound / x_amax: how the activations are brought into fp16's range (see include/puresound_hip.h); x_amax is an
+    [N, parts] tensor of partial maxima (absmax(), or the y_amax of the producing launch).  Returns (y, stats, y_amax)."""
+    require_device(x, "conv1x1_f16x2")
+    n, k, ldt = x.shape
+    y = out if out is not None else torch.empty(n, m, ldt, dtype=torch.float32, device=x.device)
+    stats = amax = None
+    if want_stats:
+        parts = lib().ps_conv1x1_stats_parts(m, t)
+        stats = torch.zeros(n, parts, 2, dtype=torch.float64, device=x.device)
+    if want_amax:
+        amax = torch.zeros(n, lib().ps_conv1x1_stats_parts(m, t), dtype=torch.float32, device=x.device)
+    if x_amax is not None:
+        require_device(x_amax, "conv1x1_f16x2 (x_amax)")
+        if x_amax.dim() != 2 or x_amax.shape[0] != n or not x_amax.is_contiguous():
+            raise ValueError(f"conv1x1_f16x2: x_amax must be a contiguous [N={n}, parts] tensor, got {tuple(x_amax.shape)}")
+    rng = F16x2Range(int(w_exp), float(x_bound), ptr(x_amax), x_amax.shape[1] if x_amax is not None else 0, ptr(amax))
+    check(lib().ps_conv1x1_f16x2_f32(ptr(x), ptr(wt_planes), C.byref(rng), ptr(y), n, k, m, t, ldt,
+                                     C.byref(pro) if pro is not None else None, ptr(bias), ptr(bias_n), ptr(res),
+                                     ptr(stats), stream_ptr(x.device)), "ps_conv1x1_f16x2_f32")
+    return y, stats, amax
+
+
+def absmax(x: torch.Tensor, t: int) -> torch.Tensor:
+    """padded rows [N, C, ldt] -> [N, ps_absmax_parts()] partial maxima of |x| over the t valid frames."""
+    require_device(x, "absmax")
+    n, c, ldt = x.shape
+    out = torch.empty(n, lib().ps_absmax_parts(), dtype=torch.float32, device=x.device)
+    check(lib().ps_absmax_f32(ptr(x), ptr(out), n, c, t, ldt, stream_ptr(x.device)), "ps_absmax_f32")
+    return out
 
 
 def conv1x1_bf16(x: torch.Tensor, t: int, wt_planes: torch.Tensor, m: int, pro: Optional[Prologue] = None,

@@ -16,13 +16,13 @@ from .. import hip
 from ..ops import op_module, same_shape
 from .._abi import PS_NORM_GLOBAL, TcnBlock, ptr
 from .lobe.cnn import DepthwiseSeparableConv1d
-from .lobe.norm import ChanLN, get_norm, norm_plan
+from .lobe.norm import ChanLN, GlobLN, get_norm, norm_plan
 
 
 _PLAN_SERIAL = [0]
 
 
-GEMM_PLANES = {"fp32": 0, "bf16": 1, "bf16x3": 3}
+GEMM_PLANES = {"fp32": 0, "bf16": 1, "fp16x2": 2, "bf16x3": 3}
 
 
 class _PlanCache:
@@ -72,20 +72,37 @@ class TCN(_PlanCache, nn.Module):
         self._plan_sig = None
 
     # -- kernel-side weight layout ----------------------------------------------------------------
-    #: arithmetic of the three 1x1 convs: "bf16x3" (default: every fp32 operand as three bf16 terms, six products on the
-    #: bf16 matrix pipe, fp32 accumulation -- the same deviation from the reference as fp32 MFMA operands, DESIGN.md 4.1b;
-    #: 1.36 x faster at 32 utterances, 1.5 x at one), "fp32" (v_mfma_f32 on fp32 operands; a row's result is then
-    #: bit-identical whatever batch it is part of) or "bf16" (operands rounded to bf16: what BASELINE.json names for its
-    #: bf16 configurations; not an fp32 result)
-    gemm_precision = "bf16x3"
+    #: arithmetic of the three 1x1 convs (fp32 tensors, fp32 accumulation in every case):
+    #:   "fp16x2" (default)  every fp32 operand as two fp16 terms, three products on the fp16 matrix pipe, operands scaled
+    #:                       into fp16's range by powers of two (bounds behind the global norms, the producer's maxima for
+    #:                       the residual stream).  Measured against fp64 products and against the reference's golden
+    #:                       vectors its error is the exact-fp32 MFMA path's; half the matrix-pipe work of
+    #:                       "bf16x3".  Blocks without global norms (bN1d, cLN) run "bf16x3" instead.
+    #:   "bf16x3"            three bf16 terms, six products: fp32-accurate by construction (dropped terms <= 2^-24)
+    #:   "fp32"              v_mfma_f32 on fp32 operands; a row's result is bit-identical whatever batch it is part of
+    #:   "bf16"              operands rounded to bf16: what BASELINE.json names for its bf16 configurations; not an fp32 result
+    gemm_precision = "fp16x2"
     #: with gemm_precision "bf16": keep the block's hidden maps (y1, y2, y3 inside the fused driver's workspace) as
     #: bf16 rows -- BASELINE's "bf16" configurations name bf16 storage with fp32 accumulation.  False: fp32 rows.
     hidden_bf16 = True
 
-    def plan(self, device: torch.device) -> dict:
+    def gemm_planes_for_plan(self) -> int:
+        """ps_tcn_block.gemm_planes this block runs with: its gemm_precision, unless the block cannot take it."""
         planes = GEMM_PLANES[self.gemm_precision]
         if max(self.in_channels, self.hid_channels) > 512:
-            planes = 0  # ps_conv1x1_bf16_f32 keeps prologue tables for up to 512 input channels: wider blocks run fp32
+            return 0  # ps_conv1x1_bf16_f32 keeps prologue tables for up to 512 input channels: wider blocks run fp32
+        if planes == 2:
+            # fp16x2 scales the activations of the pointwise / output convs by a bound on the normalised values: only a
+            # global norm (gLN, gGN) gives one.  Folded BatchNorm / cLN blocks take the three-plane bf16 split.
+            dsc = self.dconv[0]
+            if not all(isinstance(m, (GlobLN, nn.GroupNorm)) for m in (dsc.depthwise[1], dsc.pointwise[1])):
+                return 3
+            if isinstance(self.in_conv[1], ChanLN):
+                return 3
+        return planes
+
+    def plan(self, device: torch.device) -> dict:
+        planes = self.gemm_planes_for_plan()
         hb = bool(self.hidden_bf16) and planes == 1 and self.kernel == 3 and 2 * self.dilation + 8 <= 288
         sig = (_param_signature(self), str(device), planes, hb)
         if self._plan is not None and self._plan_sig == sig:
@@ -129,7 +146,15 @@ class TCN(_PlanCache, nn.Module):
         b.E = self.emb_dim
         b.gemm_planes = planes
         b.hidden_bf16 = int(hb)
-        if planes:
+        if planes == 2:
+            assert fused and kinds["dw"] == PS_NORM_GLOBAL and kinds["pw"] == PS_NORM_GLOBAL
+            for i, (key, wsrc) in enumerate((("in_wb", w_in[:, :c, 0]),
+                                             ("pw_wb", dsc.pointwise[0].weight.detach().to(**f32)),
+                                             ("out_wb", self.out_conv.weight.detach().to(**f32)))):
+                t[key], b.w_exp[i] = hip.pack_wt_f16x2(wsrc)
+            b.dw_gmax, b.dw_bmax = float(t["dw_gamma"].abs().max()), float(t["dw_beta"].abs().max())
+            b.pw_gmax, b.pw_bmax = float(t["pw_gamma"].abs().max()), float(t["pw_beta"].abs().max())
+        elif planes:
             t["in_wb"] = hip.pack_wt_bf16(w_in[:, :c, 0], planes)
             t["pw_wb"] = hip.pack_wt_bf16(dsc.pointwise[0].weight.detach().to(**f32), planes)
             t["out_wb"] = hip.pack_wt_bf16(self.out_conv.weight.detach().to(**f32), planes)
@@ -358,7 +383,8 @@ class ConvTasNet(_PlanCache, nn.Module):
         self._workspace = None
 
     def set_gemm_precision(self, name: str) -> "ConvTasNet":
-        """"bf16x3" (default) | "fp32" | "bf16" for the 1x1 convs of every normal TCN block (see TCN.gemm_precision)."""
+        """"bf16x3" (default) | "fp32" | "fp16x2" | "bf16" for the 1x1 convs of every normal TCN block (see
+        TCN.gemm_precision)."""
         if name not in GEMM_PLANES:
             raise ValueError(f"gemm precision must be one of {sorted(GEMM_PLANES)}")
         for stack in self.tcn_list:
