@@ -59,4 +59,16 @@ for name, (K, M, pro, res) in shapes.items():
         us = e0.elapsed_time(e1) / 10 * 1e3
         res_line.append(f"bf16x{planes}/{ {0: 'il', 32: 'pp'}.get(abl, 'simple') }={us:.0f}us ({flop / us / 1e6 * (6 if planes == 3 else 1) / 2500:.2f})")
     lib.ps_debug_flags(0)
+    wf, we = hip.pack_wt_f16x2(torch.randn(M, K, device=dev) * 0.05)
+    kw = dict(x_bound=1000.0) if pro else dict(x_amax=hip.absmax(x, T))
+    for _ in range(3):
+        hip.conv1x1_f16x2(x, T, wf, we, M, p, bias, None, r, want_stats=not res, out=y, want_amax=res, **kw)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        hip.conv1x1_f16x2(x, T, wf, we, M, p, bias, None, r, want_stats=not res, out=y, want_amax=res, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    res_line.append(f"fp16x2/il={e0.elapsed_time(e1) / 20 * 1e3:.0f}us")
     print(name, f"(peak {flop / 157.3e12 * 1e6:.0f}us)", "  ".join(res_line), flush=True)

@@ -6,5 +6,5 @@ for extra in "$@"; do
   touch puresound_amd/csrc/conv1x1_bf16.hip
   make -C puresound_amd/csrc EXTRA="$extra" > /dev/null 2>&1 || { echo "build failed: $extra"; exit 1; }
   echo "== EXTRA=$extra"
-  timeout -k 10 120 python tools/ablate_conv.py 2>/dev/null | sed -e 's/full=[0-9]*us  //' -e 's/bf16x3\/simple[^)]*)  //'
+  timeout -k 10 120 python tools/ablate_conv.py 2>/dev/null | sed -e 's/full=[0-9]*us  //' -e 's/bf16x3\/simple[^)]*)  //' -e 's/bf16x[13]\/pp[^)]*)  //g'
 done
