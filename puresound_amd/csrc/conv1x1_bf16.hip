@@ -78,6 +78,8 @@ struct BfArgs {
   int ablate;  // profiling only (ps_debug_flags bits 24..26): 1 = no MFMA, 2 = no epilogue, 4 = no activation split
   int x_bf16, y_bf16;  // the rows of x / y are bf16 in HBM (PLANES = 1 only; bias, residual, statistics stay fp32 / fp64)
   int delay, groups;   // interleaved kernel: start offset (cycles) between the `groups` phases of workgroups
+  int pair_r;          // interleaved kernel, two m-tiles: > 0 = workgroups per (utterance, m-tile) row; the two
+                       // workgroups that read the same activation tiles are placed on the same XCD (see bf16_launch)
   // PLANES = 2: activations are multiplied by a power of two before the fp16 split, accumulators by
   // winv / (that power) in the epilogue (winv = 2^-w_exp undoes the packer's weight scale).  The power is `xscale` (the
   // host's choice: from a bound on |f(x)|, or a default), or -- x_amax given -- per utterance from the producer's partial
@@ -1489,6 +1491,14 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
     // utterances; the in / pointwise drains are issue-bound and gain nothing)
     const_cast<BfArgs&>(a).delay = (PLANES >= 2 && res && per_wg >= 4) ? 16000 : 0;
     const_cast<BfArgs&>(a).groups = 4;
+    // out_conv (two m-tiles) reads every activation tile twice, once per m-tile.  Workgroups go to the XCDs round robin
+    // (blockIdx & 7), each XCD has its own L2: with the plain numbering the two readers of a tile sit on different XCDs
+    // and both reads come from HBM.  Renumbered so that they are 8 apart -- same XCD, dispatched together, running the
+    // same K-steps at the same time -- the second read is an L2 hit.
+    const int per = (int)(nsuper / (G > 0 ? G : 1));
+    const bool pairable = G == 256 && a.tiles_m == 2 && nsuper % 256 == 0 && per > 0 && st_per % per == 0 &&
+                          !(g_debug_flags & 64);
+    const_cast<BfArgs&>(a).pair_r = pairable ? st_per / per : 0;
 #define PS_IL(TRV, STV, RSV) \
   hipLaunchKernelGGL((conv1x1_bf16_il_kernel<PLANES, TRV, STV, RSV, XB, (YB && !RSV)>), dim3(G, 1), dim3(512), 0, stream, a)
     if (tr) {
