@@ -7,6 +7,8 @@
 #include <mutex>
 #include <vector>
 
+#include <atomic>
+
 #include "ps_common.h"
 
 namespace ps {
@@ -52,6 +54,22 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 }  // namespace ps
 
 using namespace ps;
+
+namespace ps {
+int device_cus() {
+  static std::atomic<int> cache[64];  // 0 = not read yet
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int cus = cache[dev].load(std::memory_order_relaxed);
+  if (cus == 0) {
+    hipDeviceProp_t prop;
+    cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    if (cus <= 0) cus = 256;
+    cache[dev].store(cus, std::memory_order_relaxed);
+  }
+  return cus;
+}
+}  // namespace ps
 
 extern "C" int ps_abi_version(void) { return PS_ABI_VERSION; }
 extern "C" const char* ps_last_error(void) { return g_err; }

@@ -560,15 +560,7 @@ PS_CONV1X1_KERNEL(conv1x1_tr, true, 0, false)
 PS_CONV1X1_KERNEL(conv1x1_raw_res, false, 2, false)
 
 static int persistent_grid() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return 2 * cus;  // two resident workgroups per CU (<= 256 VGPRs, 72 KiB LDS each)
+  return 2 * device_cus();  // two resident workgroups per CU (<= 256 VGPRs, 72 KiB LDS each)
 }
 
 }  // namespace ps

@@ -1434,17 +1434,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_bf16_solo_kernel(BfArgs a) {
 
 #include "conv1x1_bf16_il.inc"
 
-static int bf16_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
+static int bf16_cus() { return device_cus(); }
 
 template <int PLANES, bool XB = false, bool YB = false>
 static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {

@@ -17,6 +17,10 @@ void set_error(const char* fmt, ...);
 extern void* g_debug_buffer;  // ps_debug_buffer(): where diagnostic stamps go (NULL in production)
 extern int g_debug_flags;  // ps_debug_flags(): kernel ablation switches for profiling builds, 0 in production
 
+// Compute units of the CURRENT device (hipGetDevice), cached per device id: a process that drives several GPUs -- one
+// per thread, or hipSetDevice between calls -- gets each device's own count.
+int device_cus();
+
 // Brackets one kernel launch with hipEvents when ps_profile_enable(1) is active (no-op otherwise).
 struct LaunchTimer {
   LaunchTimer(const char* kernel, hipStream_t stream);

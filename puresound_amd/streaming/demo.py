@@ -88,8 +88,8 @@ class DemoTseNet(nn.Module):
         self.queue[:, :self.hop_size] = self.queue[:, self.hop_size:].clone()
         self.queue[:, self.hop_size:] = chunk
         # embedding terms of the FiLM layers: refreshed in place when the embeddings change
-        self._refresh_embedding(embed)
         self._check_parameters()
+        self._refresh_embedding(embed)
         if not self._use_graph:
             gen = self._hop_body()
         else:
@@ -123,6 +123,7 @@ class DemoTseNet(nn.Module):
             self._graph = None
             self._chunk_graphs = {}
             self._sig = sig
+            self.masker._embed_key = None  # the per-frame conditioning terms were made with the old weights
 
     def _refresh_embedding(self, embed: torch.Tensor) -> None:
         m = self.masker

@@ -102,6 +102,7 @@ class StreamingSkiM(SkiM):
             if m is not None:
                 m._per_frame = None
         self._graph = None
+        self._graph_sig = None
         self._use_graph = use_graph
         self._out = None
         print(f"{time.asctime(time.localtime(time.time()))}, Initialized streaming SkiM model")
@@ -111,21 +112,56 @@ class StreamingSkiM(SkiM):
         d = 1 if self.causal else 2
         return _frames_to_rows(v, self.streams).reshape(self.streams, d, self.hidden_size).permute(1, 0, 2).contiguous()
 
+    def _assign(self, dst: torch.Tensor, value: torch.Tensor) -> None:
+        """reference-shaped [D, B, H] (or [B, D*H]) state -> the frame-axis rows it lives in (in place: the captured
+        frame graph keeps reading the same buffers)"""
+        d = 1 if self.causal else 2
+        v = torch.as_tensor(value, dtype=torch.float32, device=dst.device)
+        if v.numel() != self.streams * d * self.hidden_size:
+            raise ValueError(f"state of {tuple(v.shape)} does not hold {self.streams} streams x {d * self.hidden_size} values")
+        if v.dim() == 3:
+            v = v.permute(1, 0, 2)
+        dst[0, :, :self.streams].copy_(v.reshape(self.streams, d * self.hidden_size).t())
+
+    # the reference keeps these as plain assignable attributes (skim_inference.py:146-164): reading gives copies in its
+    # layout, assigning a list of the same structure writes the values into the live state
     @property
     def seg_lstm_h_states(self):
         return [self._view(v) for v in self._seg_h]
+
+    @seg_lstm_h_states.setter
+    def seg_lstm_h_states(self, values):
+        for dst, v in zip(self._seg_h, values):
+            self._assign(dst, v)
 
     @property
     def seg_lstm_c_states(self):
         return [self._view(v) for v in self._seg_c]
 
+    @seg_lstm_c_states.setter
+    def seg_lstm_c_states(self, values):
+        for dst, v in zip(self._seg_c, values):
+            self._assign(dst, v)
+
     @property
     def mem_lstm_h_hidden(self):
         return [tuple(self._view(t) for t in s) for s in self._mem_h]
 
+    @mem_lstm_h_hidden.setter
+    def mem_lstm_h_hidden(self, values):
+        for pair, vs in zip(self._mem_h, values):
+            for dst, v in zip(pair, vs):
+                self._assign(dst, v)
+
     @property
     def mem_lstm_c_hidden(self):
         return [tuple(self._view(t) for t in s) for s in self._mem_c]
+
+    @mem_lstm_c_hidden.setter
+    def mem_lstm_c_hidden(self, values):
+        for pair, vs in zip(self._mem_c, values):
+            for dst, v in zip(pair, vs):
+                self._assign(dst, v)
 
     def reset_seg_lstm_status(self):
         self._seg_h[0].zero_()
@@ -185,6 +221,13 @@ class StreamingSkiM(SkiM):
         if x.numel() != b * self.input_size:
             raise RuntimeError(f"step_frame: expected {b} x {self.input_size} values, got {tuple(x.shape)}")
         self._x_in[0, :, :b].copy_(x.reshape(b, self.input_size).t())
+        # a parameter update (load_state_dict, an in-place edit) rebuilds the kernel plans: the captured graph replays the
+        # old pointers and the per-frame conditioning terms were made with the old weights -- both are redone
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if sig != self._graph_sig:
+            self._graph = None
+            self._graph_sig = sig
+            self._embed_key = None
         if embed is not None:
             key = (embed.data_ptr(), embed._version, tuple(embed.shape))
             if key != self._embed_key:

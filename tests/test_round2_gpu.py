@@ -339,3 +339,38 @@ def test_bf16_hidden_maps_stay_inside_the_bf16_acceptance(PA, dev):
         assert _l2rel(outs[hb], ref.numpy()) < 3e-2, hb
     assert not np.array_equal(outs[True], outs[False])
     assert _l2rel(outs[True], outs[False]) < 2e-2
+
+
+def test_step_frame_graph_follows_parameter_updates_and_states_are_assignable(dev):
+    """The frame-step graph of StreamingSkiM replays plan pointers: after load_state_dict it has to be captured again
+    (not replay the old weights).  The reference's state attributes are assignable lists (skim_inference.py:146-164)."""
+    from puresound_amd.streaming.demo import DemoTseNet
+    net = DemoTseNet().eval()
+    sd = det_state_dict(net)
+    net.load_state_dict(sd)
+    net.to(dev)
+    m = net.masker
+    m.init_status(2)
+    g = torch.Generator().manual_seed(11)
+    frames = [torch.rand(2, m.input_size, 1, generator=g).to(dev) for _ in range(6)]
+    emb = torch.rand(2, 192, generator=g).to(dev)
+    first = [m.step_frame(f, emb) for f in frames[:3]]
+    saved_h, saved_c = m.seg_lstm_h_states, m.seg_lstm_c_states
+    assert m._graph is not None
+    # new weights: the graph must not replay the old plans
+    sd2 = {k: (v * 1.25 if v.dtype.is_floating_point and "weight" in k else v) for k, v in sd.items()}
+    net.load_state_dict(sd2)
+    after = m.step_frame(frames[3], emb)
+    m2 = DemoTseNet().eval()
+    m2.load_state_dict(sd2)
+    m2.to(dev)
+    m2.masker.init_status(2, use_graph=False)
+    m2.masker.seg_lstm_h_states, m2.masker.seg_lstm_c_states = saved_h, saved_c  # the setters
+    for a, b in zip(m2.masker.seg_lstm_h_states, saved_h):
+        assert torch.equal(a, b)
+    m2.masker.frames_counter = 3
+    ref = m2.masker.step_frame(frames[3], emb)
+    assert torch.allclose(after, ref, rtol=0, atol=1e-6), float((after - ref).abs().max())
+    assert not torch.allclose(after, first[-1])
+    with pytest.raises(ValueError):
+        m2.masker.seg_lstm_h_states = [torch.zeros(3, 5)] * len(saved_h)
