@@ -438,6 +438,12 @@ size_t ps_conv_tasnet_workspace_bytes(int N, int C, int H, int T);
 int ps_conv_tasnet_f32(const ps_tcn_block* blocks_host, int n_blocks, const float* x_in, float* x_out,
                        const float* dvec, int embed_norm, int N, int T, int ldt, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* the same with the range of x_in handed over for blocks in the fp16x2 arithmetic: x_amax [N][x_amax_parts] holds, per
+ * utterance, values whose maximum is >= max |x_in[n]| (exact partial maxima, or any upper bound -- e.g. the encoder's
+ * max |wav| * max row sum of |w|); NULL = ps_conv_tasnet_f32 (one ps_absmax_f32 pass over x_in when block 0 needs it) */
+int ps_conv_tasnet_ranged_f32(const ps_tcn_block* blocks, int n_blocks, const float* x_in, float* x_out,
+                              const float* dvec, int embed_norm, int N, int T, int ldt, void* workspace,
+                              size_t workspace_bytes, const float* x_amax, int x_amax_parts, void* stream);
 
 /* Five moments of an (estimate, reference) waveform pair per row -- sum a, sum b, sum a^2, sum b^2, sum ab over L
  * samples, fp64 -- as per-workgroup partials [N][ps_wave_moments_chunks(L)][5] (the caller adds them up).  Every

@@ -112,6 +112,8 @@ SIGNATURES = {
     "ps_conv_tasnet_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "ps_conv_tasnet_f32": (C.c_int, [C.POINTER(TcnBlock), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                      C.c_int, _vp, C.c_size_t, _vp]),
+    "ps_conv_tasnet_ranged_f32": (C.c_int, [C.POINTER(TcnBlock), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, _vp, C.c_size_t, _vp, C.c_int, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -290,6 +290,17 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
 extern "C" int ps_conv_tasnet_f32(const ps_tcn_block* blocks, int n_blocks, const float* x_in, float* x_out,
                                   const float* dvec, int embed_norm, int N, int T, int ldt, void* workspace,
                                   size_t workspace_bytes, void* stream) {
+  return ps_conv_tasnet_ranged_f32(blocks, n_blocks, x_in, x_out, dvec, embed_norm, N, T, ldt, workspace, workspace_bytes,
+                                   nullptr, 0, stream);
+}
+
+extern "C" int ps_conv_tasnet_ranged_f32(const ps_tcn_block* blocks, int n_blocks, const float* x_in, float* x_out,
+                                         const float* dvec, int embed_norm, int N, int T, int ldt, void* workspace,
+                                         size_t workspace_bytes, const float* x_amax, int x_amax_parts, void* stream) {
+  if (x_amax && x_amax_parts <= 0) {
+    set_error("ps_conv_tasnet_ranged_f32: x_amax needs x_amax_parts > 0");
+    return PS_E_INVALID;
+  }
   if (!blocks || n_blocks <= 0 || !x_in || !x_out || !workspace || N <= 0 || T <= 0) {
     set_error("ps_conv_tasnet_f32: null pointer or non-positive size");
     return PS_E_INVALID;
@@ -333,12 +344,16 @@ extern "C" int ps_conv_tasnet_f32(const ps_tcn_block* blocks, int n_blocks, cons
   for (int i = 0; i < n_blocks; ++i) {
     const float* xi = i == 0 ? x_in : x_out;
     const bool f16 = blocks[i].gemm_planes == 2;
-    if (f16 && !have_parts) {  // first fp16x2 block (or one behind a block of another arithmetic): one pass over its input
+    const float* range = w.amax[i & 1];
+    if (f16 && i == 0 && x_amax) {  // the caller knows the range of x_in (maxima, or any upper bound per utterance)
+      range = x_amax;
+      have_parts = x_amax_parts;
+    } else if (f16 && !have_parts) {  // first fp16x2 block (or one behind another arithmetic): one pass over its input
       const int rc = ps_absmax_f32(xi, w.amax[i & 1], N, C, T, ldt, stream);
       if (rc) return rc;
       have_parts = ps_absmax_parts();
     }
-    const int rc = run_block(blocks[i], xi, x_out, dvec, embed_norm, N, T, ldt, w, f16 ? w.amax[i & 1] : nullptr,
+    const int rc = run_block(blocks[i], xi, x_out, dvec, embed_norm, N, T, ldt, w, f16 ? range : nullptr,
                              have_parts, f16 ? w.amax[(i + 1) & 1] : nullptr, stream);
     if (rc) return rc;
     have_parts = f16 ? out_parts : 0;

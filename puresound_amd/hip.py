@@ -64,7 +64,8 @@ def free_encode(wav: torch.Tensor, w: torch.Tensor, hop: int, relu: bool = False
     t = (length - win) // hop + 1
     need = min_frames(t) if callable(min_frames) else (min_frames or 0)
     ldt = padded_frames(max(t, need))
-    feats = torch.zeros(n, c, ldt, dtype=torch.float32, device=wav.device)
+    # frames beyond T: zero when a consumer asked for them (segment padding), otherwise never read as data
+    feats = (torch.zeros if need > t else torch.empty)(n, c, ldt, dtype=torch.float32, device=wav.device)
     check(lib().ps_free_encode_f32(ptr(wav), ptr(w), ptr(feats), n, length, c, win, hop, t, ldt, int(relu),
                                    stream_ptr(wav.device)), "ps_free_encode_f32")
     return feats, t
@@ -643,14 +644,23 @@ def l2_normalize(dvec: torch.Tensor) -> torch.Tensor:
 
 def conv_tasnet(blocks: "C.Array[TcnBlock]", n_blocks: int, x_pad: torch.Tensor, t: int, c: int, h: int,
                 dvec: Optional[torch.Tensor], embed_norm: bool,
-                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Run the whole masker on padded input [N,C,ldt]; returns padded mask logits [N,C,ldt]."""
+                workspace: Optional[torch.Tensor] = None, x_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Run the whole masker on padded input [N,C,ldt]; returns padded mask logits [N,C,ldt] (the frames beyond T are
+    not written).  x_amax [N, parts]: per utterance, values whose maximum bounds |x_pad[n]| -- the range blocks in the
+    fp16x2 arithmetic scale their input by (without it they measure it with one pass over x_pad)."""
     require_device(x_pad, "conv_tasnet")
     n, _, ldt = x_pad.shape
     need = lib().ps_conv_tasnet_workspace_bytes(n, c, h, t)
     if workspace is None or workspace.numel() < need:
         workspace = torch.zeros(need, dtype=torch.uint8, device=x_pad.device)
-    out = torch.zeros_like(x_pad)
-    check(lib().ps_conv_tasnet_f32(blocks, n_blocks, ptr(x_pad), ptr(out), ptr(dvec), int(embed_norm), n, t, ldt,
-                                   ptr(workspace), workspace.numel(), stream_ptr(x_pad.device)), "ps_conv_tasnet_f32")
+    out = torch.empty_like(x_pad)
+    parts = 0
+    if x_amax is not None:
+        require_device(x_amax, "conv_tasnet (x_amax)")
+        if x_amax.dim() != 2 or x_amax.shape[0] != n or not x_amax.is_contiguous():
+            raise ValueError(f"conv_tasnet: x_amax must be a contiguous [N={n}, parts] tensor, got {tuple(x_amax.shape)}")
+        parts = x_amax.shape[1]
+    check(lib().ps_conv_tasnet_ranged_f32(blocks, n_blocks, ptr(x_pad), ptr(out), ptr(dvec), int(embed_norm), n, t, ldt,
+                                          ptr(workspace), workspace.numel(), ptr(x_amax), parts,
+                                          stream_ptr(x_pad.device)), "ps_conv_tasnet_ranged_f32")
     return out

@@ -255,6 +255,8 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             elif part_enroll is not None:                              # base_nn.py:347-350, 697-705
                 dvec = self._speaker_embedding(part_enroll, lane)
             feats, t = self.encoder.encode_padded(part, need)          # _get_feature, base_nn.py:319-345
+            if getattr(self.masker, "takes_input_range", False) and hasattr(self.encoder, "feature_bound"):
+                kw["x_amax"] = self.encoder.feature_bound(part)        # the features' range without a pass over them
             mask = self.masker.forward_padded(feats, t, dvec, lane=lane, **kw)  # base_nn.py:709-714
             # get_mask + apply_tf_masks + _get_waveform + _wav_output_constrain, base_nn.py:716-721
             return self.encoder.decode_padded(feats, t, mask, mask_act, out_mode, out)

@@ -404,10 +404,14 @@ class ConvTasNet(_PlanCache, nn.Module):
             self._blocks_sig = sig
         return self._blocks, len(plans)
 
+    #: forward_padded takes `x_amax` (per-utterance bounds on |x_pad|) for blocks in the fp16x2 arithmetic
+    takes_input_range = True
+
     def forward_padded(self, x_pad: torch.Tensor, t: int, dvec: Optional[torch.Tensor] = None,
-                       lane: int = 0) -> torch.Tensor:
+                       lane: int = 0, x_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Padded-layout entry used by the fused wrapper: [N,C,ldt] -> mask logits [N,C,ldt].
-        `lane` selects the cached scratch buffer (one per concurrent HIP stream of the caller)."""
+        `lane` selects the cached scratch buffer (one per concurrent HIP stream of the caller); `x_amax` [N, parts]:
+        values whose per-utterance maximum bounds |x_pad| (only the fused normal-TCN path uses it)."""
         if self.tcn_layer.lower() == "gated":
             return self._forward_gated(x_pad, t, dvec)
         if not all(m.plan(x_pad.device)["fused"] for stack in self.tcn_list for m in stack):
@@ -428,7 +432,7 @@ class ConvTasNet(_PlanCache, nn.Module):
             ws = self._workspace[lane] = torch.zeros(need, dtype=torch.uint8, device=x_pad.device)
         return hip.conv_tasnet(blocks, n_blocks, x_pad, t, self.input_dim, self.tcn_dim,
                                None if dvec is None else dvec.contiguous().float(),
-                               bool(self.embed_norm), ws)
+                               bool(self.embed_norm), ws, x_amax)
 
     def _forward_staged(self, x: torch.Tensor, t: int, dvec: Optional[torch.Tensor]) -> torch.Tensor:
         """Normal TCN blocks with a cLN somewhere: block by block, stage by stage."""

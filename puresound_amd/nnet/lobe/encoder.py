@@ -50,6 +50,17 @@ class FreeEncDec(nn.Module):
         """[N,L] -> (padded feats [N,C,ldt], T); rows are zero beyond T and hold at least min_frames(T) frames."""
         return hip.free_encode(x, self.encoder.weight.detach(), self.hop_length, self.output_active, min_frames)
 
+    def feature_bound(self, x: torch.Tensor) -> torch.Tensor:
+        """[N,L] -> [N,1]: an upper bound on |forward(x)[n]|: max |x[n]| times the largest row sum of |w| (the ReLU only
+        shrinks).  Consumers that scale their input into a narrow exponent range (the fp16x2 GEMMs) take it instead of
+        measuring the features.  (The row sum is read back to the host once per weight version.)"""
+        w = self.encoder.weight
+        key = (w.data_ptr(), w._version)
+        if getattr(self, "_l1_key", None) != key:
+            self._l1 = float(w.detach().abs().sum(dim=(1, 2)).max())
+            self._l1_key = key
+        return torch.linalg.vector_norm(x.detach().float(), ord=float("inf"), dim=1, keepdim=True) * self._l1
+
     def decode_padded(self, feats_pad: torch.Tensor, t: int, mask_pad: Optional[torch.Tensor] = None,
                       mask_act: str = "linear", out_mode: str = "none",
                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
