@@ -62,7 +62,9 @@ def _rand(shape, seed, lo=-1.0, hi=1.0):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,length,c,win,hop,relu", [
     (2, 1000, 40, 32, 16, False), (3, 4111, 70, 32, 16, True), (2, 600, 24, 16, 8, False),
-    (2, 211, 9, 20, 6, True), (1, 32, 5, 32, 16, False), (1, 64000, 512, 32, 16, False)])
+    (2, 211, 9, 20, 6, True), (1, 32, 5, 32, 16, False), (1, 64000, 512, 32, 16, False),
+    # enough frames for the four-frames-per-thread kernel: T = 4001 (a one-frame tail group), T = 4098 (two), odd C
+    (5, 64032, 70, 32, 16, True), (4, 65584, 33, 32, 16, False), (5, 64036, 64, 32, 16, True)])
 def test_free_encode(H, dev, n, length, c, win, hop, relu):
     wav = _rand((n, length), 1, -0.5, 0.5)
     w = _rand((c, 1, win), 2, -0.2, 0.2)
@@ -76,7 +78,9 @@ def test_free_encode(H, dev, n, length, c, win, hop, relu):
     (2, 40, 61, 32, 16, "relu", "linear"), (2, 70, 700, 32, 16, "linear", "none"),
     (3, 24, 300, 16, 8, "sigmoid", "sigmoid"), (2, 9, 33, 20, 6, "relu", "linear"),
     (1, 8, 1, 32, 16, "linear", "none"), (1, 16, 255, 32, 16, "linear", "none"),
-    (1, 16, 256, 32, 16, "linear", "none"), (1, 512, 3999, 32, 16, "relu", "linear")])
+    (1, 16, 256, 32, 16, "linear", "none"), (1, 512, 3999, 32, 16, "relu", "linear"),
+    # channel-split workgroups (C >= 64): channel counts that do not divide by four, the 16 / 8 filterbank
+    (2, 66, 513, 32, 16, "relu", "linear"), (2, 127, 300, 16, 8, "sigmoid", "none")])
 def test_free_decode(H, dev, n, c, t, win, hop, mask_act, out_mode):
     feats = _rand((n, c, t), 3)
     mask = _rand((n, c, t), 4)
