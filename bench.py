@@ -332,8 +332,18 @@ def main():
             dt = time.perf_counter() - t0
             model.masker.set_gemm_precision(args.gemm)
             return {"value": B_PER_GPU * L * args.steps / dt, "unit": "samples/s", "ms_per_step": dt / args.steps * 1e3}
+        y_default = model.inference(noisy)
         result["fp32_mfma_path"] = dict(timed("fp32"), note="python bench.py --gemm fp32: the same step with v_mfma_f32 "
                                                             "on fp32 operands")
+        # how far the timed arithmetic is from the exact-fp32 MFMA path on this very batch (unit-range waveforms)
+        model.masker.set_gemm_precision("fp32")
+        y_fp32 = model.inference(noisy)
+        model.masker.set_gemm_precision(args.gemm)
+        result["deviation_from_fp32_mfma_path"] = {
+            "max_abs": float((y_default - y_fp32).abs().max()),
+            "l2_rel": float((y_default - y_fp32).norm() / y_fp32.norm()),
+            "note": "output waveforms of this batch, default arithmetic against --gemm fp32; against the reference's "
+                    "golden vectors all three stand at 1e-6 (tests/test_fp16x2.py, tools/gemm_precision_error.py)"}
         other = "bf16x3" if args.gemm == "fp16x2" else "fp16x2"
         result[other + "_path"] = dict(timed(other), note=f"python bench.py --gemm {other}")
     if rank == 0 and not args.no_cpu_baseline and world == 1:

@@ -19,9 +19,12 @@ def _run(*extra):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("gemm", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("gemm", [None, "bf16x3", "fp32"])
 def test_bench_line(gemm):
-    d = _run("--gemm", gemm)
+    d = _run(*(["--gemm", gemm] if gemm else []))
+    if gemm is None:
+        gemm = "fp16x2"  # the default arithmetic
+        assert d["gemm"] == "fp16x2"
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d, key
@@ -30,11 +33,21 @@ def test_bench_line(gemm):
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 32 * 64000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["traffic"] > 0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.0
-    assert r["peak"] == (157.3 if gemm == "fp32" else 2500.0 / 6)
-    if gemm == "bf16x3":
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.0 and r["traffic"] > 0
+    if gemm == "fp16x2":
+        # three products per multiply-add: the GEMMs' HBM floor is above their matrix-pipe floor
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+        assert r["mfma_side"]["peak_TFLOPs"] == 2500.0 / 3 and r["mfma_side"]["floor_ms"] < r["algorithmic_bytes_per_launch"] / 8e12 * 1e3
+    else:
+        assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
+        assert r["peak"] == (157.3 if gemm == "fp32" else 2500.0 / 6)
+    if gemm != "fp32":
+        other = "bf16x3_path" if gemm == "fp16x2" else "fp16x2_path"
         assert d["fp32_mfma_path"]["ms_per_step"] > d["ms_per_step"]  # the exact-fp32 MFMA path, timed beside it
+        assert d[other]["ms_per_step"] > 0
+        dev = d["deviation_from_fp32_mfma_path"]
+        assert 0 <= dev["max_abs"] < 1e-4 and 0 <= dev["l2_rel"] < 1e-4
     assert "cpu_baseline" not in d  # (--no-cpu-baseline)
     assert "profiles/" in r["traffic_note"] and r["kernel"].startswith("ps::conv1x1")
     assert d["config"]["hip_streams_per_gpu"] == 1  # timed path, events and a kernel trace describe the same launches
