@@ -20,7 +20,9 @@ FUSE_PROJ_LN_MAX_FRAMES = int(os.environ.get("PS_FUSE_PROJ_LN_MAX_FRAMES", "8192
 # "fp32" = v_mfma_f32 on fp32 operands, "bf16x3" = fp32-accurate 3 x bf16 split, "bf16" = operands rounded to bf16 (what
 # BASELINE.json names for the DPRNN configuration).  A per-module attribute, like TCN.gemm_precision: every PlanCache
 # module carries `gemm_precision` and hands it to the LSTM plans it builds (no process-wide switch).
-_PLANES = {"fp32": 0, "bf16": 1, "bf16x3": 3}
+# "fp16x2" (the TCN blocks' default) needs a bound on the GEMM's input that these projections do not have: it selects the
+# six-product split here.
+_PLANES = {"fp32": 0, "bf16": 1, "bf16x3": 3, "fp16x2": 3}
 
 
 def param_signature(module: nn.Module, device) -> tuple:
@@ -38,7 +40,8 @@ class PlanCache:
     gemm_precision = "fp32"  # arithmetic of the LSTM input projections built by this module (see _PLANES)
 
     def set_gemm_precision(self, name: str):
-        """"fp32" | "bf16x3" | "bf16" for the LSTM input projections of this module and of every module below it."""
+        """"fp32" | "bf16x3" (= "fp16x2" here) | "bf16" for the LSTM input projections of this module and of every module
+        below it."""
         if name not in _PLANES:
             raise ValueError(f"gemm precision must be one of {sorted(_PLANES)}")
         for m in self.modules():
