@@ -15,7 +15,7 @@ g = torch.Generator().manual_seed(1234)
 noisy = ((torch.rand(32, 64000, generator=g) * 2 - 1) * 0.5).to(dev)
 enroll = ((torch.rand(32, 64000, generator=torch.Generator().manual_seed(1235)) * 2 - 1) * 0.5).to(dev)
 ref = None
-for prec in ("fp32", "bf16x3", "bf16"):
+for prec in ("fp32", "bf16x3", "fp16x2", "bf16"):
     model.masker.set_gemm_precision(prec)
     for m in model.speaker_net:
         if hasattr(m, "gemm_precision"):

@@ -10,7 +10,7 @@ from puresound_amd.graphs import GraphedInference
 dev = torch.device("cuda:0")
 model = bench.build_model(dev)
 g = torch.Generator().manual_seed(1234)
-for gemm in ("fp32", "bf16x3"):
+for gemm in ("bf16x3", "fp16x2"):
     model.masker.set_gemm_precision(gemm)
     for n in (1, 4):
         noisy = ((torch.rand(n, bench.L, generator=g) * 2 - 1) * 0.5).to(dev)
