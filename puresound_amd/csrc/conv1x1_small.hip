@@ -193,11 +193,15 @@ struct ProjLnArgs {
 
 constexpr int PLN_MAXM = 256;
 
-template <int NRB>  // row blocks of 16 output channels: 8 (M <= 128) or 16 (M <= 256)
-__global__ __launch_bounds__(256) void proj_layernorm_kernel(ProjLnArgs a) {
-  __shared__ f32x4 part[4][NRB][64];
+// NRB: row blocks of 16 output channels: 8 (M <= 128) or 16 (M <= 256).  NW: waves that split K (4, or 8 for the short
+// rows of the streaming step, where the kernel is one latency chain on a handful of CUs: twice the loads in flight,
+// half the trips and half the MFMAs per wave).
+template <int NRB, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void proj_layernorm_kernel(ProjLnArgs a) {
+  constexpr int NT = 64 * NW, CP = NT / 16;  // threads; channel parts of the LayerNorm phase
+  __shared__ f32x4 part[NW][NRB][64];
   __shared__ float tile[NRB * 16][17];
-  __shared__ float red[16][17];
+  __shared__ float red[CP][17];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 15, kq = lane >> 4;
   const int t0 = blockIdx.x * 16, n = blockIdx.y;
@@ -208,12 +212,12 @@ __global__ __launch_bounds__(256) void proj_layernorm_kernel(ProjLnArgs a) {
   for (int j = 0; j < NRB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nk4 = a.Kp / 4;
   constexpr int UN = NRB == 8 ? 4 : 2;
-  for (int i0 = w; i0 < nk4; i0 += 4 * UN) {
+  for (int i0 = w; i0 < nk4; i0 += NW * UN) {
     float bv[UN], av[UN][NRB];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int k = 4 * (i0 + 4 * u) + kq;
-      const bool in = (i0 + 4 * u) < nk4;
+      const int k = 4 * (i0 + NW * u) + kq;
+      const bool in = (i0 + NW * u) < nk4;
       bv[u] = (in && k < a.K) ? xp[(size_t)k * a.ldt] : 0.f;
 #pragma unroll
       for (int j = 0; j < NRB; ++j) {
@@ -223,8 +227,8 @@ __global__ __launch_bounds__(256) void proj_layernorm_kernel(ProjLnArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int k = 4 * (i0 + 4 * u) + kq;
-      if (a.x_copy && (i0 + 4 * u) < nk4 && k < a.K && t0 + r < a.T)
+      const int k = 4 * (i0 + NW * u) + kq;
+      if (a.x_copy && (i0 + NW * u) < nk4 && k < a.K && t0 + r < a.T)
         a.x_copy[((size_t)n * a.K + k) * a.ldt + t0 + r] = bv[u];
 #pragma unroll
       for (int j = 0; j < NRB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][j], bv[u], acc[j], 0, 0, 0);
@@ -233,9 +237,10 @@ __global__ __launch_bounds__(256) void proj_layernorm_kernel(ProjLnArgs a) {
 #pragma unroll
   for (int j = 0; j < NRB; ++j) part[w][j][lane] = acc[j];
   __syncthreads();
-  for (int idx = threadIdx.x; idx < NRB * 64; idx += 256) {
+  for (int idx = threadIdx.x; idx < NRB * 64; idx += NT) {
     const int j = idx >> 6, ln = idx & 63;
-    const f32x4 s = (part[0][j][ln] + part[1][j][ln]) + (part[2][j][ln] + part[3][j][ln]);
+    f32x4 s = (part[0][j][ln] + part[1][j][ln]) + (part[2][j][ln] + part[3][j][ln]);
+    if constexpr (NW == 8) s += (part[4][j][ln] + part[5][j][ln]) + (part[6][j][ln] + part[7][j][ln]);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int m = j * 16 + 4 * (ln >> 4) + reg;
@@ -247,21 +252,21 @@ __global__ __launch_bounds__(256) void proj_layernorm_kernel(ProjLnArgs a) {
     }
   }
   __syncthreads();
-  // 16 frames x 16 channel parts
+  // 16 frames x CP channel parts
   const int f = threadIdx.x & 15, cp = threadIdx.x >> 4;
   const int t = t0 + f;
   auto frame_stats = [&](float& mean, float& rstd, float eps) {
     float s = 0.f;
-    for (int m = cp; m < a.M; m += 16) s += tile[m][f];
+    for (int m = cp; m < a.M; m += CP) s += tile[m][f];
     red[cp][f] = s;
     __syncthreads();
     float tot = 0.f;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) tot += red[p][f];
+    for (int p = 0; p < CP; ++p) tot += red[p][f];
     mean = tot / (float)a.M;
     __syncthreads();
     float q = 0.f;
-    for (int m = cp; m < a.M; m += 16) {
+    for (int m = cp; m < a.M; m += CP) {
       const float dv = tile[m][f] - mean;
       q += dv * dv;
     }
@@ -269,13 +274,13 @@ __global__ __launch_bounds__(256) void proj_layernorm_kernel(ProjLnArgs a) {
     __syncthreads();
     tot = 0.f;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) tot += red[p][f];
+    for (int p = 0; p < CP; ++p) tot += red[p][f];
     rstd = 1.f / sqrtf(tot / (float)a.M + eps);
     __syncthreads();
   };
   float mean, rstd;
   frame_stats(mean, rstd, a.eps);
-  for (int m = cp; m < a.M; m += 16) {
+  for (int m = cp; m < a.M; m += CP) {
     float v = (tile[m][f] - mean) * rstd * a.gamma[m] + a.beta[m];
     const size_t off = ((size_t)n * a.M + m) * a.ldt + t;
     if (!a.res_inside && a.res && t < a.T) v += a.res[off];
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256) void proj_layernorm_kernel(ProjLnArgs a) {
     __syncthreads();
     frame_stats(mean, rstd, a.eps2);
     if (t < a.T)
-      for (int m = cp; m < a.M; m += 16)
+      for (int m = cp; m < a.M; m += CP)
         a.y2[((size_t)n * a.M + m) * a.ldt + t] = (tile[m][f] - mean) * rstd * a.gamma2[m] + a.beta2[m];
   }
 }
@@ -422,7 +427,10 @@ extern "C" int ps_proj_layernorm_f32(const float* x, const float* wt, const floa
   ProjLnArgs a{x, wt, bias, gamma, beta, res, y, gamma2, beta2, y2, x_copy, res_inside, eps, eps2, K, (K + 15) / 16 * 16, M, T, ldt};
   {
     LaunchTimer timer("proj_layernorm", (hipStream_t)stream);
-    if (M <= 128)
+    // few workgroups (the streaming step: one per 16 streams): the kernel is a latency chain, eight waves split K
+    if (M <= 128 && (long long)N * ((T + 15) / 16) <= 64)
+      hipLaunchKernelGGL((proj_layernorm_kernel<8, 8>), dim3((T + 15) / 16, N), dim3(512), 0, (hipStream_t)stream, a);
+    else if (M <= 128)
       hipLaunchKernelGGL((proj_layernorm_kernel<8>), dim3((T + 15) / 16, N), dim3(256), 0, (hipStream_t)stream, a);
     else
       hipLaunchKernelGGL((proj_layernorm_kernel<16>), dim3((T + 15) / 16, N), dim3(256), 0, (hipStream_t)stream, a);

@@ -200,11 +200,14 @@ class SkiM(PlanCache, nn.Module):
             return self.seg_input_fusion[i].forward_padded(x, tp, embed, self.embed_norm)
         return x
 
-    def _output(self, x: torch.Tensor, t: int) -> torch.Tensor:
+    def _output(self, x: torch.Tensor, t: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         p = self._plan_get(x.device, self._build)
         pro = hip.make_prologue(0, True, None, 0.0, 0.0, None, None, p["out_slope"])
-        y, _ = hip.conv1x1(x, t, p["out"]["wt"], p["out"]["M"], pro, p["out"]["bias"],
-                           out=torch.empty(x.shape[0], p["out"]["M"], x.shape[2], dtype=torch.float32, device=x.device))
+        if out is None:
+            out = torch.empty(x.shape[0], p["out"]["M"], x.shape[2], dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != (x.shape[0], p["out"]["M"], x.shape[2]) or not out.is_contiguous():
+            raise ValueError(f"_output: `out` must be a contiguous {(x.shape[0], p['out']['M'], x.shape[2])} tensor")
+        y, _ = hip.conv1x1(x, t, p["out"]["wt"], p["out"]["M"], pro, p["out"]["bias"], out=out)
         return y
 
     def forward_padded(self, x_pad: torch.Tensor, t: int, embed: Optional[torch.Tensor] = None,

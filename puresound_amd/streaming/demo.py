@@ -139,8 +139,36 @@ class DemoTseNet(nn.Module):
                     f.set_per_frame_condition(m._embed_static, m.embed_norm)
 
     def _chunk_body(self, hops: int, update_at: Optional[int]):
-        """`hops` hops on the static buffers: window shift, hop body, averaging OLA; the Mem-LSTM update + block-0 reset
-        behind hop `update_at` (skim_inference.py:205-218).  Returns nothing: results are in _blocks / _tail."""
+        """`hops` hops on the static buffers; the Mem-LSTM update + block-0 reset behind hop `update_at`
+        (skim_inference.py:205-218).  Only the masker step is recurrent: the windows of all hops are encoded in ONE
+        launch up front (hop i of stream s = samples [16 i, 16 i + 32) of its previous half window followed by the
+        chunk; one "utterance" per hop, so every hop's features are the [1, C, ldB] block the masker step reads), the
+        masker steps write their masks side by side, and ONE decoder launch plus the averaging overlap-add of all hops
+        follows.  Same arithmetic per frame as the hop loop.  Results are in _blocks / _tail / queue."""
+        m, h, b = self.masker, self.hop_size, self.masker.streams
+        if self.ola_size != h:  # (the averaging below assumes win = 2 hop, as in the reference harness)
+            return self._chunk_body_by_hops(hops, update_at)
+        sig = torch.cat([self.queue[:, h:], self._chunk_in], dim=1)                      # [B, 16 + 16 hops]
+        self._wins.copy_(sig.unfold(1, self.win_size, h).permute(1, 0, 2).reshape(hops, b * self.win_size))
+        feats, _ = hip.free_encode(self._wins, self.encoder.encoder.weight.detach(), self.win_size, True)  # [hops,C,ldB]
+        if self._masks is None or self._masks.shape != (hops, m.output_fc[1].out_channels, feats.shape[-1]):
+            self._masks = torch.empty(hops, m.output_fc[1].out_channels, feats.shape[-1], dtype=torch.float32, device=feats.device)
+        for i in range(hops):
+            m._x_in = feats[i:i + 1]
+            m._frame_body(out=self._masks[i:i + 1])
+            if update_at == i:
+                m.update_mem_lstm()
+                m.reset_seg_lstm_status()
+        frames = hip.free_decode(feats, b, self.encoder.decoder.weight.detach(), self.win_size, self._masks, "linear",
+                                 "none").reshape(hops, b, self.win_size)
+        heads, tails = frames[:, :, :h], frames[:, :, h:]
+        prev = torch.cat([self._tail.unsqueeze(0), tails[:-1]], dim=0)
+        self._blocks.copy_(((prev + heads) * 0.5).permute(1, 0, 2).reshape(b, hops * h))
+        self._tail.copy_(tails[-1])
+        self.queue.copy_(sig[:, sig.shape[1] - self.win_size:])
+
+    def _chunk_body_by_hops(self, hops: int, update_at: Optional[int]):
+        """The same, hop by hop (window shift, hop body, averaging overlap-add per hop)."""
         m, h = self.masker, self.hop_size
         for i in range(hops):
             self.queue[:, :h] = self.queue[:, h:].clone()
@@ -179,6 +207,8 @@ class DemoTseNet(nn.Module):
             self._chunk_in = torch.empty(b, hops * h, dtype=torch.float32, device=dev)
             self._blocks = torch.empty(b, hops * h, dtype=torch.float32, device=dev)
             self._tail = torch.empty(b, self.ola_size, dtype=torch.float32, device=dev)
+            self._wins = torch.empty(hops, b * self.win_size, dtype=torch.float32, device=dev)
+            self._masks = None
             self._chunk_graphs = {}
         self._chunk_in.copy_(chunk[:, :hops * h])
         self._tail.copy_(pre_wav[:, pre_wav.shape[-1] - self.ola_size:])

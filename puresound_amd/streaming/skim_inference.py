@@ -167,9 +167,9 @@ class StreamingSkiM(SkiM):
         self._seg_h[0].zero_()
         self._seg_c[0].zero_()
 
-    def _frame_body(self):
+    def _frame_body(self, out: Optional[torch.Tensor] = None):
         """One frame of every stream through all blocks; reads _x_in / _embed_static, updates the seg states in
-        place, returns padded [1, C_out, ldB]."""
+        place, returns padded [1, C_out, ldB] (written into `out` when given)."""
         b = self.streams
         c_in, hid = self.input_size, self.hidden_size
         cur, cur_ln = self._x_in, None
@@ -210,7 +210,7 @@ class StreamingSkiM(SkiM):
                 norm2 = (ln["gamma"], ln["beta"], ln["eps"])
             cur, cur_ln = hip.proj_layernorm(h_new, b, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"],
                                              norm["eps"], x_rows, norm2, x_copy=h_rows)
-        return self._output(cur, b)
+        return self._output(cur, b, out)
 
     @torch.no_grad()
     def step_frame(self, x: torch.Tensor, embed: Optional[torch.Tensor]) -> torch.Tensor:
