@@ -153,12 +153,16 @@ class DemoTseNet(nn.Module):
         feats, _ = hip.free_encode(self._wins, self.encoder.encoder.weight.detach(), self.win_size, True)  # [hops,C,ldB]
         if self._masks is None or self._masks.shape != (hops, m.output_fc[1].out_channels, feats.shape[-1]):
             self._masks = torch.empty(hops, m.output_fc[1].out_channels, feats.shape[-1], dtype=torch.float32, device=feats.device)
+            self._cores = torch.empty(hops, m.input_size, feats.shape[-1], dtype=torch.float32, device=feats.device)
+        # block 0's input norm and the output layer do not touch the recurrent state either: one launch each
+        x_ln = m.input_norm_all(feats) if m.block0_takes_input_norm() else None
         for i in range(hops):
             m._x_in = feats[i:i + 1]
-            m._frame_body(out=self._masks[i:i + 1])
+            m._frame_body(x_ln=None if x_ln is None else x_ln[i:i + 1], core_out=self._cores[i:i + 1])
             if update_at == i:
                 m.update_mem_lstm()
                 m.reset_seg_lstm_status()
+        m._output(self._cores, b, out=self._masks)
         frames = hip.free_decode(feats, b, self.encoder.decoder.weight.detach(), self.win_size, self._masks, "linear",
                                  "none").reshape(hops, b, self.win_size)
         heads, tails = frames[:, :, :h], frames[:, :, h:]

@@ -167,12 +167,28 @@ class StreamingSkiM(SkiM):
         self._seg_h[0].zero_()
         self._seg_c[0].zero_()
 
-    def _frame_body(self, out: Optional[torch.Tensor] = None):
+    def block0_takes_input_norm(self) -> bool:
+        """block 0 starts with FiLM's own LayerNorm of the input frame (then `input_norm_all` may run it for many
+        frames at once: it does not depend on the recurrent state)"""
+        f = self.seg_input_fusion[0] if getattr(self, "seg_input_fusion", None) is not None else None
+        return bool(self.causal and self._embed_static is not None and self.block_with_embed[0] and isinstance(f, FiLM)
+                    and f.inp_norm and self.input_size % 2 == 0)
+
+    def input_norm_all(self, frames: torch.Tensor) -> torch.Tensor:
+        """[hops, C, ldB] encoder frames -> block 0's input norm of each, one launch"""
+        f = self.seg_input_fusion[0]
+        ln = f._plan_get(frames.device, f._build)["norm"]
+        return hip.chan_layernorm(frames, self.streams, ln["gamma"], ln["beta"], ln["eps"])
+
+    def _frame_body(self, out: Optional[torch.Tensor] = None, x_ln: Optional[torch.Tensor] = None,
+                    core_out: Optional[torch.Tensor] = None):
         """One frame of every stream through all blocks; reads _x_in / _embed_static, updates the seg states in
-        place, returns padded [1, C_out, ldB] (written into `out` when given)."""
+        place, returns padded [1, C_out, ldB] (written into `out` when given).  `x_ln`: block 0's input norm of _x_in,
+        already computed (input_norm_all).  `core_out` [1, C, ldB]: the last block's output goes there and the output
+        layer is left to the caller (one launch for many frames); returns None then."""
         b = self.streams
         c_in, hid = self.input_size, self.hidden_size
-        cur, cur_ln = self._x_in, None
+        cur, cur_ln = self._x_in, x_ln
         for i in range(self.n_blocks):
             fused = self._embed_static is not None and self.block_with_embed[i]
             if not self.causal:
@@ -208,8 +224,13 @@ class StreamingSkiM(SkiM):
             if isinstance(nxt, FiLM) and nxt.inp_norm and c_in % 2 == 0:
                 ln = nxt._plan_get(cur.device, nxt._build)["norm"]
                 norm2 = (ln["gamma"], ln["beta"], ln["eps"])
+            last = core_out if (core_out is not None and i == self.n_blocks - 1) else None
             cur, cur_ln = hip.proj_layernorm(h_new, b, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"],
-                                             norm["eps"], x_rows, norm2, x_copy=h_rows)
+                                             norm["eps"], x_rows, norm2, x_copy=h_rows, out=last)
+        if core_out is not None:
+            if cur.data_ptr() != core_out.data_ptr():
+                core_out.copy_(cur)
+            return None
         return self._output(cur, b, out)
 
     @torch.no_grad()
