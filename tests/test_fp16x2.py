@@ -207,3 +207,29 @@ def test_fp16x2_inside_a_captured_graph(dev):
     assert torch.equal(graphed(x), eager)
     x2 = det_wave(4, 1, 16000).to(dev) * 0.01  # another range through the same graph
     assert torch.equal(graphed(x2), model.inference(x2))
+
+
+@pytest.mark.gpu
+def test_input_range_may_be_a_loose_bound(dev):
+    """ps_conv_tasnet_ranged_f32: the range of the first block's input may be any upper bound (the wrapper passes
+    max |wav| x the largest row sum of the encoder's |w|); a bound 16 x too loose costs four bits of headroom, not
+    accuracy, and the measured maxima (no range given: one ps_absmax_f32 pass) give the same result to rounding."""
+    import puresound_amd.nnet as PA
+    from puresound_amd import hip as H
+    model = cases.build(PA.NS, "cfg2_full").eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    x = det_wave(9, 3, 16000).to(dev)
+    x[1] *= 1e-3
+    feats, t = model.encoder.encode_padded(x)
+    bound = model.encoder.feature_bound(x)
+    true_max = feats[..., :t].abs().amax((1, 2))
+    assert (bound[:, 0] >= true_max).all() and (bound[:, 0] < 64 * true_max).all()
+    model.masker.set_gemm_precision("fp32")
+    ref = model.masker.forward_padded(feats, t)[..., :t]
+    model.masker.set_gemm_precision("fp16x2")
+    outs = [model.masker.forward_padded(feats, t, x_amax=r)[..., :t] for r in (None, bound, bound * 16.0, H.absmax(feats, t))]
+    for o in outs:
+        assert float((o - ref).norm() / ref.norm()) < 5e-6
+    with pytest.raises(ValueError):
+        model.masker.forward_padded(feats, t, x_amax=bound[:2])
