@@ -233,3 +233,29 @@ def test_input_range_may_be_a_loose_bound(dev):
         assert float((o - ref).norm() / ref.norm()) < 5e-6
     with pytest.raises(ValueError):
         model.masker.forward_padded(feats, t, x_amax=bound[:2])
+
+
+@pytest.mark.gpu
+def test_fp16x2_on_degenerate_inputs(dev):
+    """Silence, near-silence, an impulse, a full-scale square wave and a batch mixing them: the ranges are per utterance
+    and an all-zero utterance must not turn into 0 * inf; against the exact-fp32 path."""
+    import puresound_amd.nnet as PA
+    model = cases.build(PA.NS, "cfg2_full").eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    n, length = 5, 8000
+    x = torch.zeros(n, length)
+    x[1] = det_wave(21, 1, length)[0] * 1e-7
+    x[2, 4000] = 0.9
+    x[3] = torch.sign(torch.sin(torch.arange(length) * 0.05)) * 0.99
+    x[4] = det_wave(22, 1, length)[0]
+    x = x.to(dev)
+    model.masker.set_gemm_precision("fp32")
+    ref = model.inference(x)
+    model.masker.set_gemm_precision("fp16x2")
+    y = model.inference(x)
+    assert torch.isfinite(y).all()
+    for i in range(n):
+        scale = float(ref[i].abs().max())
+        err = float((y[i] - ref[i]).abs().max())
+        assert err <= 2e-5 * max(scale, 1e-30) + 1e-12, (i, err, scale)
