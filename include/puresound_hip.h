@@ -183,6 +183,10 @@ int ps_attn_stats_pool_f32(const float* logits, const float* x, float* out, int 
  * length_to_mask(lengths * L) (pooling.py:9-50) followed by masked_fill(-inf). */
 int ps_attn_stats_pool_len_f32(const float* logits, const float* x, const float* lengths, float* out, int N, int C,
                                int T, int ldt, float eps, void* stream);
+/* the attention map itself (AttentiveStatisticsPooling.forward(..., return_weight=True), lobe/pooling.py:109-113):
+ * out[n][c][t] = softmax over the valid frames of logits[n][c][:], 0 on masked frames; lengths as above or NULL */
+int ps_attn_weights_f32(const float* logits, const float* lengths, float* out, int N, int C, int T, int ldt,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ps_conv1x1_bf16_f32: the same operation as ps_conv1x1_f32 (same prologue, bias, residual, statistics, fp32 tensors
@@ -259,7 +263,8 @@ int ps_activation_f32(float* x, int kind, const float* slope, int64_t rows, int 
  * rows of ld frames (row r belongs to channel r / rows_per_channel).  pro = PS_NORM_GLOBAL with the producing GEMM's
  * partial statistics, count = the number of VALID elements per utterance; corr_sum / corr_sq = what the pad columns
  * contributed to those statistics (zero taps there: the GEMM output is its bias, so sum_c bias[c] * F * (ld - T) and the
- * same with bias^2). */
+ * same with bias^2).  pro = PS_NORM_AFFINE (a folded eval BatchNorm: gamma / beta are its per-channel scale / shift)
+ * needs no statistics. */
 int ps_norm_activation_f32(float* x, const ps_prologue* pro, double corr_sum, double corr_sq, int rows_per_channel,
                            int kind, const float* slope, int N, int rows_per_utt, int T, int ld, void* stream);
 /* y = a + b over `count` floats (the additive skip connections of Unet(skip_conv=True), unet.py:249); y may alias a or b */

@@ -235,14 +235,21 @@ def create_fourier_tables(n_fft: int):
 # Conv-TasNet blocks
 # ---------------------------------------------------------------------------
 def ds_conv(x: torch.Tensor, sd: SD, p: str, kernel: int, dilation: int, causal: bool, norm: str) -> torch.Tensor:
-    """DepthwiseSeparableConv1d.forward without hid_channels/skip (lobe/cnn.py:84-106)."""
+    """DepthwiseSeparableConv1d.forward (lobe/cnn.py:84-106); the hid_channels transform (in_conv.*) and the skip
+    connection (skip_conv.*) are taken when their parameters are in the state dict, as the module builds them."""
     padding = (kernel - 1) * dilation if causal else ((kernel - 1) // 2) * dilation
+    x_in = x
+    if p + "in_conv.0.weight" in sd:  # cnn.py:46-53, 92-93
+        x = conv1x1(x, sd[p + "in_conv.0.weight"], sd[p + "in_conv.0.bias"])
+        x = prelu(apply_norm(x, sd, p + "in_conv.1.", norm), sd[p + "in_conv.2.weight"])
     y = dilated_conv(x, sd[p + "depthwise.0.weight"], sd[p + "depthwise.0.bias"], dilation, padding)
     y = prelu(apply_norm(y, sd, p + "depthwise.1.", norm), sd[p + "depthwise.2.weight"])
     y = conv1x1(y, sd[p + "pointwise.0.weight"], sd[p + "pointwise.0.bias"])
     y = prelu(apply_norm(y, sd, p + "pointwise.1.", norm), sd[p + "pointwise.2.weight"])
     if causal:
         y = y[..., :-padding]
+    if p + "skip_conv.weight" in sd:  # cnn.py:81-82, 103-104
+        y = y + conv1x1(x_in, sd[p + "skip_conv.weight"], sd[p + "skip_conv.bias"])
     return y
 
 

@@ -75,7 +75,56 @@ __global__ __launch_bounds__(256) void attn_stats_pool_kernel(const float* __res
   }
 }
 
+// The attention map itself (forward(..., return_weight=True), lobe/pooling.py:109-113): softmax over the valid frames of
+// each (utterance, channel) row, 0 on masked frames; the frames beyond T_all of the padded output row are cleared.
+__global__ __launch_bounds__(256) void attn_weights_kernel(const float* __restrict__ logits,
+                                                           const float* __restrict__ lens, float* __restrict__ out, int C,
+                                                           int T_all, int ldt) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, n = blockIdx.y;
+  int T = T_all;
+  if (lens) {
+    const float lim = lens[n] * (float)T_all;
+    int lo = 0, hi = T_all;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((float)mid < lim) lo = mid + 1; else hi = mid;
+    }
+    T = lo;
+  }
+  const float* lr = logits + ((size_t)n * C + c) * ldt;
+  float* o = out + ((size_t)n * C + c) * ldt;
+  float m = -INFINITY;
+  for (int t = threadIdx.x; t < T; t += 256) m = fmaxf(m, lr[t]);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) s += expf(lr[t] - m);
+  s = block_sum(s, red);
+  // (no valid frame: softmax of all -inf is NaN in the reference; 0 / 0 here)
+  const float inv = 1.f / s;
+  for (int t = threadIdx.x; t < ldt; t += 256) o[t] = t < T ? expf(lr[t] - m) * inv : (t < T_all && T == 0 ? NAN : 0.f);
+}
+
 }  // namespace ps
+
+extern "C" int ps_attn_weights_f32(const float* logits, const float* lengths, float* out, int N, int C, int T, int ldt,
+                                   void* stream) {
+  using namespace ps;
+  if (!logits || !out || N <= 0 || C <= 0 || T <= 0 || ldt < T || N > 65535) {
+    set_error("ps_attn_weights_f32: bad argument (N=%d C=%d T=%d ldt=%d)", N, C, T, ldt);
+    return PS_E_INVALID;
+  }
+  {
+    LaunchTimer timer("attn_weights", (hipStream_t)stream);
+    hipLaunchKernelGGL(attn_weights_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, logits, lengths, out, C, T, ldt);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("ps_attn_weights_f32: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
 
 extern "C" int ps_attn_stats_pool_len_f32(const float* logits, const float* x, const float* lengths, float* out, int N,
                                           int C, int T, int ldt, float eps, void* stream) {

@@ -87,19 +87,23 @@ struct NormActArgs {
 __global__ __launch_bounds__(256) void norm_activation_kernel(NormActArgs a) {
   __shared__ double red[8];
   const int n = blockIdx.z, row = blockIdx.y;
-  double sa = 0.0, sq = 0.0;
-  const double* src = a.pro.stats + (size_t)n * a.pro.parts * 2;
-  for (int i = threadIdx.x; i < a.pro.parts; i += 256) {
-    sa += src[2 * i];
-    sq += src[2 * i + 1];
+  double mean = 0.0;
+  float rstd = 1.f;
+  if (a.pro.norm == PS_NORM_GLOBAL) {  // (PS_NORM_AFFINE: a folded BatchNorm, gamma / beta are its scale / shift)
+    double sa = 0.0, sq = 0.0;
+    const double* src = a.pro.stats + (size_t)n * a.pro.parts * 2;
+    for (int i = threadIdx.x; i < a.pro.parts; i += 256) {
+      sa += src[2 * i];
+      sq += src[2 * i + 1];
+    }
+    block_sum2(sa, sq, red);
+    sa -= a.corr_sum;
+    sq -= a.corr_sq;
+    mean = sa / a.pro.count;
+    double var = sq / a.pro.count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    rstd = (float)(1.0 / sqrt(var + (double)a.pro.eps));
   }
-  block_sum2(sa, sq, red);
-  sa -= a.corr_sum;
-  sq -= a.corr_sq;
-  const double mean = sa / a.pro.count;
-  double var = sq / a.pro.count - mean * mean;
-  var = var > 0.0 ? var : 0.0;
-  const float rstd = (float)(1.0 / sqrt(var + (double)a.pro.eps));
   const int ch = row / a.rows_per_channel;
   const float sc = a.pro.gamma[ch] * rstd, sh = a.pro.beta[ch] - (float)mean * sc;
   const float s = a.slope ? a.slope[0] : 0.f;
@@ -196,7 +200,9 @@ extern "C" int ps_add_f32(const float* a, const float* b, float* y, int64_t coun
 extern "C" int ps_norm_activation_f32(float* x, const ps_prologue* pro, double corr_sum, double corr_sq,
                                       int rows_per_channel, int kind, const float* slope, int N, int rows_per_utt, int T,
                                       int ld, void* stream) {
-  if (!x || !pro || pro->norm != PS_NORM_GLOBAL || !pro->stats || pro->parts <= 0 || pro->count <= 0 || !pro->gamma ||
+  const bool global = pro && pro->norm == PS_NORM_GLOBAL;
+  if (!x || !pro || (!global && pro->norm != PS_NORM_AFFINE) ||
+      (global && (!pro->stats || pro->parts <= 0 || pro->count <= 0)) || !pro->gamma ||
       !pro->beta || N <= 0 || N > 65535 || rows_per_utt <= 0 || rows_per_utt > 65535 || rows_per_channel <= 0 ||
       T <= 0 || ld < T || ld % 4 || ((uintptr_t)x & 15) || kind < 0 || kind > 5 || (kind == 2 && !slope)) {
     set_error("ps_norm_activation_f32: bad argument (N=%d rows=%d T=%d ld=%d kind=%d)", N, rows_per_utt, T, ld, kind);

@@ -310,6 +310,20 @@ def attn_stats_pool(logits: torch.Tensor, x: torch.Tensor, t: int, eps: float = 
     return out
 
 
+def attn_weights(logits: torch.Tensor, t: int, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """padded attention logits [N,C,ldt] (+ relative lengths [N]) -> padded softmax over the valid frames."""
+    require_device(logits, "attn_weights")
+    n, c, ldt = logits.shape
+    out = torch.empty_like(logits)
+    if lengths is not None:
+        lengths = lengths.detach().to(device=logits.device, dtype=torch.float32).contiguous()
+        if lengths.numel() != n:
+            raise RuntimeError(f"attn_weights: lengths must hold one value per utterance ({n}), got {tuple(lengths.shape)}")
+    check(lib().ps_attn_weights_f32(ptr(logits), ptr(lengths), ptr(out), n, c, t, ldt, stream_ptr(logits.device)),
+          "ps_attn_weights_f32")
+    return out
+
+
 def lstm(gx: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int, q: int, q_stride: int, steps: int,
          step_stride: int, h0: Optional[torch.Tensor] = None, c0: Optional[torch.Tensor] = None,
          want_state: bool = False, state_shift: int = 0, state_out: Optional[tuple] = None):

@@ -14,6 +14,7 @@ from .dpcrn import DPCRN, DPRNNblock2D
 from .dparn import DPARN, DPARNblock2D
 from .lobe.attention import MhaSelfAttenLayer
 from .lobe.rnn import SingleRNN
+from .lobe.cnn import DepthwiseSeparableConv1d
 
 # the class namespace the parity tests hand to tests/golden/cases.build()
 class _Namespace(SimpleNamespace):
@@ -28,4 +29,4 @@ NS = _Namespace(SoTaskWrapModule=SoTaskWrapModule, SiMoTaskWrapModule=SiMoTaskWr
                      ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                      AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM, MemLSTM=MemLSTM, Unet=Unet, UnetTcn=UnetTcn,
                 DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, DPARN=DPARN, DPARNblock2D=DPARNblock2D,
-                MhaSelfAttenLayer=MhaSelfAttenLayer, SingleRNN=SingleRNN, Magnitude=Magnitude, FbankEnc=FbankEnc, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate)
+                MhaSelfAttenLayer=MhaSelfAttenLayer, SingleRNN=SingleRNN, Magnitude=Magnitude, FbankEnc=FbankEnc, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate, DepthwiseSeparableConv1d=DepthwiseSeparableConv1d)

@@ -1,15 +1,19 @@
 """Depthwise-separable conv lobe (mirror of puresound/nnet/lobe/cnn.py:9-106).
 
 Holds the parameters under the reference's keys (depthwise.{0,1,2}, pointwise.{0,1,2}, optional
-in_conv / skip_conv).  The arithmetic lives in ps_dwconv_f32 and ps_conv1x1_f32 and is driven by the
-enclosing TCN block; the hid_channels / skip variants are not used by any Conv-TasNet preset.
+in_conv / skip_conv).  Inside a TCN block the arithmetic is driven by the block's fused driver
+(ps_conv_tasnet_f32); called on its own -- with the hid_channels transform and the skip connection, which no
+Conv-TasNet preset uses -- `forward` runs the same kernels stage by stage: every norm + PReLU is the consumer-side
+prologue of the next kernel, the last one is applied by ps_norm_activation_f32 / ps_chan_layernorm_f32.
 """
 from typing import Optional
 
 import torch
 import torch.nn as nn
 
-from .norm import get_norm
+from ... import hip
+from ..._abi import PS_NORM_GLOBAL
+from .norm import ChanLN, get_norm, norm_plan
 
 
 class DepthwiseSeparableConv1d(nn.Module):
@@ -42,5 +46,65 @@ class DepthwiseSeparableConv1d(nn.Module):
             self.skip_conv = nn.Conv1d(in_channels, out_channels, 1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError(
-            "DepthwiseSeparableConv1d runs fused inside TCN.forward on the HIP path; call the TCN block")
+        """x [N, C, T] -> [N, out_channels, T] (cnn.py:84-106): [in_conv] -> depthwise -> pointwise (each conv + norm +
+        PReLU) [+ skip_conv(x)].  Causal: the reference pads both sides and cuts the tail, i.e. left padding only."""
+        hip.require_device(x, "DepthwiseSeparableConv1d.forward")
+        if self.stride != 1:
+            raise NotImplementedError("DepthwiseSeparableConv1d on HIP: stride 1 only (every recipe's setting)")
+        if not self.causal and self.kernel % 2 == 0:
+            raise RuntimeError("DepthwiseSeparableConv1d: an even kernel with symmetric padding changes the length")
+        with torch.no_grad():
+            n, _, t = x.shape
+            f32 = dict(dtype=torch.float32, device=x.device)
+            xp = hip.pad_rows(x.float())
+            ldt = xp.shape[-1]
+
+            def parts(seq):
+                """conv weight [M, K], bias, (kind, gamma, beta) of the norm, PReLU slope of one conv + norm + PReLU"""
+                conv, norm, act = seq
+                if act.weight.numel() != 1:
+                    raise NotImplementedError("PReLU with per-channel slopes is not on the HIP path")
+                if isinstance(norm, ChanLN):
+                    nk = ("cln", norm.gamma.detach().to(**f32).contiguous(), norm.beta.detach().to(**f32).contiguous())
+                else:
+                    kind, g, b = norm_plan(norm)
+                    nk = (kind, g.to(**f32).contiguous(), b.to(**f32).contiguous())
+                return conv, nk, act.weight.detach().to(**f32).contiguous()
+
+            keep = []  # a prologue holds raw pointers: its tensors stay alive until the last launch is enqueued
+
+            def settle(y, stats, nk, slope, rows):
+                """(tensor, prologue) the next kernel consumes for the norm + PReLU that follow `y`"""
+                kind, g, b = nk
+                keep.extend((y, stats, g, b, slope))
+                if kind == "cln":
+                    return hip.chan_layernorm(y, t, g, b, 1e-8, slope=slope), None
+                return y, hip.make_prologue(kind, True, stats, rows * t, 1e-8, g, b, slope)
+
+            a, pro = xp, None
+            h = self.hid_channels
+            if self.transform:
+                conv, nk, slope = parts(self.in_conv)
+                y, st = hip.conv1x1(xp, t, hip.pack_wt(conv.weight.detach().to(**f32)), h, None,
+                                    conv.bias.detach().to(**f32), want_stats=nk[0] == PS_NORM_GLOBAL,
+                                    out=torch.empty(n, h, ldt, **f32))
+                a, pro = settle(y, st, nk, slope, h)
+            conv, nk, slope = parts(self.depthwise)
+            y, st = hip.dwconv(a, t, conv.weight.detach().to(**f32).contiguous(), conv.bias.detach().to(**f32).contiguous(),
+                               self.dilation, self.padding, pro, nk[0] == PS_NORM_GLOBAL)
+            a, pro = settle(y, st, nk, slope, h)
+            conv, nk, slope = parts(self.pointwise)
+            m = conv.out_channels
+            y, st = hip.conv1x1(a, t, hip.pack_wt(conv.weight.detach().to(**f32)), m, pro, conv.bias.detach().to(**f32),
+                                want_stats=nk[0] == PS_NORM_GLOBAL, out=torch.empty(n, m, ldt, **f32))
+            if nk[0] == "cln":
+                y = hip.chan_layernorm(y, t, nk[1], nk[2], 1e-8, slope=slope)
+            else:
+                keep.extend((st, nk[1], nk[2], slope))
+                last = hip.make_prologue(nk[0], False, st, m * t, 1e-8, nk[1], nk[2], None)
+                hip.norm_activation_(y.view(n, m, 1, ldt), t, last, 0.0, 0.0, "prelu", slope)
+            if self.skip:
+                sc = self.skip_conv
+                y, _ = hip.conv1x1(xp, t, hip.pack_wt(sc.weight.detach().to(**f32)), m, None, sc.bias.detach().to(**f32),
+                                   res=y, out=torch.empty(n, m, ldt, **f32))
+            return hip.unpad_rows(y, t)

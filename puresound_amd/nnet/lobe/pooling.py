@@ -2,7 +2,8 @@
 
 tdnn (1x1 conv -> ReLU -> BatchNorm1d) and the attention conv run on ps_conv1x1_f32 -- the ReLU, the folded
 eval BatchNorm and the tanh are the second GEMM's prologue -- and ps_attn_stats_pool_f32 does the softmax over
-frames and the weighted mean / std.  `lengths` (ragged batches) and `return_weight` are not on the HIP path.
+frames and the weighted mean / std (`lengths`: ragged batches); `return_weight=True` returns the softmax map itself
+(ps_attn_weights_f32).
 """
 import torch
 import torch.nn as nn
@@ -51,8 +52,8 @@ class AttentiveStatisticsPooling(nn.Module):
                               b2=self.conv.bias.detach().to(**f32).contiguous(), scale=scale, shift=shift)
         return self._plan
 
-    def forward_padded(self, x_pad: torch.Tensor, t: int, lengths=None) -> torch.Tensor:
-        """padded [N,C,ldt] (+ relative lengths [N]) -> [N,2C] (mean ; std)."""
+    def forward_padded(self, x_pad: torch.Tensor, t: int, lengths=None, return_weight: bool = False) -> torch.Tensor:
+        """padded [N,C,ldt] (+ relative lengths [N]) -> [N,2C] (mean ; std), or the padded attention map [N,C,ldt]."""
         p = self._get_plan(x_pad.device)
         n, _, ldt = x_pad.shape
         h, _ = hip.conv1x1(x_pad, t, p["w1"], self.attention_channels, None, p["b1"],
@@ -61,6 +62,8 @@ class AttentiveStatisticsPooling(nn.Module):
                                 pre_relu=True, post_tanh=True)
         logits, _ = hip.conv1x1(h, t, p["w2"], self.channels, pro, p["b2"],
                                 out=torch.empty(n, self.channels, ldt, device=x_pad.device))
+        if return_weight:
+            return hip.attn_weights(logits, t, lengths)
         return hip.attn_stats_pool(logits, x_pad, t, self.eps, lengths)
 
     def _pool(self, x: torch.Tensor, lengths=None):
@@ -69,7 +72,9 @@ class AttentiveStatisticsPooling(nn.Module):
 
     def forward(self, x: torch.Tensor, lengths=None, return_weight: bool = False):
         """x [N,C,L] (+ relative lengths [N]) -> [N,2C,1] (pooling.py:87-126)."""
-        if return_weight:
-            raise NotImplementedError("AttentiveStatisticsPooling on HIP: return_weight (the attention map itself) is "
-                                      "not built")
+        if return_weight:  # the attention map itself [N,C,L] (pooling.py:112-113)
+            hip.require_device(x, "AttentiveStatisticsPooling.forward")
+            with torch.no_grad():
+                t = x.shape[-1]
+                return hip.unpad_rows(self.forward_padded(hip.pad_rows(x), t, lengths, True), t)
         return self._pool(x, lengths)

@@ -204,6 +204,18 @@ CASES = {
                                                        tcn_norm="cLN", dconv_norm="cLN", causal=True,
                                                        tcn_layer="normal"),
                     B=2, T=33, seed=15),
+    # ---- DepthwiseSeparableConv1d on its own (lobe/cnn.py:9-106): the hid_channels transform and the skip connection
+    # that no Conv-TasNet preset uses, every norm the lobe accepts, causal and not
+    "dsc_plain_ggn": dict(kind="lobe", cls="DepthwiseSeparableConv1d", args=(12, 20),
+                          kw=dict(norm_cls="gGN", kernel=5, dilation=3), B=2, T=61, seed=61),
+    "dsc_transform_skip_gln": dict(kind="lobe", cls="DepthwiseSeparableConv1d", args=(12, 20),
+                                   kw=dict(hid_channels=18, norm_cls="gLN", kernel=3, dilation=2, skip=True),
+                                   B=2, T=70, seed=62),
+    "dsc_causal_bn": dict(kind="lobe", cls="DepthwiseSeparableConv1d", args=(10, 10),
+                          kw=dict(hid_channels=16, norm_cls="bN1d", kernel=3, dilation=4, skip=True, causal=True),
+                          B=3, T=50, seed=63, bn_stats=True),
+    "dsc_causal_cln": dict(kind="lobe", cls="DepthwiseSeparableConv1d", args=(10, 14),
+                           kw=dict(norm_cls="cLN", kernel=2, dilation=1, skip=True, causal=True), B=2, T=33, seed=64),
     # ---- recurrent maskers, module level: T mod K in {0, 1, K-1}, causal / bidirectional, FiLM / Gate
     # conditioning, embedding-free TSE (embed = enrolment features), overlapped segments
     "dprnn_causal_r0": dict(kind="rnn", cls="DPRNN", args=(16, 8, 16), kw=dict(n_blocks=2, seg_size=5, causal=True),
@@ -395,7 +407,7 @@ def build(ns, name):
         return build_masker(ns, c["masker"])
     if c["kind"] == "encdec":
         return build_encoder(ns, c["enc"])
-    if c["kind"] == "rnn":
+    if c["kind"] in ("rnn", "lobe"):
         return getattr(ns, c["cls"])(*c["args"], **c["kw"])
     if c["kind"] == "unet":
         return getattr(ns, c["cls"])(**c["kw"])

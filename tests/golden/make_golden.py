@@ -42,6 +42,7 @@ from puresound.nnet.dpcrn import DPCRN  # noqa: E402
 from puresound.nnet.dparn import DPARN  # noqa: E402
 from puresound.nnet.lobe.trivial import Magnitude  # noqa: E402
 from puresound.nnet.lobe.rnn import SingleRNN  # noqa: E402
+from puresound.nnet.lobe.cnn import DepthwiseSeparableConv1d  # noqa: E402
 
 import cases  # noqa: E402
 from detweights import det_state_dict, det_wave  # noqa: E402
@@ -50,7 +51,8 @@ REF = cases.namespace(SoTaskWrapModule=SoTaskWrapModule, SiMoTaskWrapModule=SiMo
                       ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                       AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM,
                       StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN, DPARN=DPARN,
-                      Magnitude=Magnitude, FbankEnc=FbankEnc, SingleRNN=SingleRNN)
+                      Magnitude=Magnitude, FbankEnc=FbankEnc, SingleRNN=SingleRNN,
+                      DepthwiseSeparableConv1d=DepthwiseSeparableConv1d)
 
 
 def sub(x: torch.Tensor, cs: int = 7, ts: int = 5) -> np.ndarray:
@@ -143,6 +145,15 @@ def run_fbank(name, c):
 def _uniform(seed, shape, lo=-1.0, hi=1.0):
     g = np.random.Generator(np.random.Philox(key=seed))
     return torch.tensor(g.uniform(lo, hi, shape), dtype=torch.float32)
+
+
+@torch.no_grad()
+def run_lobe(name, c):
+    """a lobe on its own: x [B, C, T] -> y"""
+    model = cases.build(REF, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    x = _uniform(c["seed"], (c["B"], c["args"][0], c["T"]))
+    return {"x": x.numpy(), "y": model(x.clone()).numpy()}
 
 
 @torch.no_grad()
@@ -301,7 +312,7 @@ def main():
     dump_state_dict_keys()
     for name, c in cases.CASES.items():
         fn = {"wrap": run_wrap, "masker": run_masker, "encdec": run_encdec, "rnn": run_rnn,
-              "stream": run_stream, "unet": run_unet, "fbank": run_fbank, "loss": run_loss, "simo": run_simo, "func": run_func}[c["kind"]]
+              "lobe": run_lobe, "stream": run_stream, "unet": run_unet, "fbank": run_fbank, "loss": run_loss, "simo": run_simo, "func": run_func}[c["kind"]]
         if only and name not in only:
             continue
         out = fn(name, c)

@@ -311,8 +311,18 @@ def test_attentive_stats_pooling_module_matches_oracle(PA, dev):
     assert out.shape == ref.shape == (3, 96, 1)
     assert rel_max(out.cpu().numpy(), ref.numpy()) < 2e-5
     assert torch.equal(pool(x.to(dev), lengths=torch.ones(3, device=dev)), out)  # (lengths: tests/test_round2_gpu.py)
-    with pytest.raises(NotImplementedError):
-        pool(x.to(dev), return_weight=True)
+    # return_weight: the attention map itself (pooling.py:109-113), without and with relative lengths
+    att = O.conv1x1(x, sd["tdnn.0.weight"], sd["tdnn.0.bias"])
+    att = O.batch_norm_eval(torch.relu(att), sd, "tdnn.2.")
+    att = O.conv1x1(torch.tanh(att), sd["conv.weight"], sd["conv.bias"])
+    w = pool(x.to(dev), return_weight=True)
+    assert w.shape == (3, 48, 333)
+    assert rel_max(w.cpu().numpy(), torch.softmax(att, 2).numpy()) < 2e-5
+    lens = torch.tensor([1.0, 0.5, 0.25])
+    w2 = pool(x.to(dev), lengths=lens.to(dev), return_weight=True).cpu()
+    for i, cnt in enumerate((333, 167, 84)):  # frame t takes part iff t < lens * L
+        assert rel_max(w2[i, :, :cnt].numpy(), torch.softmax(att[i, :, :cnt], 1).numpy()) < 2e-5
+        assert float(w2[i, :, cnt:].abs().max() if cnt < 333 else 0.0) == 0.0
     with pytest.raises(RuntimeError):
         pool(x.to(dev), lengths=torch.ones(3))  # a CPU tensor
     with pytest.raises(RuntimeError):
@@ -997,6 +1007,21 @@ def test_ns_dpcrn_preset_matches_reference_golden(PA, dev, golden_dir, name):
     out = model.inference(n3.to(dev))
     sl = slice(16, ref.shape[1] - 16)
     assert rel_max(out.cpu().numpy()[:, sl], ref.numpy()[:, sl]) < TOL
+
+
+@pytest.mark.parametrize("name", [n for n, c in cases.CASES.items() if c["kind"] == "lobe"])
+def test_depthwise_separable_lobe_on_its_own(PA, dev, golden_dir, name):
+    """DepthwiseSeparableConv1d.forward (lobe/cnn.py:84-106) with the hid_channels transform, the skip connection, every
+    norm the lobe takes, causal and not: the stage-by-stage HIP path against the reference's golden vectors."""
+    g = _load(golden_dir, name)
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    y = model(torch.tensor(g["x"]).to(dev))
+    assert y.shape == g["y"].shape
+    assert rel_max(y.cpu().numpy(), g["y"]) < TOL
+    with pytest.raises(RuntimeError):
+        model(torch.tensor(g["x"]))  # CPU tensor: no fallback
 
 
 @pytest.mark.parametrize("name", ["tse_unet_tcn_causal_short", "tse_unet_tcn_short", "tse_skim_causal_short",

@@ -117,6 +117,22 @@ def test_overlap_add_variants_agree():
 # ------------------------------------------------------------------------------------------------
 from oracle import dualpath_oracle as DP  # noqa: E402
 
+LOBE = [n for n, c in cases.CASES.items() if c["kind"] == "lobe"]
+
+
+@pytest.mark.parametrize("name", LOBE)
+def test_depthwise_separable_lobe_oracle_matches_reference(golden_dir, name):
+    """DepthwiseSeparableConv1d on its own, with the hid_channels transform and the skip connection (lobe/cnn.py:84-106)."""
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    sd = {k: v.double() for k, v in det_state_dict(cases.build(PA.NS, name)).items()}
+    kw = c["kw"]
+    y = O.ds_conv(torch.tensor(g["x"]).double(), sd, "", kw.get("kernel", 3), kw.get("dilation", 1),
+                  kw.get("causal", False), kw["norm_cls"])
+    assert y.shape == g["y"].shape
+    assert rel_max(y.numpy(), g["y"]) < TOL
+
+
 RNN = [n for n, c in cases.CASES.items() if c["kind"] == "rnn"]
 STREAM = [n for n, c in cases.CASES.items() if c["kind"] == "stream"]
 
