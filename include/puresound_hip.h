@@ -267,6 +267,11 @@ int ps_activation_f32(float* x, int kind, const float* slope, int64_t rows, int 
  * needs no statistics. */
 int ps_norm_activation_f32(float* x, const ps_prologue* pro, double corr_sum, double corr_sq, int rows_per_channel,
                            int kind, const float* slope, int N, int rows_per_utt, int T, int ld, void* stream);
+/* partial (sum, sum of squares) over the valid frames of each utterance's rows: stats [N][ps_row_stats_parts()][2] fp64,
+ * the slab layout the PS_NORM_GLOBAL prologues and ps_norm_activation_f32 read -- GlobLN called on its own
+ * (lobe/norm.py:20-34) is ps_row_stats_f64 + ps_norm_activation_f32 */
+int ps_row_stats_parts(void);
+int ps_row_stats_f64(const float* x, double* stats, int N, int rows, int T, int ld, void* stream);
 /* y = a + b over `count` floats (the additive skip connections of Unet(skip_conv=True), unet.py:249); y may alias a or b */
 int ps_add_f32(const float* a, const float* b, float* y, int64_t count, void* stream);
 

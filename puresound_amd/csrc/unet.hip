@@ -127,6 +127,32 @@ __global__ __launch_bounds__(256) void norm_activation_kernel(NormActArgs a) {
   *reinterpret_cast<f32x4*>(p) = v;
 }
 
+// partial (sum, sum of squares) of the valid frames of an utterance's rows: stats [N][kRowStatsParts][2] fp64, the
+// slab layout the global-norm prologues and ps_norm_activation_f32 consume (GlobLN called on its own)
+constexpr int kRowStatsParts = 64;
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int rows,
+                                                        int T, int ld) {
+  __shared__ double red[8];
+  const int p = blockIdx.x, n = blockIdx.y;
+  double sa = 0.0, sq = 0.0;
+  for (int r = p; r < rows; r += kRowStatsParts) {
+    const float* row = x + ((size_t)n * rows + r) * ld;
+    float fa = 0.f, fq = 0.f;  // (a row's share per thread is short: fp32 inside, fp64 across rows)
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const float v = row[t];
+      fa += v;
+      fq += v * v;
+    }
+    sa += fa;
+    sq += fq;
+  }
+  block_sum2(sa, sq, red);
+  if (threadIdx.x == 0) {
+    stats[((size_t)n * kRowStatsParts + p) * 2] = sa;
+    stats[((size_t)n * kRowStatsParts + p) * 2 + 1] = sq;
+  }
+}
+
 __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                        float* __restrict__ y, size_t n4) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -195,6 +221,21 @@ extern "C" int ps_add_f32(const float* a, const float* b, float* y, int64_t coun
   LaunchTimer timer("add", (hipStream_t)stream);
   hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, n4);
   return unet_status("ps_add_f32");
+}
+
+extern "C" int ps_row_stats_parts(void) { return ps::kRowStatsParts; }
+
+extern "C" int ps_row_stats_f64(const float* x, double* stats, int N, int rows, int T, int ld, void* stream) {
+  using namespace ps;
+  if (!x || !stats || N <= 0 || N > 65535 || rows <= 0 || T <= 0 || ld < T) {
+    set_error("ps_row_stats_f64: bad argument (N=%d rows=%d T=%d ld=%d)", N, rows, T, ld);
+    return PS_E_INVALID;
+  }
+  {
+    LaunchTimer timer("row_stats", (hipStream_t)stream);
+    hipLaunchKernelGGL(row_stats_kernel, dim3(kRowStatsParts, N), dim3(256), 0, (hipStream_t)stream, x, stats, rows, T, ld);
+  }
+  return unet_status("ps_row_stats_f64");
 }
 
 extern "C" int ps_norm_activation_f32(float* x, const ps_prologue* pro, double corr_sum, double corr_sq,

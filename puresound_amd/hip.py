@@ -523,6 +523,15 @@ def activation_(x: torch.Tensor, kind: str, slope: Optional[torch.Tensor], t: in
     return x
 
 
+def row_stats(x: torch.Tensor, t: int) -> torch.Tensor:
+    """padded rows [N, rows, ld] -> [N, parts, 2] fp64 partial (sum, sum of squares) over the t valid frames."""
+    require_device(x, "row_stats")
+    n, rows, ld = x.shape
+    out = torch.empty(n, lib().ps_row_stats_parts(), 2, dtype=torch.float64, device=x.device)
+    check(lib().ps_row_stats_f64(ptr(x), ptr(out), n, rows, t, ld, stream_ptr(x.device)), "ps_row_stats_f64")
+    return out
+
+
 def norm_activation_(x4: torch.Tensor, t: int, pro: Prologue, corr_sum: float, corr_sq: float, kind: str,
                      slope: Optional[torch.Tensor]) -> torch.Tensor:
     """gLN over [CH, F, T] + activation, in place on [N, CH, F, ld]."""

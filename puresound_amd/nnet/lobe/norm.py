@@ -1,13 +1,14 @@
 """Normalisation lobes (mirror of puresound/nnet/lobe/norm.py:5-112).
 
-On the HIP path a norm is never a kernel of its own: its statistics are produced by the epilogue of
+Inside the models a norm is never a kernel of its own: its statistics are produced by the epilogue of
 the convolution in front of it and it is applied in the prologue of the convolution behind it
-(csrc/conv1x1.hip, csrc/dwconv.hip).  These classes therefore only hold the parameters, under the
-reference's state_dict keys, and say how the kernels should treat them.
+(csrc/conv1x1.hip, csrc/dwconv.hip).  Called on their own the classes run: GlobLN = ps_row_stats_f64 +
+ps_norm_activation_f32, ChanLN / InstantLN = ps_chan_layernorm_f32.
 """
 import torch
 import torch.nn as nn
 
+from ... import hip
 from ..._abi import PS_NORM_AFFINE, PS_NORM_GLOBAL
 
 
@@ -21,22 +22,56 @@ class _LayerNorm(nn.Module):
         self.gamma = nn.Parameter(torch.ones(channel_size), requires_grad=True)
         self.beta = nn.Parameter(torch.zeros(channel_size), requires_grad=True)
 
-    def forward(self, x):
-        raise NotImplementedError(
-            f"{type(self).__name__} is fused into the neighbouring convolution kernels on the HIP path; "
-            "it is not callable on its own")
+    def _params(self, x):
+        f32 = dict(dtype=torch.float32, device=x.device)
+        return self.gamma.detach().to(**f32).contiguous(), self.beta.detach().to(**f32).contiguous()
+
+    def _per_position(self, x: torch.Tensor, channels: int) -> torch.Tensor:
+        """statistics over `channels` (dim 1 of the [N, channels, positions] view) at every position"""
+        hip.require_device(x, type(self).__name__ + ".forward")
+        with torch.no_grad():
+            g, b = self._params(x)
+            if g.numel() != channels:
+                raise RuntimeError(f"{type(self).__name__}: {channels} channels, {g.numel()} gains")
+            rows = x.float().reshape(x.shape[0], channels, -1)
+            t = rows.shape[-1]
+            return hip.unpad_rows(hip.chan_layernorm(hip.pad_rows(rows), t, g, b, self.eps), t).reshape(x.shape)
 
 
 class GlobLN(_LayerNorm):
-    """gLN: per-utterance statistics over [C,T] (norm.py:20-34)."""
+    """gLN: per-utterance statistics over everything but the batch axis (norm.py:20-34)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """[N, C, *] -> same shape: (x - mean) / sqrt(var + eps) * gamma[c] + beta[c]."""
+        hip.require_device(x, "GlobLN.forward")
+        if x.dim() < 3:
+            raise RuntimeError("GlobLN: input of at least three dimensions [batch, chan, *]")
+        with torch.no_grad():
+            g, b = self._params(x)
+            n, c, t = x.shape[0], x.shape[1], x.shape[-1]
+            inner = x[0, 0].numel() // t                      # rows per channel
+            rows = hip.pad_rows(x.float().reshape(n, c * inner, t))
+            stats = hip.row_stats(rows, t)
+            pro = hip.make_prologue(PS_NORM_GLOBAL, False, stats, float(c * inner * t), self.eps, g, b, None)
+            hip.norm_activation_(rows.view(n, c, inner, rows.shape[-1]), t, pro, 0.0, 0.0, "none", None)
+            return hip.unpad_rows(rows, t).reshape(x.shape)
 
 
 class ChanLN(_LayerNorm):
-    """cLN: per-frame statistics over C (norm.py:37-50).  Parameters only; no HIP kernel yet."""
+    """cLN: statistics over the channel axis at every position (norm.py:37-50)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._per_position(x, x.shape[1])
 
 
 class InstantLN(_LayerNorm):
-    """iLN (norm.py:53-68).  Parameters only; off the Conv-TasNet path."""
+    """iLN (norm.py:53-68): [N, CH, C, T], statistics over CH * C at every frame."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 4:
+            raise ValueError("InstantLN: [N, CH, C, T] input")  # (the reference fails unpacking the shape)
+        n, ch, c, t = x.shape
+        return self._per_position(x.reshape(n, ch * c, t), ch * c).reshape(n, ch, c, t)
 
 
 # Aliases, as norm.py:90-97

@@ -1009,6 +1009,41 @@ def test_ns_dpcrn_preset_matches_reference_golden(PA, dev, golden_dir, name):
     assert rel_max(out.cpu().numpy()[:, sl], ref.numpy()[:, sl]) < TOL
 
 
+def test_norm_lobes_on_their_own(dev):
+    """GlobLN / ChanLN / InstantLN called directly (lobe/norm.py:20-68), 3-D and 4-D inputs, against the formulas."""
+    from puresound_amd.nnet.lobe.norm import ChanLN, GlobLN, InstantLN
+    x3, x4 = _rand((3, 10, 77), 201, -2.0, 3.0), _rand((2, 6, 5, 41), 202, -1.0, 4.0)
+
+    def fill(m, seed):
+        m.gamma.data = _rand((m.channel_size,), seed, 0.5, 1.5)
+        m.beta.data = _rand((m.channel_size,), seed + 1, -0.3, 0.3)
+        return m.to(dev)
+
+    for x in (x3, x4):
+        c = x.shape[1]
+        view = [1, c] + [1] * (x.dim() - 2)
+        m = fill(GlobLN(c), 203)
+        dims = list(range(1, x.dim()))
+        mean = x.double().mean(dims, keepdim=True)
+        var = ((x.double() - mean) ** 2).mean(dims, keepdim=True)
+        ref = (x.double() - mean) / (var + 1e-8).sqrt() * m.gamma.detach().cpu().double().view(view) + m.beta.detach().cpu().double().view(view)
+        assert rel_max(m(x.to(dev)).cpu().numpy(), ref.numpy()) < 2e-6
+        m = fill(ChanLN(c), 205)
+        mean = x.double().mean(1, keepdim=True)
+        var = x.double().var(1, keepdim=True, unbiased=False)
+        ref = (x.double() - mean) / (var + 1e-8).sqrt() * m.gamma.detach().cpu().double().view(view) + m.beta.detach().cpu().double().view(view)
+        assert rel_max(m(x.to(dev)).cpu().numpy(), ref.numpy()) < 2e-6
+    n, ch, c, t = x4.shape
+    m = fill(InstantLN(ch * c), 207)
+    flat = x4.double().reshape(n, ch * c, t)
+    mean, var = flat.mean(1, keepdim=True), flat.var(1, keepdim=True, unbiased=False)
+    ref = ((flat - mean) / (var + 1e-8).sqrt() * m.gamma.detach().cpu().double().view(1, -1, 1)
+           + m.beta.detach().cpu().double().view(1, -1, 1)).reshape(n, ch, c, t)
+    assert rel_max(m(x4.to(dev)).cpu().numpy(), ref.numpy()) < 2e-6
+    with pytest.raises(RuntimeError):
+        GlobLN(10)(x3)  # CPU tensor: no fallback
+
+
 @pytest.mark.parametrize("name", [n for n, c in cases.CASES.items() if c["kind"] == "lobe"])
 def test_depthwise_separable_lobe_on_its_own(PA, dev, golden_dir, name):
     """DepthwiseSeparableConv1d.forward (lobe/cnn.py:84-106) with the hid_channels transform, the skip connection, every
