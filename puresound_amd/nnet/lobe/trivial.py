@@ -16,13 +16,16 @@ from .norm import ChanLN
 
 
 def _magnitude_shape(ctor, x, aux, params):
-    return (x[0], x[1] // 2 - int(bool(ctor.get("drop_first", True))), x[2])
+    drop = int(bool(ctor.get("drop_first", True)))
+    if len(x) == 4:  # [N, H, T, 2]
+        return (x[0], x[1] - drop, x[2])
+    return (x[0], x[1] // 2 - drop, x[2])
 
 
 @op_module("magnitude_fwd", _magnitude_shape)
 class Magnitude(nn.Module):
-    """STFT [re; im] -> magnitude (lobe/trivial.py:21-59).  3-D input [N, 2H, T] (channel halves) only: that is what
-    the wrapper hands the speaker net."""
+    """STFT [re; im] -> magnitude (lobe/trivial.py:21-59): 3-D input [N, 2H, T] (channel halves, what the wrapper
+    hands the speaker net) or the encoder's own 4-D [N, H, T, 2]."""
 
     def __init__(self, drop_first: bool = True, log1p: bool = False) -> None:
         super().__init__()
@@ -36,9 +39,11 @@ class Magnitude(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         hip.require_device(x, "Magnitude.forward")
-        if x.dim() != 3:
-            if x.dim() == 4:
-                raise NotImplementedError("Magnitude on HIP: [N, 2H, T] input (the [N, H, T, 2] form is not built)")
+        if x.dim() == 4:  # [N, H, T, 2] -> the channel-halves form (trivial.py:40-42)
+            if x.shape[-1] != 2:
+                raise TypeError
+            x = torch.cat([x[..., 0], x[..., 1]], dim=1)
+        elif x.dim() != 3:
             raise TypeError
         t = x.shape[-1]
         return hip.unpad_rows(self.forward_padded(hip.pad_rows(x), t), t)

@@ -374,3 +374,21 @@ def test_step_frame_graph_follows_parameter_updates_and_states_are_assignable(de
     assert not torch.allclose(after, first[-1])
     with pytest.raises(ValueError):
         m2.masker.seg_lstm_h_states = [torch.zeros(3, 5)] * len(saved_h)
+
+
+def test_magnitude_lobe_takes_the_encoders_four_dimensional_output(PA, dev):
+    """Magnitude (lobe/trivial.py:21-59) on [N, H, T, 2] and on the channel-halves form [N, 2H, T]."""
+    x = det_wave(31, 2 * 9 * 2, 40).reshape(2, 9, 2, 40).permute(0, 1, 3, 2).contiguous()   # [N, H, T, 2]
+    for drop, log1p in ((True, False), (False, True)):
+        lobe = PA.NS.Magnitude(drop_first=drop, log1p=log1p)
+        re, im = x[..., 0], x[..., 1]
+        if drop:
+            re, im = re[:, 1:], im[:, 1:]
+        ref = torch.sqrt(re ** 2 + im ** 2 + 1e-8)
+        ref = torch.log1p(ref) if log1p else ref
+        y4 = lobe(x.to(dev))
+        y3 = lobe(torch.cat([x[..., 0], x[..., 1]], 1).to(dev))
+        assert y4.shape == ref.shape and torch.equal(y4, y3)
+        assert float((y4.cpu() - ref).abs().max()) < 1e-6
+    with pytest.raises(TypeError):
+        PA.NS.Magnitude()(x[..., :1].to(dev))
