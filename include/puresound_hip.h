@@ -216,6 +216,10 @@ int ps_conv1x1_bf16_f32(const float* x, const void* wt_planes, float* y, int N, 
  * ------------------------------------------------------------------------------------------- */
 int ps_unfold_taps_f32(const float* x, float* y, int N, int K, int T, int ldt, int P, int dilation, int left,
                        const float* scale, const float* shift, const float* embed, int E, void* stream);
+/* the same with T_out >= T output frames per row (inputs beyond T read as zero): the reference's causal gated block pads
+ * both sides and trims only after its output conv, so its norms see T + padding frames (conv_tasnet.py:203-211) */
+int ps_unfold_taps_out_f32(const float* x, float* y, int N, int K, int T, int T_out, int ldt, int P, int dilation, int left,
+                           const float* scale, const float* shift, const float* embed, int E, void* stream);
 int ps_gated_product_f32(const float* left, const float* right, float* y, int N, int H, int T, int ldt,
                          const ps_prologue* pro_left, const ps_prologue* pro_right, void* stream);
 

@@ -89,6 +89,7 @@ SIGNATURES = {
     "ps_attn_weights_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ps_lstm_f32": (C.c_int, [C.POINTER(LstmArgs), _vp]),
     "ps_unfold_taps_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 7 + [_vp, _vp, _vp, C.c_int, _vp]),
+    "ps_unfold_taps_out_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 8 + [_vp, _vp, _vp, C.c_int, _vp]),
     "ps_gated_product_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [C.POINTER(Prologue), C.POINTER(Prologue), _vp]),
     "ps_segment_overlap_f32": (C.c_int, [_vp, _vp, C.c_int64] + [C.c_int] * 6 + [_vp]),
     "ps_film_conv_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),

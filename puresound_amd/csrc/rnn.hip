@@ -700,14 +700,16 @@ namespace ps {
 __global__ __launch_bounds__(256) void unfold_taps_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
-                                                          const float* __restrict__ embed, int K, int E, int T, int ldt,
-                                                          int P, int dilation, int left) {
+                                                          const float* __restrict__ embed, int K, int E, int T, int T_out,
+                                                          int ldt, int P, int dilation, int left) {
+  // T = valid input frames, T_out >= T = output frames (the causal gated block of the reference pads both sides and
+  // trims only after its output conv: its norms see T + padding frames, conv_tasnet.py:203-211)
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int row = blockIdx.y;  // j * (K + E) + k
   const int n = blockIdx.z;
   const int Kc = K + E;
   const int j = row / Kc, k = row % Kc;
-  if (t >= T) return;
+  if (t >= T_out) return;
   const int src = t + j * dilation - left;
   float v = 0.f;
   if (src >= 0 && src < T) {
@@ -759,7 +761,13 @@ __global__ __launch_bounds__(256) void gated_product_kernel(GateArgs a) {
 
 extern "C" int ps_unfold_taps_f32(const float* x, float* y, int N, int K, int T, int ldt, int P, int dilation, int left,
                                   const float* scale, const float* shift, const float* embed, int E, void* stream) {
-  if (!x || !y || N <= 0 || K <= 0 || T <= 0 || ldt < T || P <= 0 || dilation <= 0 || left < 0 || E < 0 ||
+  return ps_unfold_taps_out_f32(x, y, N, K, T, T, ldt, P, dilation, left, scale, shift, embed, E, stream);
+}
+
+extern "C" int ps_unfold_taps_out_f32(const float* x, float* y, int N, int K, int T, int T_out, int ldt, int P,
+                                      int dilation, int left, const float* scale, const float* shift,
+                                      const float* embed, int E, void* stream) {
+  if (!x || !y || N <= 0 || K <= 0 || T <= 0 || T_out < T || ldt < T_out || P <= 0 || dilation <= 0 || left < 0 || E < 0 ||
       (E > 0 && !embed) || ((scale == nullptr) != (shift == nullptr)) || (long long)P * (K + E) > 65535 || N > 65535) {
     set_error("ps_unfold_taps_f32: bad argument (N=%d K=%d T=%d P=%d dilation=%d left=%d E=%d)", N, K, T, P, dilation,
               left, E);
@@ -767,8 +775,8 @@ extern "C" int ps_unfold_taps_f32(const float* x, float* y, int N, int K, int T,
   }
   {
     LaunchTimer timer("unfold_taps", (hipStream_t)stream);
-    hipLaunchKernelGGL(unfold_taps_kernel, dim3((T + 255) / 256, P * (K + E), N), dim3(256), 0, (hipStream_t)stream, x,
-                       y, scale, shift, embed, K, E, T, ldt, P, dilation, left);
+    hipLaunchKernelGGL(unfold_taps_kernel, dim3((T_out + 255) / 256, P * (K + E), N), dim3(256), 0, (hipStream_t)stream,
+                       x, y, scale, shift, embed, K, E, T, T_out, ldt, P, dilation, left);
   }
   return launch_status("ps_unfold_taps_f32");
 }

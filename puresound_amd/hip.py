@@ -375,15 +375,17 @@ def chan_layernorm(x: torch.Tensor, t: int, gamma: torch.Tensor, beta: torch.Ten
 
 
 def unfold_taps(x: torch.Tensor, t: int, taps: int, dilation: int, left: int, scale: Optional[torch.Tensor] = None,
-                shift: Optional[torch.Tensor] = None, embed: Optional[torch.Tensor] = None) -> torch.Tensor:
+                shift: Optional[torch.Tensor] = None, embed: Optional[torch.Tensor] = None,
+                t_out: Optional[int] = None) -> torch.Tensor:
     """x padded [N,K,ldt] -> [N, taps*(K+E), ldt]: tap-shifted copies (zero outside [0,T)), optional per-(n,k) affine
-    before the padding, optional constant embedding rows."""
+    before the padding, optional constant embedding rows.  t_out > t: that many output frames per row."""
     require_device(x, "unfold_taps")
     n, k, ldt = x.shape
     e = 0 if embed is None else embed.shape[1]
+    t_out = t if t_out is None else t_out
     y = torch.empty(n, taps * (k + e), ldt, dtype=torch.float32, device=x.device)
-    check(lib().ps_unfold_taps_f32(ptr(x), ptr(y), n, k, t, ldt, taps, dilation, left, ptr(scale), ptr(shift),
-                                   ptr(embed), e, stream_ptr(x.device)), "ps_unfold_taps_f32")
+    check(lib().ps_unfold_taps_out_f32(ptr(x), ptr(y), n, k, t, t_out, ldt, taps, dilation, left, ptr(scale), ptr(shift),
+                                       ptr(embed), e, stream_ptr(x.device)), "ps_unfold_taps_out_f32")
     return y
 
 

@@ -280,9 +280,6 @@ class GatedTCN(_PlanCache, nn.Module):
                 g, b = mod.gamma.detach(), mod.beta.detach()
             else:
                 kind, g, b = norm_plan(mod)
-                if kind == PS_NORM_GLOBAL and self.causal:
-                    # the reference normalises over the T + padding frames it trims only after out_conv
-                    raise NotImplementedError("GatedTCN on HIP: gLN/gGN with causal=True is not supported")
                 t[side + "_kind"] = kind
             t[side + "_gamma"], t[side + "_beta"] = g.to(**f32).contiguous(), b.to(**f32).contiguous()
         if self.use_film:
@@ -297,6 +294,16 @@ class GatedTCN(_PlanCache, nn.Module):
         n, c, ldt = x.shape
         h, k, d = self.hid_channels, self.kernel, self.dilation
         left = self.padd
+        # causal with a global norm (the constructor's default norm): the reference pads BOTH sides of its dense convs
+        # and trims only after out_conv (conv_tasnet.py:203-211), so gLN's statistics run over T + padding frames, the
+        # last `padding` of them convolutions over the zero-padded tail.  Reproduced: the conv / norm / product stages
+        # cover tt = T + padding frames, out_conv the first T.
+        tt, ld_in = t, ldt
+        if self.causal and p["left_kind"] == PS_NORM_GLOBAL:
+            tt = t + self.padd
+            if hip.padded_frames(tt) > ldt:  # rows with room for the tail
+                x = hip.pad_rows(hip.unpad_rows(x, t), tt)
+                ldt = x.shape[-1]
         new = lambda rows: torch.empty(n, rows, ldt, dtype=torch.float32, device=x.device)  # noqa: E731
         y, _ = hip.conv1x1(x, t, p["w_in"], h, out=new(h))
         scale = shift = emb_rows = None
@@ -307,24 +314,28 @@ class GatedTCN(_PlanCache, nn.Module):
                 scale, shift = sb[:, :h].contiguous(), sb[:, h:].contiguous()
             else:
                 emb_rows = embed
-        col_l = hip.unfold_taps(y, t, k, d, left)
+        col_l = hip.unfold_taps(y, t, k, d, left, t_out=tt)
         col_r = col_l if (scale is None and emb_rows is None) else hip.unfold_taps(y, t, k, d, left, scale, shift,
-                                                                                  emb_rows)
+                                                                                  emb_rows, t_out=tt)
         cln = p["left_kind"] == "cln"
         want = (not cln) and p["left_kind"] == PS_NORM_GLOBAL
-        lo, ls = hip.conv1x1(col_l, t, p["w_left"], h, want_stats=want, out=new(h))
-        ro, rs = hip.conv1x1(col_r, t, p["w_right"], h, want_stats=want, out=new(h))
+        lo, ls = hip.conv1x1(col_l, tt, p["w_left"], h, want_stats=want, out=new(h))
+        ro, rs = hip.conv1x1(col_r, tt, p["w_right"], h, want_stats=want, out=new(h))
         if cln:
             lf = hip.chan_layernorm(lo, t, p["left_gamma"], p["left_beta"], 1e-8, slope=p["left_slope"])
             g = hip.chan_layernorm(ro, t, p["right_gamma"], p["right_beta"], 1e-8, slope=p["right_slope"],
                                    sigmoid=True, mul=lf)
         else:
-            pl = hip.make_prologue(p["left_kind"], True, ls, h * t, 1e-8, p["left_gamma"], p["left_beta"],
+            pl = hip.make_prologue(p["left_kind"], True, ls, h * tt, 1e-8, p["left_gamma"], p["left_beta"],
                                    p["left_slope"])
-            pr = hip.make_prologue(p["right_kind"], True, rs, h * t, 1e-8, p["right_gamma"], p["right_beta"],
+            pr = hip.make_prologue(p["right_kind"], True, rs, h * tt, 1e-8, p["right_gamma"], p["right_beta"],
                                    p["right_slope"])
-            g = hip.gated_product(lo, ro, t, pl, pr)
+            g = hip.gated_product(lo, ro, tt, pl, pr)
         out, _ = hip.conv1x1(g, t, p["w_out"], c, res=x, out=new(c))
+        if ldt != ld_in:  # back to the caller's row length
+            out = hip.pad_rows(hip.unpad_rows(out, t), ld_in)
+            if out.shape[-1] != ld_in:
+                raise RuntimeError("GatedTCN: the caller's rows are shorter than padded_frames(T)")
         return out
 
     def forward(self, x: torch.Tensor, embed: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -199,6 +199,13 @@ CASES = {
                                                                 per_tcn_stack=2, tcn_norm="bN1d", causal=True,
                                                                 tcn_layer="gated"),
                              B=2, T=45, seed=14),
+    # causal with the constructor's default gLN: the reference's gated block normalises over the T + padding frames it
+    # trims only after out_conv (conv_tasnet.py:203-211); T + padding crosses a row-length boundary here
+    "ctn_gated_causal_gln": dict(kind="masker", masker=masker_args(16, 6, True, [1, 0], tcn_kernel=3, tcn_dim=8,
+                                                                    repeat_tcn=2, tcn_dilated_basic=2,
+                                                                    per_tcn_stack=2, tcn_norm="gLN", causal=True,
+                                                                    tcn_layer="gated"),
+                                 B=2, T=127, seed=15),
     "tcn_cln": dict(kind="masker", masker=masker_args(16, 0, False, [0, 0], tcn_kernel=3, tcn_dim=8,
                                                        repeat_tcn=1, tcn_dilated_basic=2, per_tcn_stack=2,
                                                        tcn_norm="cLN", dconv_norm="cLN", causal=True,

@@ -230,7 +230,7 @@ def test_abi_rejects_bad_arguments(H, dev):
 # ------------------------------------------------------------------------------------------------
 # masker and wrapper against the reference's golden vectors
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["ctn_embed", "ctn_dil3_k5", "ctn_gated", "ctn_gated_causal", "tcn_cln"])
+@pytest.mark.parametrize("name", ["ctn_embed", "ctn_dil3_k5", "ctn_gated", "ctn_gated_causal", "ctn_gated_causal_gln", "tcn_cln"])
 def test_masker_matches_reference_golden(PA, dev, golden_dir, name):
     g = _load(golden_dir, name)
     model = cases.build(PA.NS, name).eval()
