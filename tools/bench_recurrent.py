@@ -24,6 +24,8 @@ def cfg4(args):
     model.load_state_dict(det_state_dict(model))
     model.to(dev)
     model.masker.set_gemm_precision(args.gemm)
+    if args.hip_streams:
+        model.hip_streams = args.hip_streams
     g = torch.Generator().manual_seed(1234)
     noisy = ((torch.rand(args.batch, 64000, generator=g) * 2 - 1) * 0.5).to(dev)
     for _ in range(args.warmup):
@@ -35,8 +37,21 @@ def cfg4(args):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
     line = {"config": "cfg4 DPRNN(128,64,128,6 blocks,K=20,causal) fp32 storage", "input_projection_gemm": args.gemm,
-            "batch": args.batch, "ms_per_forward": ms,
+            "batch": args.batch, "ms_per_forward": ms, "hip_streams": int(getattr(model, "hip_streams", 2)),
             "samples_per_s": args.batch * 64000 / ms * 1e3}
+    # the same forward replayed as one hipGraph (45 short kernels: the eager path leaves gaps between them)
+    from puresound_amd.graphs import GraphedInference
+    fast = GraphedInference(model)
+    for _ in range(3):
+        fast(noisy)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fast(noisy)
+    torch.cuda.synchronize()
+    msg = (time.perf_counter() - t0) / args.steps * 1e3
+    line["hipgraph_ms_per_forward"] = msg
+    line["hipgraph_samples_per_s"] = args.batch * 64000 / msg * 1e3
     if args.profile:
         import ctypes as C
         lib = _abi.lib()
@@ -131,6 +146,7 @@ def cfg5(args):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default="cfg4,cfg5")
+    ap.add_argument("--hip-streams", type=int, default=0, help="cfg4: HIP streams the batch is split over (0 = the model's default)")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
