@@ -11,7 +11,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpuresound_hip.so")
+# PURESOUND_HIP_LIB: an experimental build of the same library (tools/build_variant.sh); kernel experiments only
+LIB_PATH = os.environ.get("PURESOUND_HIP_LIB") or os.path.join(_HERE, "libpuresound_hip.so")
 ABI_VERSION = 6
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2

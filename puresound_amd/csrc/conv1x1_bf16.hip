@@ -1433,6 +1433,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_bf16_solo_kernel(BfArgs a) {
 }
 
 #include "conv1x1_bf16_il.inc"
+#include "conv1x1_f16x2_w1.inc"
 
 static int bf16_cus() { return device_cus(); }
 
@@ -1481,6 +1482,13 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
     // utterances; the in / pointwise drains are issue-bound and gain nothing)
     const_cast<BfArgs&>(a).delay = (PLANES >= 2 && res && per_wg >= 4) ? 16000 : 0;
     const_cast<BfArgs&>(a).groups = 4;
+#ifdef PS_TUNE  // tuning builds only: phase offset / phase count from the environment (res / stats / plain launches)
+    {
+      const char* key = res ? "PS_IL_DELAY_RES" : stats ? "PS_IL_DELAY_STATS" : "PS_IL_DELAY_PLAIN";
+      if (const char* v = getenv(key)) const_cast<BfArgs&>(a).delay = atoi(v);
+      if (const char* v = getenv("PS_IL_GROUPS")) const_cast<BfArgs&>(a).groups = atoi(v);
+    }
+#endif
     // out_conv (two m-tiles) reads every activation tile twice, once per m-tile.  Workgroups go to the XCDs round robin
     // (blockIdx & 7), each XCD has its own L2: with the plain numbering the two readers of a tile sit on different XCDs
     // and both reads come from HBM.  Renumbered so that they are 8 apart -- same XCD, dispatched together, running the
@@ -1489,6 +1497,25 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
     const bool pairable = G == 256 && a.tiles_m == 2 && nsuper % 256 == 0 && per > 0 && st_per % per == 0 &&
                           !(g_debug_flags & 64);
     const_cast<BfArgs&>(a).pair_r = pairable ? st_per / per : 0;
+    // fp16x2 on fp32 rows: ps_debug_flags bit 7 selects the one-wave-per-SIMD kernel (conv1x1_f16x2_w1.inc; tests run
+    // both).  Measured in the same process on the benchmark's step: 126-130 us per launch against 124 for the interleaved
+    // kernel -- two unrelated schedules land within 3 % of each other (profiles/r03_gemm_two_designs.txt).
+    if constexpr (PLANES == 2 && !XB && !YB) if (g_debug_flags & 128) {
+#define PS_W1(TRV, STV, RSV) \
+  hipLaunchKernelGGL((conv1x1_f16x2_w1_kernel<TRV, STV, RSV>), dim3(G, 1), dim3(256), 0, stream, a)
+      const_cast<BfArgs&>(a).delay = 0;
+      if (tr) {
+        if (stats) PS_W1(true, true, false);
+        else if (res) PS_W1(true, false, true);
+        else PS_W1(true, false, false);
+      } else {
+        if (stats) PS_W1(false, true, false);
+        else if (res) PS_W1(false, false, true);
+        else PS_W1(false, false, false);
+      }
+#undef PS_W1
+      return;
+    }
 #define PS_IL(TRV, STV, RSV) \
   hipLaunchKernelGGL((conv1x1_bf16_il_kernel<PLANES, TRV, STV, RSV, XB, (YB && !RSV)>), dim3(G, 1), dim3(512), 0, stream, a)
     if (tr) {

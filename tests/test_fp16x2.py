@@ -101,7 +101,9 @@ def test_fp16x2_gemm_is_as_close_to_fp64_as_the_fp32_kernel(dev, n, k, m, t, mod
     first = None
     # 0 = the persistent interleaved kernel where the launch is large enough, bit 27 = the one-tile-per-workgroup
     # kernel (256 x 32 tiles for small grids), bits 27 | 29 = its 256 x 128 tile
-    for flags in (0, 1 << 27, (1 << 27) | (1 << 29)):
+    # bit 7 = the one-wave-per-SIMD persistent kernel (conv1x1_f16x2_w1.inc) instead of the interleaved one, bit 28 = a
+    # persistent kernel at any launch size (where the shape allows one)
+    for flags in (0, 1 << 27, (1 << 27) | (1 << 29), 128, 1 << 28, 128 | (1 << 28)):
         old = _abi.lib().ps_debug_flags(flags)
         try:
             y, st, am = H.conv1x1_f16x2(xd, t, wf, we, m, pro, b.to(dev), None, resd, want_stats=want, want_amax=True,

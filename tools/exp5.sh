@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+timeout -k 10 200 python tools/dbg_w1.py 2>&1 | grep "max err"
+for i in 1 2; do
+  PS_FLAGS=0 timeout -k 10 200 python tools/step_time.py fp16x2 20 2>&1 | grep "ms/step"
+  PS_FLAGS=128 timeout -k 10 200 python tools/step_time.py fp16x2 20 2>&1 | grep "ms/step"
+done
+timeout -k 10 300 python tools/time_f16x2.py 2>&1 | grep -v amdgpu.ids
+timeout -k 10 300 python tools/time_f16x2.py 128 2>&1 | grep -v amdgpu.ids
