@@ -37,16 +37,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, batch, results):
+def _worker(rank, world, port, batch, results, name="tiny_free", length=900):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        name = "tiny_free"
         sd = det_state_dict(cases.build(PA.NS, name))
         cfg = cases.oracle_cfg(name)
-        noisy = det_wave(21, batch, 900)
+        noisy = det_wave(21, batch, length)
 
         def infer(x):
             return O.inference(x, sd, cfg)
@@ -68,6 +67,21 @@ def test_sharded_inference_two_ranks_gloo(batch):
     mgr = mp.Manager()
     results = mgr.dict()
     mp.spawn(_worker, args=(world, port, batch, results), nprocs=world, join=True)
+    assert len(results) == world
+    for r in range(world):
+        same_as_unsharded, deterministic, shape = results[r]
+        assert same_as_unsharded and deterministic and shape[0] == batch
+
+
+@pytest.mark.parametrize("batch", [4, 3])
+def test_config4_dprnn_sharded_two_ranks_gloo(batch):
+    """BASELINE config 4 (the DPRNN separator, data-parallel): the split tools/bench_recurrent.py --gpus N times, with the
+    oracle as each rank's compute -- equal and ragged shards reassemble to the unsharded result."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, port, batch, results, "cfg4_short", 1300), nprocs=world, join=True)
     assert len(results) == world
     for r in range(world):
         same_as_unsharded, deterministic, shape = results[r]

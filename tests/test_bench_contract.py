@@ -38,6 +38,10 @@ def test_bench_line(gemm):
         # three products per multiply-add: the GEMMs' HBM floor is above their matrix-pipe floor
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
         assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+        # (3C + 4H) elements per frame over the three launches of a block (C = 512, H = 256, T = 3999, 32 x fp32)
+        assert r["algorithmic_bytes_per_launch"] == 32 * 3999 * 4.0 * (3 * 512 + 4 * 256) / 3
+        assert abs(r["step_algorithmic_bytes"] - 38.54e9) < 0.01e9
+        assert abs(r["step_frac"] - r["step_algorithmic_bytes"] / (d["ms_per_step"] * 1e-3) / 8e12) < 1e-9
         assert r["mfma_side"]["peak_TFLOPs"] == 2500.0 / 3 and r["mfma_side"]["floor_ms"] < r["algorithmic_bytes_per_launch"] / 8e12 * 1e3
     else:
         assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
@@ -49,6 +53,13 @@ def test_bench_line(gemm):
         dev = d["deviation_from_fp32_mfma_path"]
         assert 0 <= dev["max_abs"] < 1e-4 and 0 <= dev["l2_rel"] < 1e-4
     assert "cpu_baseline" not in d  # (--no-cpu-baseline)
+    if gemm == "fp16x2":  # the default run carries bounded timings of the other BASELINE configurations
+        oc = d["other_configs"]
+        assert oc["cfg3"]["fp16x2"]["ms"] > 0 and oc["cfg3"]["bf16"]["l2_rel_vs_fp32"] < 3e-2
+        assert oc["cfg4"]["ms"] > 0 and oc["cfg4"]["us_per_serial_step"] > 0 and oc["cfg4"]["serial_steps"] == 1320
+        assert oc["cfg5"]["chunks"] >= 300 and 0 < oc["cfg5"]["p50_ms"] <= oc["cfg5"]["p90_ms"] <= oc["cfg5"]["max_ms"]
+    else:
+        assert "other_configs" not in d
     assert "profiles/" in r["traffic_note"] and r["kernel"].startswith("ps::conv1x1")
     assert d["config"]["hip_streams_per_gpu"] == 1  # timed path, events and a kernel trace describe the same launches
     assert d["distributed"] == {"world_size": 1, "backend": None, "collective": None,

@@ -1,0 +1,116 @@
+"""Timed lines for BASELINE configs 3, 4 and 5 (bench.py's `other_configs`, tools/bench_recurrent.py, tools/bench_cfg3.py).
+Every function builds the named configuration with the deterministic weights, runs on the given device and returns a
+dict of plain numbers; nothing here prints."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+L = 64000
+
+
+def _waves(n, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(n, L, generator=g) * 2 - 1) * 0.5).to(dev)
+
+
+def _build(name, dev):
+    import cases
+    from detweights import det_state_dict
+    import puresound_amd.nnet as PA
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    return model.to(dev)
+
+
+def _timed(fn, steps, warmup):
+    for _ in range(warmup):
+        out = fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, out
+
+
+def cfg3(dev, steps=5, warmup=2, modes=("fp16x2", "bf16"), batch=32):
+    """td_tse_conv_tasnet_v0 (egs/tse/model.py:95-140), batch x (4 s mixture + 4 s enrolment).  "bf16" is the arithmetic
+    BASELINE names for this config (bf16 products and hidden rows, fp32 accumulation); l2_rel is taken against an
+    exact-fp32 run of the same batch."""
+    model = _build("cfg3_short", dev)
+    noisy, enroll = _waves(batch, 1234, dev), _waves(batch, 1235, dev)
+
+    def set_mode(prec):
+        model.masker.set_gemm_precision(prec)
+        for m in model.speaker_net:
+            if hasattr(m, "gemm_precision"):
+                m.gemm_precision = prec
+    set_mode("fp32")
+    ref = model.inference(noisy, enroll)
+    out = {"workload": f"td_tse_conv_tasnet_v0, {batch} x (4 s mixture + 4 s enrolment), 1 GPU", "steps": steps}
+    for prec in modes:
+        set_mode(prec)
+        ms, y = _timed(lambda: model.inference(noisy, enroll), steps, warmup)
+        out[prec] = {"ms": ms, "samples_s": batch * L / ms * 1e3,
+                     "l2_rel_vs_fp32": float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref))}
+    return out
+
+
+def cfg4_model(dev, gemm="fp32"):
+    model = _build("cfg4_short", dev)
+    model.masker.set_gemm_precision(gemm)
+    return model
+
+
+def cfg4(dev, steps=10, warmup=3, batch=32, gemm="fp32", graph=True):
+    """FreeEncDec(32,16,128) + DPRNN(128,64,128, 6 blocks, K=20, causal), batch x 4 s per GPU: eager and as one hipGraph.
+    serial_steps = the 6 x (20 + 200) dependent LSTM cell steps of one forward."""
+    model = cfg4_model(dev, gemm)
+    noisy = _waves(batch, 1234, dev)
+    ms, _ = _timed(lambda: model.inference(noisy), steps, warmup)
+    out = {"workload": f"DPRNN(128,64,128,6 blocks,K=20,causal), {batch} x 4 s, 1 GPU, fp32 rows, input projections {gemm}",
+           "steps": steps, "ms": ms, "samples_s": batch * L / ms * 1e3, "serial_steps": 6 * (20 + 200),
+           "us_per_serial_step": ms * 1e3 / (6 * (20 + 200))}
+    if graph:
+        from puresound_amd.graphs import GraphedInference
+        fast = GraphedInference(model)
+        msg, _ = _timed(lambda: fast(noisy), steps, 3)
+        out["hipgraph_ms"] = msg
+        out["hipgraph_us_per_serial_step"] = msg * 1e3 / (6 * (20 + 200))
+    return out
+
+
+def cfg5(dev, chunks=300, streams=64, warmup=10):
+    """Demo preset (egs/tse/demo/utils.py:51-72), `streams` concurrent streams, 320-sample chunks, one hipGraph per chunk."""
+    from detweights import det_state_dict
+    from puresound_amd.streaming.demo import DemoTseNet
+    net = DemoTseNet().eval()
+    net.load_state_dict(det_state_dict(net))
+    net.to(dev)
+    net.init_streams(streams)
+    g = torch.Generator().manual_seed(1236)
+    embed = torch.rand(streams, 192, generator=g).to(dev)
+    wav = ((torch.rand(streams, 320 * 8, generator=g) * 2 - 1) * 0.5).to(dev)
+    lat, pre = [], None
+    for i in range(chunks + warmup):
+        chunk = wav[:, (i % 8) * 320:(i % 8 + 1) * 320]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y = net.streaming_inference_chunk(chunk, embed, pre)
+        pre = y[:, -16:]
+        torch.cuda.synchronize()
+        if i >= warmup:
+            lat.append((time.perf_counter() - t0) * 1e3)
+    lat = np.array(lat)
+    return {"workload": f"demo StreamingSkiM(128,256,128,4 blocks,K=150), {streams} streams x 320-sample chunks, one hipGraph "
+                        f"per chunk", "chunks": int(len(lat)), "p50_ms": float(np.percentile(lat, 50)),
+            "p90_ms": float(np.percentile(lat, 90)), "max_ms": float(lat.max()), "budget_ms": 20.0,
+            "mem_lstm_updates_seen": int(len(lat) * 20 // 150)}

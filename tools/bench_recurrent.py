@@ -12,6 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import cases  # noqa: E402
 from detweights import det_state_dict  # noqa: E402
 import puresound_amd.nnet as PA  # noqa: E402
@@ -19,54 +20,83 @@ from puresound_amd import _abi  # noqa: E402
 
 
 def cfg4(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench_recurrent.py --gpus {args.gpus} but WORLD_SIZE = {world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} (one rank per GPU)")
+    if world > 1:
+        return cfg4_data_parallel(args, world)
+    import bench_configs as BC
     dev = "cuda:0"
-    model = cases.build(PA.NS, "cfg4_short").eval()
-    model.load_state_dict(det_state_dict(model))
-    model.to(dev)
-    model.masker.set_gemm_precision(args.gemm)
-    if args.hip_streams:
-        model.hip_streams = args.hip_streams
-    g = torch.Generator().manual_seed(1234)
-    noisy = ((torch.rand(args.batch, 64000, generator=g) * 2 - 1) * 0.5).to(dev)
-    for _ in range(args.warmup):
-        model.inference(noisy)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.inference(noisy)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    r = BC.cfg4(dev, steps=args.steps, warmup=args.warmup, batch=args.batch, gemm=args.gemm)
     line = {"config": "cfg4 DPRNN(128,64,128,6 blocks,K=20,causal) fp32 storage", "input_projection_gemm": args.gemm,
-            "batch": args.batch, "ms_per_forward": ms, "hip_streams": int(getattr(model, "hip_streams", 2)),
-            "samples_per_s": args.batch * 64000 / ms * 1e3}
-    # the same forward replayed as one hipGraph (45 short kernels: the eager path leaves gaps between them)
-    from puresound_amd.graphs import GraphedInference
-    fast = GraphedInference(model)
-    for _ in range(3):
-        fast(noisy)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fast(noisy)
-    torch.cuda.synchronize()
-    msg = (time.perf_counter() - t0) / args.steps * 1e3
-    line["hipgraph_ms_per_forward"] = msg
-    line["hipgraph_samples_per_s"] = args.batch * 64000 / msg * 1e3
+            "batch": args.batch, "ms_per_forward": r["ms"], "samples_per_s": r["samples_s"],
+            "us_per_serial_step": r["us_per_serial_step"], "hipgraph_ms_per_forward": r["hipgraph_ms"],
+            "hipgraph_samples_per_s": args.batch * 64000 / r["hipgraph_ms"] * 1e3}
     if args.profile:
         import ctypes as C
         lib = _abi.lib()
+        model = BC.cfg4_model(dev, args.gemm)
+        noisy = BC._waves(args.batch, 1234, dev)
         model.hip_streams = 1
+        model.inference(noisy)
         lib.ps_profile_enable(1)
         model.inference(noisy)
         torch.cuda.synchronize()
         fam = {}
-        for k in ("conv1x1", "lstm", "chan_layernorm", "free_encode", "free_decode", "film_apply"):
+        for k in ("conv1x1", "lstm", "chan_layernorm", "proj_layernorm", "free_encode", "free_decode", "film_apply"):
             ms_k, cnt = C.c_double(), C.c_int()
             lib.ps_profile_read(k.encode(), C.byref(ms_k), C.byref(cnt))
             fam[k] = [round(ms_k.value, 4), cnt.value]
         lib.ps_profile_enable(0)
         line["kernel_ms_per_forward"] = fam
     print(json.dumps(line))
+
+
+def cfg4_data_parallel(args, world):
+    """BASELINE config 4 as north_star states it: batch = 32 * N x 4 s, data-parallel over N GPUs of one node, one rank per
+    GPU (torch.distributed.run), utterances sharded with no data-path collective, ONE all-gather of the [32, L] output
+    waveforms per step (puresound_amd.batch_shard.sharded_inference -- what replaces the reference's nn.DataParallel,
+    task/base.py:226-229).  Weak scaling: per-GPU work is fixed; the time is the max over ranks between barriers."""
+    import torch.distributed as dist
+    import bench_configs as BC
+    from puresound_amd.batch_shard import sharded_inference
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev)
+    model = BC.cfg4_model(dev, args.gemm)
+    total_b = args.batch * world
+    noisy = BC._waves(total_b, 1234, dev)  # every rank holds the synthetic batch and runs its own contiguous share
+
+    def step():
+        return sharded_inference(model.inference, noisy)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    mine = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    every = torch.empty(world, device=dev, dtype=torch.float64)
+    dist.all_gather_into_tensor(every, mine)
+    elapsed = float(every.max().item())
+    if rank == 0:
+        print(json.dumps({"config": "cfg4 DPRNN(128,64,128,6 blocks,K=20,causal), data-parallel", "n_gpus": world,
+                          "global_batch": total_b, "scaling": "weak", "input_projection_gemm": args.gemm,
+                          "ms_per_step": elapsed / args.steps * 1e3, "samples_per_s": total_b * 64000 * args.steps / elapsed,
+                          "distributed": {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                          "collective": "all_gather_into_tensor of [B/N, L] fp32 inside the timed step",
+                                          "ms_per_step_by_rank": [float(v) / args.steps * 1e3 for v in every.tolist()]}}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def dpcrn(args):
@@ -106,47 +136,20 @@ def dpcrn(args):
 
 
 def cfg5(args):
-    from puresound_amd.streaming.demo import DemoTseNet
-    dev = "cuda:0"
-    net = DemoTseNet().eval()
-    net.load_state_dict(det_state_dict(net))
-    net.to(dev)
-    b = args.streams
-    net.init_streams(b)
-    g = torch.Generator().manual_seed(1236)
-    embed = torch.rand(b, 192, generator=g).to(dev)
-    wav = ((torch.rand(b, 320 * 8, generator=g) * 2 - 1) * 0.5).to(dev)
-    lat = {"hop_graphs": [], "chunk_graph": []}
-    for mode in ("hop_graphs", "chunk_graph"):   # 20 replays of the hop graph (round 1) | one graph per chunk, OLA included
-        net.init_streams(b)
-        pre = None
-        for i in range(args.chunks + 10):
-            chunk = wav[:, (i % 8) * 320:(i % 8 + 1) * 320]
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            if mode == "hop_graphs":
-                for j in range(20):
-                    net.streaming_inference(chunk[:, j * 16:(j + 1) * 16], embed)
-            else:
-                out = net.streaming_inference_chunk(chunk, embed, pre)
-                pre = out[:, -16:]
-            torch.cuda.synchronize()
-            if i >= 10:
-                lat[mode].append((time.perf_counter() - t0) * 1e3)
-    hop = np.array(lat["hop_graphs"])
-    lat = np.array(lat["chunk_graph"])
+    import bench_configs as BC
+    r = BC.cfg5("cuda:0", chunks=args.chunks, streams=args.streams)
     print(json.dumps({"config": "cfg5 demo preset StreamingSkiM(128,256,128,4 blocks,K=150) fp32, one hipGraph per "
                                 "320-sample chunk (window shifts, 20 hops, overlap-add, Mem-LSTM update inside)",
-                      "streams": b, "hop_graph_chunk_ms_p50": float(np.percentile(hop, 50)),
-                      "chunks": len(lat), "chunk_ms_p50": float(np.percentile(lat, 50)),
-                      "chunk_ms_p90": float(np.percentile(lat, 90)), "chunk_ms_max": float(lat.max()),
-                      "budget_ms": 20.0}))
+                      "streams": args.streams, "chunks": r["chunks"], "chunk_ms_p50": r["p50_ms"],
+                      "chunk_ms_p90": r["p90_ms"], "chunk_ms_max": r["max_ms"], "budget_ms": 20.0}))
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default="cfg4,cfg5")
-    ap.add_argument("--hip-streams", type=int, default=0, help="cfg4: HIP streams the batch is split over (0 = the model's default)")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="cfg4: data-parallel over N GPUs (launch with torch.distributed.run --nproc-per-node N): 32 utterances "
+                         "per rank, one all-gather of the outputs per step")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -155,11 +158,10 @@ if __name__ == "__main__":
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="ps_debug_flags (kernel variant switches)")
     ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x3", "bf16"],
-                    help="arithmetic of the LSTM input projections (puresound_amd.nnet._plans.set_recurrent_gemm_precision)")
+                    help="arithmetic of the LSTM input projections (per module: masker.set_gemm_precision)")
     a = ap.parse_args()
     if a.flags:
         _abi.lib().ps_debug_flags(a.flags)
-    from puresound_amd.nnet import _plans
     if "cfg4" in a.which:
         cfg4(a)
     if "cfg5" in a.which:
