@@ -423,7 +423,8 @@ int ps_dwconv_io(const void* x, int x_bf16, const float* w, const float* b, void
  *   weights      wt_planes = the two-plane image of 2^w_exp * W ([ceil(M/256)][ceil(K/16)][2][256][16] fp16,
  *                ps_conv1x1_bf16_weight_bytes(M, K, 2) bytes); the packer picks w_exp so that max |2^w_exp W| lies in
  *                [2^13, 2^14);
- *   activations  x_bound > 0: a host-known bound on |f(x)| (behind a global norm: max|gamma| sqrt(count) + max|beta|),
+ *   activations  x_bound > 0: a host-known bound on |f(x)| (behind a global norm: max|gamma| sqrt(count) + max|beta|, times
+ *                max(1, |slope|) when a PReLU follows: f includes it),
  *                the kernel scales by the power of two that puts it below 2^15;
  *                else x_amax != NULL: [N][x_amax_parts] partial maxima of |x| left by the producer (y_amax of the
  *                launch before, or ps_absmax_f32): per utterance, max |x| goes to [2^14, 2^15);

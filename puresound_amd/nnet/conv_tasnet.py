@@ -152,8 +152,12 @@ class TCN(_PlanCache, nn.Module):
                                              ("pw_wb", dsc.pointwise[0].weight.detach().to(**f32)),
                                              ("out_wb", self.out_conv.weight.detach().to(**f32)))):
                 t[key], b.w_exp[i] = hip.pack_wt_f16x2(wsrc)
-            b.dw_gmax, b.dw_bmax = float(t["dw_gamma"].abs().max()), float(t["dw_beta"].abs().max())
-            b.pw_gmax, b.pw_bmax = float(t["pw_gamma"].abs().max()), float(t["pw_beta"].abs().max())
+            # bound on |PReLU(gamma z + beta)| for the fp16 range: the PReLU runs before the split, and a slope beyond 1
+            # in magnitude makes a negative value LARGER -- the factor max(1, |slope|) covers it
+            fd = max(1.0, abs(float(t["dw_slope"][0])))
+            fp = max(1.0, abs(float(t["pw_slope"][0])))
+            b.dw_gmax, b.dw_bmax = float(t["dw_gamma"].abs().max()) * fd, float(t["dw_beta"].abs().max()) * fd
+            b.pw_gmax, b.pw_bmax = float(t["pw_gamma"].abs().max()) * fp, float(t["pw_beta"].abs().max()) * fp
         elif planes:
             t["in_wb"] = hip.pack_wt_bf16(w_in[:, :c, 0], planes)
             t["pw_wb"] = hip.pack_wt_bf16(dsc.pointwise[0].weight.detach().to(**f32), planes)

@@ -22,6 +22,16 @@ CASES = {
     "cfg2_short": dict(kind="wrap", enc=dict(kind="free", win=32, hop=16, C=512),
                        masker=masker_args(512, 0, False, [0] * 8, **CTN_FULL),
                        wrap=dict(mask_constraint="ReLU"), B=2, L=4000, seed=1234),
+    # configs 2 and 3 with the weights a trained checkpoint may have (detweights mode "wild": norm gains over 2^-4 .. 2^4,
+    # biases in +-2, PReLU slopes up to 3, weight rows spanning 2^18): the fp16x2 range logic end to end
+    "cfg2_wild_short": dict(kind="wrap", enc=dict(kind="free", win=32, hop=16, C=512),
+                            masker=masker_args(512, 0, False, [0] * 8, **CTN_FULL),
+                            wrap=dict(mask_constraint="ReLU"), B=2, L=4000, seed=1234, weights="wild", amp=1e-3),
+    "cfg3_wild_short": dict(kind="wrap", enc=dict(kind="free", win=32, hop=16, C=512),
+                            masker=masker_args(512, 192, True, [1, 0, 0, 0, 0, 0, 0, 0], **CTN_FULL),
+                            speaker_net=dict(n_tcn=5, C=512, H=256, att=128, E=192),
+                            wrap=dict(mask_constraint="ReLU"), B=2, L=4000, L_enroll=4000, seed=1234, weights="wild",
+                            amp=1e-3),
     "cfg2_full": dict(kind="wrap", enc=dict(kind="free", win=32, hop=16, C=512),
                       masker=masker_args(512, 0, False, [0] * 8, **CTN_FULL),
                       wrap=dict(mask_constraint="ReLU"), B=1, L=64000, seed=1234),

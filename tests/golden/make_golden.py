@@ -63,9 +63,9 @@ def sub(x: torch.Tensor, cs: int = 7, ts: int = 5) -> np.ndarray:
 @torch.no_grad()
 def run_wrap(name, c):
     model = cases.build(REF, name).eval()
-    sd = det_state_dict(model)
+    sd = det_state_dict(model, mode=c.get("weights", "plain"))
     model.load_state_dict(sd)
-    noisy = det_wave(c["seed"], c["B"], c["L"])
+    noisy = det_wave(c["seed"], c["B"], c["L"], c.get("amp", 0.5))
     enroll = det_wave(c["seed"] + 1, c["B"], c["L_enroll"]) if "L_enroll" in c else None
     out = {"n_params": np.int64(sum(p.numel() for p in model.parameters()))}
     wav = model.inference(noisy.clone(), None if enroll is None else enroll.clone())

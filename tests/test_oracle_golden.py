@@ -24,7 +24,7 @@ def _load(golden_dir, name):
 
 
 def _sd(name):
-    return det_state_dict(cases.build(PA.NS, name))
+    return det_state_dict(cases.build(PA.NS, name), mode=cases.CASES[name].get("weights", "plain"))
 
 
 WRAP = [n for n, c in cases.CASES.items() if c["kind"] == "wrap"]
@@ -37,7 +37,7 @@ def test_wrapper_inference_matches_reference(golden_dir, name):
     c = cases.CASES[name]
     g = _load(golden_dir, name)
     sd = _sd(name)
-    noisy = det_wave(c["seed"], c["B"], c["L"])
+    noisy = det_wave(c["seed"], c["B"], c["L"], c.get("amp", 0.5))
     enroll = det_wave(c["seed"] + 1, c["B"], c["L_enroll"]) if "L_enroll" in c else None
     taps = {}
     wav = O.inference(noisy, sd, cases.oracle_cfg(name), enroll, taps)

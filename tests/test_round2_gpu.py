@@ -40,14 +40,17 @@ def _l2rel(a, b):
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
-def test_benchmark_arithmetic_at_benchmark_size(PA, dev, golden_dir):
-    """bench.py's path exactly: config 2, batch 32 x 64000, the 3 x bf16 split GEMM on the persistent kernel.  Row 0
-    is the reference's golden utterance (1e-4); rows agree with their B = 1 runs to fp32 rounding (the split GEMM picks
-    its kernel by launch size, so not bit for bit); length law; |y| <= 1."""
+@pytest.mark.parametrize("gemm", ["fp16x2", "bf16x3"])
+def test_benchmark_arithmetic_at_benchmark_size(PA, dev, golden_dir, gemm):
+    """bench.py's path exactly: config 2, batch 32 x 64000, in the benchmark's default arithmetic (fp16x2: two fp16 terms
+    per operand on the persistent kernel, the range chain across 24 blocks) and in the six-product bf16 split.  Row 0 of
+    the batch IS the reference's golden utterance (1e-4 against tests/golden/cfg2_full.npz, directly); rows agree with
+    their B = 1 runs to fp32 rounding (the split GEMMs pick their kernel by launch size, so not bit for bit); length
+    law; |y| <= 1."""
     name = "cfg2_full"
     g = np.load(f"{golden_dir}/{name}.npz")
     model, _ = _build(PA, name, dev)
-    model.masker.set_gemm_precision("bf16x3")
+    model.masker.set_gemm_precision(gemm)
     batch = torch.cat([det_wave(cases.CASES[name]["seed"], 1, 64000), det_wave(99, 31, 64000)]).to(dev)
     for streams in (1, 2):
         model.hip_streams = streams
@@ -56,7 +59,7 @@ def test_benchmark_arithmetic_at_benchmark_size(PA, dev, golden_dir):
         assert rel_max(out[0:1].cpu().numpy(), g["wav"]) < TOL
         for i in (0, 7, 16, 31):
             single = model.inference(batch[i:i + 1])
-            assert float((single[0] - out[i]).abs().max()) <= 1e-5, (streams, i)
+            assert float((single[0] - out[i]).abs().max()) <= (2e-5 if gemm == "fp16x2" else 1e-5), (streams, i)
 
 
 def test_config3_in_its_bf16_arithmetic(PA, dev):
