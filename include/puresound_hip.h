@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 6
+#define PS_ABI_VERSION 7
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -54,7 +54,7 @@ const char* ps_last_error(void);
  * ps_profile_read synchronises the recorded events and returns the summed duration and launch count
  * of one kernel family ("conv1x1", "dwconv", "free_encode", "free_decode", "embed_bias", "pad_rows",
  * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product", "segment_overlap",
- * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "conv1x1_bf16", "unfold2d", "conv2d", "activation", "add", "magnitude", "real_mask", "norm_activation", "self_attention", "add_position",
+ * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "stream_windows", "stream_overlap", "conv1x1_bf16", "unfold2d", "conv2d", "activation", "add", "magnitude", "real_mask", "norm_activation", "self_attention", "add_position",
  * "film_apply").  Not for use under stream capture. */
 int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
                                   <0 reads; returns the old value */
@@ -357,6 +357,18 @@ int ps_proj_layernorm_f32(const float* x, const float* wt, const float* bias, co
  * j < overlap (tail = the last `overlap` samples of the running output, row stride ld_tail), cur[b][j] otherwise. */
 int ps_overlap_average_f32(const float* tail, int ld_tail, const float* cur, float* out, int B, int win, int overlap,
                            void* stream);
+
+/* The same harness for ALL hops of a chunk in two launches (replaces the hop-by-hop window shift and overlap-add of
+ * DemoTseNet.streaming_inference_chunk, egs/tse/demo/utils.py:100-128; win = 2 * hop):
+ *   ps_stream_windows_f32  wins[i][b * win + j] = sig_b[i * hop + j], sig_b = queue[b][hop .. win) ++ chunk[b][0 .. hops * hop)
+ *                          (queue [B][win] = the previous window, chunk [B][hops * hop]) -- one "utterance" per hop for the
+ *                          encoder;
+ *   ps_stream_overlap_f32  frames [hops][B][win] (the decoder's output) -> blocks[b][i * hop + j] = (prev + frames[i][b][j]) / 2
+ *                          with prev = tail[b][j] (i = 0) or frames[i-1][b][hop + j]; then tail[b][:] = frames[hops-1][b][hop:]
+ *                          and queue[b][:] = wins[hops-1][b] (the last window).  tail [B][hop], blocks [B][hops * hop]. */
+int ps_stream_windows_f32(const float* queue, const float* chunk, float* wins, int B, int hops, int win, int hop, void* stream);
+int ps_stream_overlap_f32(const float* frames, const float* wins, float* tail, float* blocks, float* queue, int B, int hops,
+                          int win, int hop, void* stream);
 
 /* One cell update per (unit, frame) from COMPLETE gate pre-activations gates [N][D*4H][ld_gates] (W_ih x + W_hh h + both
  * biases: the streaming step puts [x; h] on the K axis of one ps_conv1x1_f32):  c' = sig(f) c + sig(i) tanh(g) in

@@ -226,6 +226,39 @@ __global__ __launch_bounds__(256) void overlap_average_kernel(const float* __res
   out[(size_t)b * win + j] = j < ov ? (tail[(size_t)b * ld_tail + j] + v) * 0.5f : v;
 }
 
+// The harness' sliding window for all hops of a chunk at once (egs/tse/demo/utils.py:100-118 runs it hop by hop):
+// sig_b = queue[b][hop .. win) ++ chunk[b][0 .. hops * hop); wins[i][b * win + j] = sig_b[i * hop + j].
+__global__ __launch_bounds__(256) void stream_windows_kernel(const float* __restrict__ queue, const float* __restrict__ chunk,
+                                                             float* __restrict__ wins, int B, int hops, int win, int hop) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (i, b, j)
+  if (idx >= hops * B * win) return;
+  const int j = idx % win, b = (idx / win) % B, i = idx / (win * B);
+  const int s = i * hop + j;  // position in sig_b; its first win - hop samples are the tail of the previous window
+  const int keep = win - hop;
+  wins[idx] = s < keep ? queue[(size_t)b * win + hop + s] : chunk[(size_t)b * hops * hop + (s - keep)];
+}
+
+// Averaging overlap-add of all hops of a chunk (utils.py:121-128, win = 2 hop): block i of stream b is the mean of the
+// previous frame's second half (the running tail for i = 0) and frame i's first half; then tail <- the last frame's
+// second half and queue <- the last window.  One thread per (stream, sample of a hop) walks the hops in order, so the
+// tail it reads is the one it later replaces.
+__global__ __launch_bounds__(256) void stream_overlap_kernel(const float* __restrict__ frames, const float* __restrict__ wins,
+                                                             float* __restrict__ tail, float* __restrict__ blocks,
+                                                             float* __restrict__ queue, int B, int hops, int win, int hop) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * win) return;
+  const int j = idx % win, b = idx / win;
+  queue[idx] = wins[(size_t)(hops - 1) * B * win + idx];
+  if (j >= hop) return;
+  float prev = tail[(size_t)b * hop + j];
+  for (int i = 0; i < hops; ++i) {
+    const float* f = frames + ((size_t)i * B + b) * win;
+    blocks[(size_t)b * hops * hop + i * hop + j] = (prev + f[j]) * 0.5f;
+    prev = f[hop + j];
+  }
+  tail[(size_t)b * hop + j] = prev;
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                        int64_t rows, int T, int ldt) {
@@ -379,6 +412,31 @@ extern "C" int ps_overlap_average_f32(const float* tail, int ld_tail, const floa
   hipLaunchKernelGGL(overlap_average_kernel, dim3((win + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, tail,
                      ld_tail, cur, out, win, overlap);
   return check_launch("ps_overlap_average_f32");
+}
+
+extern "C" int ps_stream_windows_f32(const float* queue, const float* chunk, float* wins, int B, int hops, int win,
+                                     int hop, void* stream) {
+  if (!queue || !chunk || !wins || B <= 0 || hops <= 0 || hop <= 0 || win != 2 * hop ||
+      (long long)B * hops * win > 0x7fffffffLL) {
+    set_error("ps_stream_windows_f32: bad argument (B=%d hops=%d win=%d hop=%d; win must be 2 * hop)", B, hops, win, hop);
+    return PS_E_INVALID;
+  }
+  LaunchTimer timer("stream_windows", (hipStream_t)stream);
+  hipLaunchKernelGGL(stream_windows_kernel, dim3((hops * B * win + 255) / 256), dim3(256), 0, (hipStream_t)stream, queue,
+                     chunk, wins, B, hops, win, hop);
+  return check_launch("ps_stream_windows_f32");
+}
+
+extern "C" int ps_stream_overlap_f32(const float* frames, const float* wins, float* tail, float* blocks, float* queue,
+                                     int B, int hops, int win, int hop, void* stream) {
+  if (!frames || !wins || !tail || !blocks || !queue || B <= 0 || hops <= 0 || hop <= 0 || win != 2 * hop) {
+    set_error("ps_stream_overlap_f32: bad argument (B=%d hops=%d win=%d hop=%d; win must be 2 * hop)", B, hops, win, hop);
+    return PS_E_INVALID;
+  }
+  LaunchTimer timer("stream_overlap", (hipStream_t)stream);
+  hipLaunchKernelGGL(stream_overlap_kernel, dim3((B * win + 255) / 256), dim3(256), 0, (hipStream_t)stream, frames, wins,
+                     tail, blocks, queue, B, hops, win, hop);
+  return check_launch("ps_stream_overlap_f32");
 }
 
 extern "C" int ps_embed_bias_f32(const float* dvec, const float* w_embed, float* bias_n, int N, int E, int M,

@@ -483,6 +483,30 @@ def overlap_average(prev: torch.Tensor, cur: torch.Tensor, overlap: int) -> torc
     return out
 
 
+def stream_windows(queue: torch.Tensor, chunk: torch.Tensor, wins: torch.Tensor, hop: int) -> None:
+    """queue [B, 2 hop] ‖ chunk [B, hops * hop] -> wins [hops, B * 2 hop]: window i of stream b (ps_stream_windows_f32)."""
+    require_device(chunk, "stream_windows")
+    b, win = queue.shape
+    hops = chunk.shape[1] // hop
+    if not (queue.is_contiguous() and chunk.is_contiguous() and wins.is_contiguous()) or wins.shape != (hops, b * win):
+        raise RuntimeError("stream_windows: contiguous queue [B, win], chunk [B, hops * hop], wins [hops, B * win] expected")
+    check(lib().ps_stream_windows_f32(ptr(queue), ptr(chunk), ptr(wins), b, hops, win, hop, stream_ptr(chunk.device)),
+          "ps_stream_windows_f32")
+
+
+def stream_overlap(frames: torch.Tensor, wins: torch.Tensor, tail: torch.Tensor, blocks: torch.Tensor,
+                   queue: torch.Tensor, hop: int) -> None:
+    """Averaging overlap-add of all hops of a chunk, in place on tail / blocks / queue (ps_stream_overlap_f32)."""
+    require_device(frames, "stream_overlap")
+    b, win = queue.shape
+    hops = wins.shape[0]
+    if not all(t.is_contiguous() for t in (frames, wins, tail, blocks, queue)) or frames.numel() != hops * b * win \
+            or tail.shape != (b, hop) or blocks.shape != (b, hops * hop):
+        raise RuntimeError("stream_overlap: frames [hops, B, win], tail [B, hop], blocks [B, hops * hop] (contiguous) expected")
+    check(lib().ps_stream_overlap_f32(ptr(frames), ptr(wins), ptr(tail), ptr(blocks), ptr(queue), b, hops, win, hop,
+                                      stream_ptr(frames.device)), "ps_stream_overlap_f32")
+
+
 ACT_KINDS = {"none": 0, "relu": 1, "prelu": 2, "mish": 3, "sigmoid": 4, "tanh": 5}
 
 

@@ -15,6 +15,8 @@ with 150-frame segments and 20-hop chunks that is three graphs.  The graphs are 
 """
 from typing import Optional
 
+import math
+
 import torch
 import torch.nn as nn
 
@@ -138,18 +140,18 @@ class DemoTseNet(nn.Module):
                 if f is not None:
                     f.set_per_frame_condition(m._embed_static, m.embed_norm)
 
-    def _chunk_body(self, hops: int, update_at: Optional[int]):
-        """`hops` hops on the static buffers; the Mem-LSTM update + block-0 reset behind hop `update_at`
-        (skim_inference.py:205-218).  Only the masker step is recurrent: the windows of all hops are encoded in ONE
+    def _chunk_body(self, hops: int, updates: tuple):
+        """`hops` hops on the static buffers; the Mem-LSTM update + block-0 reset behind every hop listed in `updates`
+        (skim_inference.py:205-218; a chunk longer than a segment wraps the frame counter more than once).  Only the masker step is recurrent: the windows of all hops are encoded in ONE
         launch up front (hop i of stream s = samples [16 i, 16 i + 32) of its previous half window followed by the
         chunk; one "utterance" per hop, so every hop's features are the [1, C, ldB] block the masker step reads), the
         masker steps write their masks side by side, and ONE decoder launch plus the averaging overlap-add of all hops
         follows.  Same arithmetic per frame as the hop loop.  Results are in _blocks / _tail / queue."""
         m, h, b = self.masker, self.hop_size, self.masker.streams
-        if self.ola_size != h:  # (the averaging below assumes win = 2 hop, as in the reference harness)
-            return self._chunk_body_by_hops(hops, update_at)
-        sig = torch.cat([self.queue[:, h:], self._chunk_in], dim=1)                      # [B, 16 + 16 hops]
-        self._wins.copy_(sig.unfold(1, self.win_size, h).permute(1, 0, 2).reshape(hops, b * self.win_size))
+        if self.ola_size != h or self.win_size != 2 * h:  # (the batched kernels assume win = 2 hop, as in the reference harness)
+            return self._chunk_body_by_hops(hops, updates)
+        # window i of stream s = samples [16 i, 16 i + 32) of (second half of the previous window ‖ chunk): one launch
+        hip.stream_windows(self.queue, self._chunk_in, self._wins, h)
         feats, _ = hip.free_encode(self._wins, self.encoder.encoder.weight.detach(), self.win_size, True)  # [hops,C,ldB]
         if self._masks is None or self._masks.shape != (hops, m.output_fc[1].out_channels, feats.shape[-1]):
             self._masks = torch.empty(hops, m.output_fc[1].out_channels, feats.shape[-1], dtype=torch.float32, device=feats.device)
@@ -159,19 +161,44 @@ class DemoTseNet(nn.Module):
         for i in range(hops):
             m._x_in = feats[i:i + 1]
             m._frame_body(x_ln=None if x_ln is None else x_ln[i:i + 1], core_out=self._cores[i:i + 1])
-            if update_at == i:
+            if i in updates:
                 m.update_mem_lstm()
                 m.reset_seg_lstm_status()
         m._output(self._cores, b, out=self._masks)
         frames = hip.free_decode(feats, b, self.encoder.decoder.weight.detach(), self.win_size, self._masks, "linear",
-                                 "none").reshape(hops, b, self.win_size)
-        heads, tails = frames[:, :, :h], frames[:, :, h:]
-        prev = torch.cat([self._tail.unsqueeze(0), tails[:-1]], dim=0)
-        self._blocks.copy_(((prev + heads) * 0.5).permute(1, 0, 2).reshape(b, hops * h))
-        self._tail.copy_(tails[-1])
-        self.queue.copy_(sig[:, sig.shape[1] - self.win_size:])
+                                 "none")                                                  # [hops, B * win]
+        # averaging overlap-add of all hops, the new tail and the new window queue: one launch
+        hip.stream_overlap(frames, self._wins, self._tail, self._blocks, self.queue, h)
 
-    def _chunk_body_by_hops(self, hops: int, update_at: Optional[int]):
+    _CHUNK_GRAPH_CAP = 24  # captured (hops, update pattern) variants kept; the oldest goes first
+
+    def _updates_in_chunk(self, frames_counter: int, hops: int) -> tuple:
+        """Hop indices of the chunk behind which the segment counter wraps (utils.py:100-118 / skim_inference.py:205-218)."""
+        seg = self.masker.seg_size
+        return tuple(i for i in range(hops) if (frames_counter + i + 1) % seg == 0)
+
+    def _capture_chunk_graph(self, key: tuple, device) -> None:
+        hops, updates = key
+        m = self.masker
+        state = m._seg_h + m._seg_c + [t for pair in m._mem_h + m._mem_c for t in pair] + [self.queue, self._tail]
+        saved = [t.clone() for t in state]
+        s = torch.cuda.Stream(device)
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):          # warm-up outside the capture: plans, per-frame embedding terms
+            self._chunk_body(hops, updates)
+        torch.cuda.current_stream(device).wait_stream(s)
+        for t, v in zip(state, saved):
+            t.copy_(v)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._chunk_body(hops, updates)
+        for t, v in zip(state, saved):
+            t.copy_(v)
+        while len(self._chunk_graphs) >= self._CHUNK_GRAPH_CAP:
+            self._chunk_graphs.pop(next(iter(self._chunk_graphs)))
+        self._chunk_graphs[key] = g
+
+    def _chunk_body_by_hops(self, hops: int, updates: tuple):
         """The same, hop by hop (window shift, hop body, averaging overlap-add per hop)."""
         m, h = self.masker, self.hop_size
         for i in range(hops):
@@ -180,7 +207,7 @@ class DemoTseNet(nn.Module):
             frame = self._hop_body()
             self._blocks[:, i * h:(i + 1) * h] = hip.overlap_average(self._tail, frame, self.ola_size)[:, :h]
             self._tail.copy_(frame[:, h:])
-            if update_at == i:
+            if i in updates:
                 m.update_mem_lstm()
                 m.reset_seg_lstm_status()
 
@@ -204,8 +231,7 @@ class DemoTseNet(nn.Module):
         self._check_parameters()
         self._refresh_embedding(embed)
         b, h = m.streams, self.hop_size
-        left = m.seg_size - m.frames_counter            # hops until the segment counter wraps
-        update_at = left - 1 if left <= hops else None
+        updates = self._updates_in_chunk(m.frames_counter, hops)
         if self._tail is None or getattr(self, "_chunk_in", None) is None or self._chunk_in.shape != (b, hops * h):
             dev = chunk.device
             self._chunk_in = torch.empty(b, hops * h, dtype=torch.float32, device=dev)
@@ -216,24 +242,21 @@ class DemoTseNet(nn.Module):
             self._chunk_graphs = {}
         self._chunk_in.copy_(chunk[:, :hops * h])
         self._tail.copy_(pre_wav[:, pre_wav.shape[-1] - self.ola_size:])
-        key = (hops, update_at)
+        key = (hops, updates)
         g = self._chunk_graphs.get(key)
         if g is None:
-            state = m._seg_h + m._seg_c + [t for pair in m._mem_h + m._mem_c for t in pair] + [self.queue, self._tail]
-            saved = [t.clone() for t in state]
-            s = torch.cuda.Stream(chunk.device)
-            s.wait_stream(torch.cuda.current_stream(chunk.device))
-            with torch.cuda.stream(s):          # warm-up outside the capture: plans, per-frame embedding terms
-                self._chunk_body(hops, update_at)
-            torch.cuda.current_stream(chunk.device).wait_stream(s)
-            for t, v in zip(state, saved):
-                t.copy_(v)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._chunk_body(hops, update_at)
-            for t, v in zip(state, saved):
-                t.copy_(v)
-            self._chunk_graphs[key] = g
+            # Capturing costs two runs of the chunk body (10 ms and more): the first graphed chunk of a given length pays it
+            # for EVERY position pattern the segment counter can reach with chunks of that length, so that no later chunk
+            # does (round 2 captured lazily: the 12-15 ms maxima of its latency lines were these captures).
+            todo = [key]
+            if not any(k[0] == hops for k in self._chunk_graphs):
+                step = math.gcd(hops, m.seg_size)
+                todo += [(hops, u) for u in sorted({self._updates_in_chunk(fc, hops)
+                                                    for fc in range(m.frames_counter % step, m.seg_size, step)})
+                         if (hops, u) != key]
+            for k in todo[:self._CHUNK_GRAPH_CAP]:
+                self._capture_chunk_graph(k, chunk.device)
+            g = self._chunk_graphs[key]
         g.replay()
         m.frames_counter = (m.frames_counter + hops) % m.seg_size
         return torch.cat([pre_wav[:, :pre_wav.shape[-1] - self.ola_size], self._blocks, self._tail], dim=-1)

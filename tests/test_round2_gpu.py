@@ -201,7 +201,8 @@ def test_chunk_graph_equals_the_hop_loop_across_mem_lstm_updates(dev):
         states.append([t.clone() for t in net.masker._seg_h + net.masker._seg_c])
         if use_graph:
             # (the stream's very first hop only fills the window, so the segment counter lags the hop count by one)
-            assert set(net._chunk_graphs) == {(20, 10), (20, 0), (20, None)}
+            # all three update patterns a 20-hop chunk can meet are captured with the first graphed chunk
+            assert set(net._chunk_graphs) == {(20, (10,)), (20, (0,)), (20, ())}
     assert outs[0].shape == (b, 16 * (20 * n_chunks - 1) + 16)
     assert torch.equal(outs[0], outs[1])
     for a, c in zip(*states):
@@ -220,6 +221,31 @@ def test_chunk_graph_equals_the_hop_loop_across_mem_lstm_updates(dev):
     for i in range(3):
         got = net.streaming_inference_chunk(wav[:, i * 320:(i + 1) * 320], emb, got)
     assert torch.equal(got, ref) and not torch.equal(got, outs[0][:, :got.shape[1]])
+
+
+def test_chunk_longer_than_a_segment_wraps_the_counter_more_than_once(dev):
+    """A chunk of 170 hops (> seg_size = 150) crosses one or two segment boundaries: every Mem-LSTM update and block-0
+    reset inside it happens in the chunk graph as in the hop loop (round 2 handled at most one per chunk)."""
+    from puresound_amd.streaming.demo import DemoTseNet
+    net = DemoTseNet().eval()
+    net.load_state_dict(det_state_dict(net))
+    net.to(dev)
+    b, hops, n_chunks = 3, 170, 4
+    wav = det_wave(511, b, 16 * hops * n_chunks).to(dev)
+    emb = torch.rand(b, 192, generator=torch.Generator().manual_seed(512)).to(dev)
+    outs = []
+    for use_graph in (False, True):
+        net.init_streams(b, use_graph=use_graph)
+        pre = None
+        for i in range(n_chunks):
+            pre = net.streaming_inference_chunk(wav[:, i * 16 * hops:(i + 1) * 16 * hops], emb, pre)
+        outs.append(pre.clone())
+        if use_graph:
+            assert any(len(u) == 2 for (_, u) in net._chunk_graphs) and len(net._chunk_graphs) <= net._CHUNK_GRAPH_CAP
+    # (170 hops side by side take another GEMM kernel for the output layer than one hop at a time: equal to fp32 rounding,
+    #  not bit for bit as at 20 hops; a dropped Mem-LSTM update shows up at 1e-2)
+    print("max difference", float((outs[0] - outs[1]).abs().max()))
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-6
 
 
 def test_mask_functions_and_magphase_on_the_device(PA, dev, golden_dir):
