@@ -6,3 +6,12 @@ signatures, state_dict keys and error types, with the arithmetic done by hand-wr
 libpuresound_hip.so (C ABI: include/puresound_hip.h).  There is no CPU fallback.
 """
 __version__ = "0.1.0"
+
+
+def _register_operators():
+    """torch.ops.puresound_amd.* exist as soon as the package is imported (the module files register them)."""
+    from . import nnet  # noqa: F401
+    from .streaming import skim_inference  # noqa: F401
+
+
+_register_operators()

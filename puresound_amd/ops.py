@@ -90,6 +90,42 @@ _define("free_decode", "(Tensor feats, Tensor weight, int hop) -> Tensor", _free
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# functional operator: an LSTM recurrence over precomputed gate pre-activations (what nn.LSTM does after its input
+# projection; the DPRNN / SkiM / SingleRNN paths run it as ps_lstm_f32 behind one GEMM for all frames)
+# ---------------------------------------------------------------------------------------------------------------------
+def _lstm_seq_hip(gx: torch.Tensor, whh: torch.Tensor, h0: Optional[torch.Tensor], c0: Optional[torch.Tensor]):
+    """gx [N, T, 4H] = W_ih x_t + b_ih + b_hh (gate order i, f, g, o as in nn.LSTM.weight_ih_l0), whh [4H, H] =
+    weight_hh_l0, optional h0 / c0 [N, H]  ->  (y [N, T, H], h_T [N, H], c_T [N, H])."""
+    from . import hip
+    n, t, rows = gx.shape
+    hid = whh.shape[1]
+    if rows != 4 * hid or whh.shape[0] != 4 * hid:
+        raise RuntimeError(f"lstm_seq_fwd: gx [N, T, 4H] and whh [4H, H] expected, got {tuple(gx.shape)} / {tuple(whh.shape)}")
+    g_rows = hip.pad_rows(gx.float().transpose(1, 2))                     # [N, 4H, ldt]
+    whh_t = whh.detach().float().t().contiguous().reshape(1, hid, 4 * hid)
+    st = []
+    for v in (h0, c0):
+        st.append(None if v is None else hip.pad_rows(v.float().reshape(n, hid, 1)))
+    if (st[0] is None) != (st[1] is None):   # one of the two given: the other starts at zero
+        z = hip.pad_rows(torch.zeros(n, hid, 1, dtype=torch.float32, device=gx.device))
+        st = [z if v is None else v for v in st]
+    hseq, state = hip.lstm(g_rows, whh_t, hid, 1, 1, g_rows.shape[2], t, 1, st[0], st[1], want_state=True)
+    return hip.unpad_rows(hseq, t).transpose(1, 2).contiguous(), state[0][:, :, 0].contiguous(), state[1][:, :, 0].contiguous()
+
+
+def _lstm_seq_meta(gx, whh, h0, c0):
+    n, t, rows = gx.shape
+    hid = whh.shape[1]
+    if rows != 4 * hid or whh.shape[0] != 4 * hid:
+        raise RuntimeError(f"lstm_seq_fwd: gx [N, T, 4H] and whh [4H, H] expected, got {tuple(gx.shape)} / {tuple(whh.shape)}")
+    return gx.new_empty((n, t, hid)), gx.new_empty((n, hid)), gx.new_empty((n, hid))
+
+
+_define("lstm_seq_fwd", "(Tensor gx, Tensor whh, Tensor? h0, Tensor? c0) -> (Tensor, Tensor, Tensor)", _lstm_seq_hip,
+        _lstm_seq_meta)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # module-backed operators
 # ---------------------------------------------------------------------------------------------------------------------
 def module_tensors(m: torch.nn.Module) -> List[torch.Tensor]:
@@ -188,3 +224,23 @@ def op_module(kind: str, shape: Callable, method: str = "forward", rebuild: Opti
 
 def same_shape(ctor, x, aux, params):
     return x
+
+
+def module_op(kind: str, cls, schema: str, hip_impl: Callable, meta_impl: Callable, rebuild: Optional[Callable] = None):
+    """A module-backed operator with a signature of its own (the streaming step: states cross the boundary too).
+    `hip_impl(module, *args)` gets the live (or rebuilt) module; `params` and `cfg` must be the LAST two arguments."""
+    def impl(*args):
+        *rest, params, cfg = args
+        return hip_impl(_resolve(kind, cfg, params), *rest)
+    _KINDS[kind] = dict(cls=cls, method=None, shape=None, rebuild=rebuild or (lambda a: a))
+    _define(kind, schema, impl, meta_impl)
+    return getattr(getattr(torch.ops, NAMESPACE), kind)
+
+
+def call_args(module: torch.nn.Module, kind: str):
+    """(params, cfg) of a module-backed call, and the live-registry entry that lets the implementation find `module`."""
+    params = module_tensors(module)
+    cfg = json.dumps({"ctor": getattr(module, "_ctor_args", None)}, sort_keys=True)
+    if params and params[0].device.type == "cuda":
+        _LIVE[(kind, cfg, tuple(p.data_ptr() for p in params))] = module
+    return params, cfg

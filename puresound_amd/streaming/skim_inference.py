@@ -42,6 +42,29 @@ class StreamingSkiM(SkiM):
     @torch.no_grad()
     def step_chunk(self, x: torch.Tensor, seg_lstm_h_state=None, mem_lstm_h_hidden=None, seg_lstm_c_state=None,
                    mem_lstm_c_hidden=None, embed: Optional[torch.Tensor] = None):
+        """The reference's chunk API (skim_inference.py:41-139) through torch.ops.puresound_amd.skim_chunk: the states the
+        caller carries are flattened into one tensor list (absent ones as empty tensors) and come back the same way."""
+        nb = self.n_blocks
+        e = x.new_empty(0)
+        flat = [e if seg_lstm_h_state is None else seg_lstm_h_state[i] for i in range(nb - 1)]
+        flat += [e if seg_lstm_c_state is None else seg_lstm_c_state[i] for i in range(nb - 1)]
+        for src in (mem_lstm_h_hidden, mem_lstm_c_hidden):
+            for i in range(nb - 1):
+                pair = None if src is None else src[i]
+                flat += [e, e] if pair is None else [pair[0], pair[1]]
+        from ..ops import call_args
+        params, cfg = call_args(self, "skim_chunk")
+        out = torch.ops.puresound_amd.skim_chunk(x, embed, flat, params, cfg)
+        y, rest = out[0], list(out[1:])
+        n1 = nb - 1
+        seg_h, seg_c = rest[:n1], rest[n1:2 * n1]
+        mem_h = [(rest[2 * n1 + 2 * i], rest[2 * n1 + 2 * i + 1]) for i in range(n1)]
+        mem_c = [(rest[4 * n1 + 2 * i], rest[4 * n1 + 2 * i + 1]) for i in range(n1)]
+        return y, seg_h, mem_h, seg_c, mem_c
+
+    @torch.no_grad()
+    def _step_chunk_impl(self, x: torch.Tensor, seg_lstm_h_state=None, mem_lstm_h_hidden=None, seg_lstm_c_state=None,
+                         mem_lstm_c_hidden=None, embed: Optional[torch.Tensor] = None):
         """x [B,K,C] = one whole segment (B = 1 in the reference); states as the reference passes them: seg states
         lists of [D,B,H] for blocks 1.., Mem-LSTM hidden lists of ((h, c)) [D,B,H] (skim_inference.py:41-139).
         A frame-by-frame walk through the blocks equals one pass of every block's SegLSTM over the segment."""
@@ -233,8 +256,25 @@ class StreamingSkiM(SkiM):
             return None
         return self._output(cur, b, out)
 
+    def state_tensors(self) -> List[torch.Tensor]:
+        """The live streaming state in the library's layout (streams on the frame axis): seg h, seg c, Mem-LSTM (h, c) pairs
+        of the h path, then of the c path -- what torch.ops.puresound_amd.skim_step updates in place."""
+        return (list(self._seg_h) + list(self._seg_c) + [t for pair in self._mem_h for t in pair]
+                + [t for pair in self._mem_c for t in pair])
+
     @torch.no_grad()
     def step_frame(self, x: torch.Tensor, embed: Optional[torch.Tensor]) -> torch.Tensor:
+        """The reference's frame API (skim_inference.py:176-218) through torch.ops.puresound_amd.skim_step: x one frame per
+        stream, embed [B,E] -> [B,C_out,1]; the state tensors are arguments of the operator and updated in place."""
+        from ..ops import call_args
+        params, cfg = call_args(self, "skim_step")
+        fc = int(self.frames_counter)
+        y = torch.ops.puresound_amd.skim_step(x, embed, self.state_tensors(), fc, params, cfg)
+        self.frames_counter = (fc + 1) % self.seg_size
+        return y
+
+    @torch.no_grad()
+    def _step_frame_impl(self, x: torch.Tensor, embed: Optional[torch.Tensor]) -> torch.Tensor:
         """x: one frame per stream, [B,C,1] / [B,1,C] / [B,C] (the reference passes [1,C,1] or [1,1,C]);
         embed [B,E] -> [B,C_out,1] (skim_inference.py:176-218)."""
         hip.require_device(x, "StreamingSkiM.step_frame")
@@ -303,3 +343,65 @@ class StreamingSkiM(SkiM):
             self._seg_c[i + 1].copy_(c)
             for dst, src in zip(self._mem_h[i] + self._mem_c[i], hs + cs):
                 dst.copy_(src)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the streaming API at the custom-op boundary: torch.ops.puresound_amd.skim_step / skim_chunk
+# ---------------------------------------------------------------------------------------------------------------------
+def _skim_step_hip(m: "StreamingSkiM", x, embed, state, frames_counter):
+    b = x.numel() // m.input_size
+    own = m.state_tensors() if getattr(m, "_seg_c", None) is not None and getattr(m, "streams", None) == b else None
+    live = own is not None and len(own) == len(state) and all(p.data_ptr() == q.data_ptr() for p, q in zip(own, state))
+    if not live:
+        # a module rebuilt from a loaded trace, or a state set that is not this module's own: run on the module's buffers
+        m.init_status(streams=b, device=x.device, use_graph=False)
+        for dst, src in zip(m.state_tensors(), state):
+            dst.copy_(src)
+    m.frames_counter = int(frames_counter)
+    y = m._step_frame_impl(x, embed)
+    if not live:
+        for dst, src in zip(state, m.state_tensors()):
+            dst.copy_(src)
+    return y
+
+
+def _skim_step_meta(x, embed, state, frames_counter, params, cfg):
+    import json
+    ctor = json.loads(cfg).get("ctor") or {}
+    b = x.numel() // int(ctor["input_size"])
+    return x.new_empty((b, int(ctor["output_size"]), 1))
+
+
+def _skim_chunk_hip(m: "StreamingSkiM", x, embed, states):
+    n1 = m.n_blocks - 1
+    opt = lambda t: None if t.numel() == 0 else t  # noqa: E731
+    seg_h, seg_c = [opt(t) for t in states[:n1]], [opt(t) for t in states[n1:2 * n1]]
+    pairs = lambda off: [None if states[off + 2 * i].numel() == 0 else (states[off + 2 * i], states[off + 2 * i + 1])  # noqa: E731
+                         for i in range(n1)]
+    mem_h, mem_c = pairs(2 * n1), pairs(4 * n1)
+    none_if = lambda lst: None if all(v is None for v in lst) else lst  # noqa: E731
+    y, sh, mh, sc, mc = m._step_chunk_impl(x, none_if(seg_h), none_if(mem_h), none_if(seg_c), none_if(mem_c), embed)
+    return [y] + list(sh) + list(sc) + [t for pair in mh for t in pair] + [t for pair in mc for t in pair]
+
+
+def _skim_chunk_meta(x, embed, states, params, cfg):
+    import json
+    ctor = json.loads(cfg).get("ctor") or {}
+    b, k, _ = x.shape
+    n1, hid = int(ctor["n_blocks"]) - 1, int(ctor["hidden_size"])
+    d = 1 if ctor.get("causal", True) else 2
+    st = lambda: x.new_empty((d, b, hid))  # noqa: E731
+    return [x.new_empty((b, int(ctor["output_size"]), k))] + [st() for _ in range(6 * n1)]
+
+
+def _register_ops():
+    from ..ops import module_op
+    module_op("skim_step", StreamingSkiM,
+              "(Tensor x, Tensor? embed, Tensor(a!)[] state, int frames_counter, Tensor[] params, str cfg) -> Tensor",
+              _skim_step_hip, _skim_step_meta)
+    module_op("skim_chunk", StreamingSkiM,
+              "(Tensor x, Tensor? embed, Tensor[] states, Tensor[] params, str cfg) -> Tensor[]",
+              _skim_chunk_hip, _skim_chunk_meta)
+
+
+_register_ops()

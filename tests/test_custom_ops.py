@@ -16,6 +16,7 @@ import torch
 
 import cases
 import puresound_amd.nnet as PA
+from conftest import rel_max
 from detweights import det_state_dict, det_wave
 from puresound_amd import ops
 
@@ -32,7 +33,7 @@ def _export_parts(model):
 def test_every_operator_has_hip_meta_and_cpu_registrations():
     expected = {"free_encode", "free_decode", "stft_encode", "istft_decode", "conv_tasnet_fwd", "tcn_block_fwd",
                 "gated_tcn_fwd", "attn_stats_pool_fwd", "magnitude_fwd", "dprnn_fwd", "skim_fwd", "unet_fwd",
-                "unet_tcn_fwd", "dpcrn_fwd", "dparn_fwd"}
+                "unet_tcn_fwd", "dpcrn_fwd", "dparn_fwd", "lstm_seq_fwd", "skim_step", "skim_chunk"}
     assert expected <= set(ops.OP_NAMES)
     for name in ops.OP_NAMES:
         for key in ("CUDA", "Meta", "CPU"):
@@ -69,6 +70,30 @@ def test_module_forwards_propagate_shapes_on_the_meta_device(name):
         dvec = dvec.squeeze(-1)
     out = model.masker(feats, dvec) if dvec is not None else model.masker(feats)
     assert out.shape[0] == 2 and out.shape[-1] == t
+
+
+def test_sequence_and_streaming_operators_propagate_shapes_on_the_meta_device():
+    """lstm_seq_fwd and the streaming step (skim_step: the frame API, skim_chunk: the chunk API) are operators
+    with Meta kernels, so a tracer or a shape check sees them."""
+    gx, whh = torch.empty(3, 50, 4 * 64, device="meta"), torch.empty(4 * 64, 64, device="meta")
+    y, h, c = torch.ops.puresound_amd.lstm_seq_fwd(gx, whh, None, torch.empty(3, 64, device="meta"))
+    assert y.shape == (3, 50, 64) and h.shape == (3, 64) and c.shape == (3, 64)
+    with pytest.raises(RuntimeError, match="4H"):
+        torch.ops.puresound_amd.lstm_seq_fwd(gx, torch.empty(100, 64, device="meta"), None, None)
+    from puresound_amd.streaming.skim_inference import StreamingSkiM
+    m = StreamingSkiM(16, 8, 24, n_blocks=3, seg_size=5, causal=True, embed_dim=4, embed_norm=True, embed_fusion="FiLM",
+                      block_with_embed=[1, 1, 1]).to("meta")
+    x, e = torch.empty(2, 5, 16, device="meta"), torch.empty(2, 4, device="meta")
+    out, seg_h, mem_h, seg_c, mem_c = m.step_chunk(x, None, None, None, None, e)
+    assert out.shape == (2, 24, 5) and len(seg_h) == len(seg_c) == len(mem_h) == len(mem_c) == 2
+    assert all(t.shape == (1, 2, 8) for t in seg_h + seg_c) and all(t.shape == (1, 2, 8) for p in mem_h + mem_c for t in p)
+    # the frame step: states are (mutable) arguments of the operator
+    state = [torch.empty(1, 8, 128, device="meta") for _ in range(3 + 3 + 4 + 4)]
+    params, cfg = ops.call_args(m, "skim_step")
+    yf = torch.ops.puresound_amd.skim_step(torch.empty(2, 16, device="meta"), e, state, 0, params, cfg)
+    assert yf.shape == (2, 24, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        torch.ops.puresound_amd.lstm_seq_fwd(torch.zeros(1, 2, 8), torch.zeros(8, 2), None, None)
 
 
 def test_operators_work_under_fake_tensor_mode():
@@ -178,3 +203,78 @@ def test_traced_module_runs_without_the_module_that_recorded_it():
         buf.seek(0)
         t2 = torch.jit.load(buf, map_location=dev)
         assert torch.equal(t2(x, d), want)
+
+
+@pytest.mark.gpu
+def test_lstm_seq_fwd_matches_nn_lstm_on_the_device():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    for n, t, i, h in ((3, 37, 20, 64), (2, 150, 16, 128), (5, 9, 12, 24)):
+        lstm = torch.nn.LSTM(i, h, batch_first=True)
+        x = torch.randn(n, t, i)
+        h0, c0 = torch.randn(1, n, h) * 0.3, torch.randn(1, n, h) * 0.3
+        ref, (hn, cn) = lstm(x, (h0, c0))
+        gx = x @ lstm.weight_ih_l0.t() + lstm.bias_ih_l0 + lstm.bias_hh_l0
+        y, hT, cT = torch.ops.puresound_amd.lstm_seq_fwd(gx.detach().to(dev), lstm.weight_hh_l0.detach().to(dev),
+                                                         h0[0].to(dev), c0[0].to(dev))
+        assert rel_max(y.cpu().numpy(), ref.detach().numpy()) < 1e-5
+        assert rel_max(hT.cpu().numpy(), hn[0].detach().numpy()) < 1e-5
+        assert rel_max(cT.cpu().numpy(), cn[0].detach().numpy()) < 1e-5
+        y0, _, _ = torch.ops.puresound_amd.lstm_seq_fwd(gx.detach().to(dev), lstm.weight_hh_l0.detach().to(dev), None, None)
+        ref0, _ = lstm(x)
+        assert rel_max(y0.cpu().numpy(), ref0.detach().numpy()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_streaming_frame_step_is_a_traceable_operator():
+    """StreamingSkiM.step_frame goes through torch.ops.puresound_amd.skim_step: a trace of it records the operator with
+    the state tensors as (mutated) inputs, and replaying the trace walks the stream exactly as eager calls do --
+    across a Mem-LSTM update."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    from puresound_amd.streaming.skim_inference import StreamingSkiM
+    dev = torch.device("cuda:0")
+    kw = dict(n_blocks=3, seg_size=5, causal=True, embed_dim=4, embed_norm=True, embed_fusion="FiLM",
+              block_with_embed=[1, 1, 1])
+    m = StreamingSkiM(16, 8, 16, **kw).eval()
+    m.load_state_dict(det_state_dict(m))
+    m.to(dev)
+    b = 2
+    x = det_wave(71, b, 12 * 16, 1.0).reshape(b, 12, 16).to(dev)
+    e = det_wave(72, b, 4, 1.0).to(dev)
+    m.init_status(streams=b, use_graph=False)
+    eager = [m.step_frame(x[:, i], e).clone() for i in range(12)]
+    # the operator called directly on a fresh state set equals the method
+    m.init_status(streams=b, use_graph=False)
+    params, cfg = ops.call_args(m, "skim_step")
+    state = [t.clone() for t in m.state_tensors()]
+    direct = []
+    for i in range(12):
+        direct.append(torch.ops.puresound_amd.skim_step(x[:, i], e, state, i % 5, params, cfg).clone())
+    for a, c in zip(eager, direct):
+        assert torch.equal(a, c)
+    # chunk API through its operator == the frames of one segment
+    m2 = StreamingSkiM(16, 8, 16, **kw).eval()
+    m2.load_state_dict(det_state_dict(m2))
+    m2.to(dev)
+    out, *_ = m2.step_chunk(x[:, :5].contiguous(), None, None, None, None, e)
+    assert rel_max(out.cpu().numpy(), torch.cat(eager[:5], dim=2).cpu().numpy()) < 1e-5
+    # a trace records the operator
+    class Step(torch.nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, xx, ee):
+            return self.net.step_frame(xx, ee)
+
+    m.init_status(streams=b, use_graph=False)
+    traced = torch.jit.trace(Step(m), (x[:, 0], e), check_trace=False)
+    assert "puresound_amd::skim_step" in str(traced.inlined_graph)
+    # replay: the trace holds the state tensors (the module's live ones, updated in place) and the frame counter it was
+    # recorded with, so right after recording -- which consumed frame 0 -- it walks frames 1..3 of the segment exactly
+    # as the eager calls did (the Mem-LSTM update of frame 4 depends on the counter, which a trace freezes)
+    for i in range(1, 4):
+        assert torch.equal(traced(x[:, i], e), eager[i]), i
