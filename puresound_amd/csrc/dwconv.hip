@@ -222,6 +222,149 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
   }
 }
 
+// ---- wave-private variant (round 3): P = 3, fp32 rows, halo <= 256 frames -------------------------------------------------
+// The kernel above synchronises a 256-thread workgroup twice per batch of rows; with HBM under load every batch then waits
+// for the slowest of its 256 threads' loads, and the launch ran at 4.0 TB/s where a device copy of the same bytes reaches
+// 6.1 (tools/copy_ceiling.py).  Here a WAVE owns a row segment: 64 lanes x 16-byte loads cover 1024 frames in four
+// coalesced 1 KiB pieces (+ the halo piece), the wave transforms them, writes them to its own LDS strip and reads the taps
+// back -- LDS operations of one wave execute in order, so no workgroup barrier is needed, and the loads of the wave's
+// next row are in flight while it works on the current one.  Same grid, same partial-statistics slots as the kernel
+// above (one (sum, sumsq) per workgroup = 16 rows x 1024 frames).
+constexpr int DWW_SEG = DW_FRAMES + 256;  // frames per LDS strip (64 * DWW_NV pieces): 4 x 5 KiB = 20 KiB per workgroup, so
+                                          // that EIGHT workgroups -- all 2048 of a 32 x 256 x 3999 launch at once -- fit a CU
+constexpr int DWW_NV = 5;                     // 16-byte pieces per lane: 4 + halo
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256, 8) void dwconv_wave_kernel(DwArgs a) {
+  __shared__ __attribute__((aligned(16))) float strip[4][DWW_SEG];
+  double* const red = reinterpret_cast<double*>(&strip[0][0]);  // the two reductions run before / after the strips are in use
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.z;
+  const int h0 = blockIdx.y * DW_ROWS;
+  const int t0 = blockIdx.x * DW_FRAMES;
+  const int halo = 2 * a.dilation;
+  const int lpad = (a.left + 3) / 4 * 4;
+  const int org = t0 - lpad;
+  const int shift = lpad - a.left;
+  const int nvec = DW_FRAMES / 4 + (lpad + halo - a.left + 3) / 4;  // <= 320 (launcher)
+  const bool has_norm = a.pro.norm != PS_NORM_NONE;
+  const bool has_prelu = a.pro.prelu != 0;
+  const float slope = has_prelu ? a.pro.slope[0] : 1.f;
+  const bool slope01 = slope >= 0.f && slope <= 1.f;
+  float* const seg = strip[wave];
+
+  // (one row per wave in flight: at eight waves per SIMD the other waves cover the latency, and a second row in registers
+  //  would push the kernel past 64 VGPRs -- below eight workgroups per CU the launch needs a second, ragged round)
+  f32x4 v[1][DWW_NV];
+  auto load_row = [&](int r, auto q_c) {
+    constexpr int q = decltype(q_c)::value;
+    const int h = h0 + wave + 4 * r;
+    const size_t row = ((size_t)n * a.H + (h < a.H ? h : a.H - 1)) * a.ldt;
+#pragma unroll
+    for (int k = 0; k < DWW_NV; ++k) {
+      const int idx = k * 64 + lane, f = org + idx * 4;
+      v[q][k] = (idx < nvec && f >= 0 && f < a.T) ? *reinterpret_cast<const f32x4*>(a.x + row + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  using q0 = std::integral_constant<int, 0>;
+  load_row(0, q0{});
+  // gamma / beta / taps / bias of the wave's four rows (their loads are in flight behind the row loads)
+  float gam[4], bet[4], w0[4], w1[4], w2[4], bia[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int h = h0 + wave + 4 * r, hc = h < a.H ? h : a.H - 1;
+    gam[r] = has_norm ? a.pro.gamma[hc] : 1.f;
+    bet[r] = has_norm ? a.pro.beta[hc] : 0.f;
+    w0[r] = a.w[hc * 3], w1[r] = a.w[hc * 3 + 1], w2[r] = a.w[hc * 3 + 2];
+    bia[r] = a.b ? a.b[hc] : 0.f;
+  }
+  const NormScalars ns = load_norm_scalars(a.pro, n, red);  // (the only workgroup barriers before the final reduction)
+  __syncthreads();                                          // (red is strip 0: every thread has read its totals)
+  float fsum = 0.f, fsq = 0.f;
+  auto process_row = [&](auto r_c, auto q_c) {
+    constexpr int r = decltype(r_c)::value, q = decltype(q_c)::value;
+    const int h = h0 + wave + 4 * r;
+    const float sc = has_norm ? gam[r] * ns.rstd : 1.f;
+    const float sh = bet[r] - ns.mean * sc;
+#pragma unroll
+    for (int k = 0; k < DWW_NV; ++k) {
+      const int idx = k * 64 + lane, f = org + idx * 4;
+      if (k == DWW_NV - 1 && idx >= nvec) continue;
+      f32x4 u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float z = v[q][k][e] * sc + sh;
+        if (has_prelu) z = slope01 ? fmaxf(z, slope * z) : prelu(z, slope);
+        u[e] = z;
+      }
+      if (!(f >= 0 && f + 3 < a.T)) {  // edge pieces only: the conv's zero padding, applied AFTER norm + PReLU
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = (f + e >= 0 && f + e < a.T) ? u[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(seg + idx * 4) = u;
+    }
+    __builtin_amdgcn_wave_barrier();  // (the wave's own writes above, its own reads below: in order in the LDS queue)
+    asm volatile("" ::: "memory");
+    if (h < a.H) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = t0 + (k * 64 + lane) * 4;
+        if (t < a.T) {
+          const float* sp = seg + (k * 64 + lane) * 4 + shift;
+          f32x4 s0, s1, s2;
+          if constexpr (ALIGNED) {
+            s0 = *reinterpret_cast<const f32x4*>(sp);
+            s1 = *reinterpret_cast<const f32x4*>(sp + a.dilation);
+            s2 = *reinterpret_cast<const f32x4*>(sp + 2 * a.dilation);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s0[e] = sp[e], s1[e] = sp[a.dilation + e], s2[e] = sp[2 * a.dilation + e];
+          }
+          f32x4 out;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) out[e] = ((bia[r] + w0[r] * s0[e]) + w1[r] * s1[e]) + w2[r] * s2[e];
+          if (t + 3 < a.T) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              fsum += out[e];
+              fsq += out[e] * out[e];
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (t + e < a.T) {
+                fsum += out[e];
+                fsq += out[e] * out[e];
+              }
+          }
+          *reinterpret_cast<f32x4*>(a.y + ((size_t)n * a.H + h) * a.ldt + t) = out;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  };
+  process_row(std::integral_constant<int, 0>{}, q0{});
+  load_row(1, q0{});
+  process_row(std::integral_constant<int, 1>{}, q0{});
+  load_row(2, q0{});
+  process_row(std::integral_constant<int, 2>{}, q0{});
+  load_row(3, q0{});
+  process_row(std::integral_constant<int, 3>{}, q0{});
+  if (a.ostats) {
+    double s = fsum, q = fsq;
+    __syncthreads();  // (every wave is done with its strip)
+    block_sum2(s, q, red);
+    if (tid == 0) {
+      const int parts = gridDim.x * gridDim.y;
+      double* dst = a.ostats + ((size_t)n * parts + blockIdx.y * gridDim.x + blockIdx.x) * 2;
+      dst[0] = s;
+      dst[1] = q;
+    }
+  }
+}
+
 }  // namespace ps
 
 extern "C" int ps_dwconv_stats_parts(int H, int T) {
@@ -309,6 +452,10 @@ extern "C" int ps_dwconv_io(const void* x_any, int x_bf16, const float* w, const
         else PS_DW(false, false, true);
       }
 #undef PS_DW
+    } else if (P == 3 && 2 * dilation <= 256 && DW_FRAMES / 4 + ((left + 3) / 4 * 4 + 2 * dilation - left + 3) / 4 <= 64 * DWW_NV &&
+               !(g_debug_flags & 1)) {  // (ps_debug_flags bit 0 keeps the workgroup-synchronised kernel: tests run both)
+      if (aligned) hipLaunchKernelGGL((dwconv_wave_kernel<true>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dwconv_wave_kernel<false>), grid, dim3(256), 0, st, a);
     } else if (P == 3 && aligned && small)
       hipLaunchKernelGGL((dwconv_kernel<3, true, DW_SMALLHALO>), grid, dim3(256), 0, st, a);
     else if (P == 3 && small)

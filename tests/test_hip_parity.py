@@ -150,7 +150,7 @@ def test_conv1x1_prologue(H, dev, norm, n, k, m, t):
 
 @pytest.mark.parametrize("p,dil,causal", [(3, 1, False), (3, 2, False), (3, 4, False), (3, 8, False), (3, 128, False),
                                           (3, 3, False), (5, 9, False), (3, 1, True), (3, 2, True), (3, 16, True)])
-@pytest.mark.parametrize("n,h,t", [(2, 12, 77), (1, 40, 1500)])
+@pytest.mark.parametrize("n,h,t", [(2, 12, 77), (1, 40, 1500), (2, 19, 4001)])
 def test_dwconv(H, dev, p, dil, causal, n, h, t):
     from puresound_amd import _abi
     x = _rand((n, h, t), 15) + 0.1
@@ -164,11 +164,18 @@ def test_dwconv(H, dev, p, dil, causal, n, h, t):
     stats = torch.stack([x.double().sum((1, 2)), (x.double() ** 2).sum((1, 2))], -1).reshape(n, 1, 2).to(dev)
     g_d, b_d, s_d = gamma.to(dev), beta.to(dev), slope.to(dev)
     pro = H.make_prologue(_abi.PS_NORM_GLOBAL, True, stats, h * t, 1e-8, g_d, b_d, s_d)
-    y, st = H.dwconv(H.pad_rows(x.to(dev)), t, w.to(dev), b.to(dev), dil, left, pro, want_stats=True)
-    assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 1e-5
-    s = st.sum(1).cpu().numpy()
-    np.testing.assert_allclose(s[:, 0], ref.double().sum((1, 2)).numpy(), rtol=1e-5, atol=1e-3)
-    np.testing.assert_allclose(s[:, 1], (ref.double() ** 2).sum((1, 2)).numpy(), rtol=1e-5)
+    # 0: the wave-private kernel where the shape allows it (P = 3, halo <= 256), bit 0: the workgroup-synchronised kernel
+    for flags in (0, 1):
+        old = _abi.lib().ps_debug_flags(flags)
+        try:
+            y, st = H.dwconv(H.pad_rows(x.to(dev)), t, w.to(dev), b.to(dev), dil, left, pro, want_stats=True)
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
+        assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 1e-5, flags
+        s = st.sum(1).cpu().numpy()
+        np.testing.assert_allclose(s[:, 0], ref.double().sum((1, 2)).numpy(), rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(s[:, 1], (ref.double() ** 2).sum((1, 2)).numpy(), rtol=1e-5)
 
 
 @pytest.mark.parametrize("grid_cap", [1, 2, 3])
