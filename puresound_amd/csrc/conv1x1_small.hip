@@ -189,6 +189,7 @@ struct ProjLnArgs {
   int res_inside;  // 0: y = res + LN(W x + b)   1: y = LN(W x + b + res)  (post-norm transformer blocks)
   float eps, eps2;
   int K, Kp, M, T, ldt;
+  int N;  // (the persistent row kernel walks utterances itself)
 };
 
 constexpr int PLN_MAXM = 256;
@@ -294,6 +295,139 @@ __global__ __launch_bounds__(64 * NW) void proj_layernorm_kernel(ProjLnArgs a) {
       for (int m = cp; m < a.M; m += CP)
         a.y2[((size_t)n * a.M + m) * a.ldt + t] = (tile[m][f] - mean) * rstd * a.gamma2[m] + a.beta2[m];
   }
+}
+
+// The same operator on LONG rows (the offline DPRNN / SkiM / DPCRN paths: every frame of a 32 x 4 s batch goes through
+// it twice per block): the kernel above owns 16 frames per workgroup and moves 64-byte pieces -- 141 us per launch at
+// 32 x 4000 frames, C = 128, H = 64 (163 MB: 1.2 TB/s).  Here a wave owns 32 frames x ALL output channels as NB
+// 32 x 32 accumulator blocks of v_mfma_f32_32x32x2_f32 (exact fp32 products): lanes 0-31 / 32-63 hold two rows of 32
+// consecutive frames, so every global access is two 128-byte pieces, the projection matrix sits in LDS ([k][m], rows
+// padded by 32 floats: the two half-waves read different banks), and a frame's LayerNorm needs the lane's own registers
+// and ONE exchange with lane ^ 32.  Two-pass variance as the reference.
+template <int NB>
+__global__ __launch_bounds__(256) void proj_layernorm_rows_kernel(ProjLnArgs a) {
+  constexpr int MB = NB * 32, LDW = MB + 32;
+  extern __shared__ __attribute__((aligned(16))) float pl_smem[];
+  float* wl = pl_smem;                 // [Kp][LDW]
+  float* gl = wl + (size_t)a.Kp * LDW;  // gamma[MB] | beta[MB] | bias[MB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  // the projection matrix goes to LDS ONCE per (persistent) workgroup: 16-byte loads, eight in flight per thread (a
+  // dword-at-a-time loop of dependent load / store pairs cost 20 us per workgroup -- more than its tiles)
+  {
+    constexpr int V4 = MB / 4;  // float4 pieces per k-row (the packer's rows are 256 floats: zero beyond M and K)
+    const int nv = a.Kp * V4;
+    for (int i0 = tid; i0 < nv; i0 += 256 * 8) {
+      f32x4 wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u;
+        const int k = i / V4, m4 = i % V4;
+        wv[u] = i < nv ? *reinterpret_cast<const f32x4*>(a.wt + (size_t)k * 256 + 4 * m4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < nv) *reinterpret_cast<f32x4*>(wl + (i / V4) * LDW + 4 * (i % V4)) = wv[u];
+      }
+    }
+  }
+  for (int m = tid; m < MB; m += 256) {
+    gl[m] = m < a.M ? a.gamma[m] : 0.f;
+    gl[MB + m] = m < a.M ? a.beta[m] : 0.f;
+    gl[2 * MB + m] = (m < a.M && a.bias) ? a.bias[m] : 0.f;
+  }
+  __syncthreads();
+  const int tb = (a.T + 127) / 128;  // 128-frame blocks per utterance
+  for (int tile = blockIdx.x; tile < tb * a.N; tile += gridDim.x) {
+  const int n = tile / tb, t0 = (tile % tb) * 128 + wave * 32;
+  if (t0 >= a.T) continue;
+  const int t = t0 + lr;
+  const bool live = t < a.T;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const float* xp = a.x + (size_t)n * a.K * a.ldt + t;  // (frames beyond T inside the row are padding: computed, not stored)
+  // the residual values of the tile are requested up front, next to the activations: behind the MFMAs they would be 16 NB
+  // dependent loads per lane with nothing left to hide them (the first version: 40 us per tile)
+  const size_t row0 = (size_t)n * a.M * a.ldt + t;
+  float rv[NB][16];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      rv[j][r] = (a.res && live && c < a.M) ? a.res[row0 + (size_t)c * a.ldt] : 0.f;
+    }
+  constexpr int KU = 16;                                // k-pairs whose activation loads are in flight together
+  for (int k0 = 0; k0 < a.Kp; k0 += 2 * KU) {
+    float bv[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int k = k0 + 2 * u + lh;
+      bv[u] = (k < a.K && t < a.ldt) ? xp[(size_t)k * a.ldt] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int k = k0 + 2 * u + lh;
+      if (k0 + 2 * u < a.Kp) {
+        const float* wr = wl + k * LDW + lr;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[j * 32], bv[u], acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // element (j, r) of this lane: channel 32 j + (r & 3) + 8 (r >> 2) + 4 lh, frame t
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int c0 = 32 * j + 8 * rq + 4 * lh;
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(gl + 2 * MB + c0);
+#pragma unroll
+      for (int r3 = 0; r3 < 4; ++r3) {
+        const int c = c0 + r3;
+        float v = acc[j][rq * 4 + r3] + b4[r3];
+        if (a.res_inside) v += rv[j][rq * 4 + r3];
+        v = c < a.M ? v : 0.f;
+        acc[j][rq * 4 + r3] = v;
+        s += v;
+      }
+    }
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s / (float)a.M;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float dv = c < a.M ? acc[j][r] - mean : 0.f;
+      q += dv * dv;
+    }
+  q += __shfl_xor(q, 32, 64);
+  const float rstd = 1.f / sqrtf(q / (float)a.M + a.eps);
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int c0 = 32 * j + 8 * rq + 4 * lh;
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(gl + c0), be4 = *reinterpret_cast<const f32x4*>(gl + MB + c0);
+#pragma unroll
+      for (int r3 = 0; r3 < 4; ++r3) {
+        const int c = c0 + r3;
+        if (live && c < a.M) {
+          float v = (acc[j][rq * 4 + r3] - mean) * rstd * g4[r3] + be4[r3];
+          const size_t off = row0 + (size_t)c * a.ldt;
+          if (!a.res_inside) v += rv[j][rq * 4 + r3];
+          a.y[off] = v;
+        }
+      }
+    }
+  }  // tiles
 }
 
 int conv1x1_small_launch(const float* x, const float* wt, float* y, int N, int K, int M, int T, int ldt,
@@ -424,7 +558,25 @@ extern "C" int ps_proj_layernorm_f32(const float* x, const float* wt, const floa
     set_error("ps_proj_layernorm_f32: M=%d > %d output channels", M, PLN_MAXM);
     return PS_E_UNSUPPORTED;
   }
-  ProjLnArgs a{x, wt, bias, gamma, beta, res, y, gamma2, beta2, y2, x_copy, res_inside, eps, eps2, K, (K + 15) / 16 * 16, M, T, ldt};
+  ProjLnArgs a{x, wt, bias, gamma, beta, res, y, gamma2, beta2, y2, x_copy, res_inside, eps, eps2, K, (K + 15) / 16 * 16, M, T, ldt, N};
+  // long rows without the streaming step's extras: the row kernel (ps_debug_flags bit 4 keeps the 16-frame kernel: tests
+  // compare the two on the same data)
+  const int kp = (K + 15) / 16 * 16;
+  const int nb = M <= 128 ? 4 : 8;
+  const size_t lds = ((size_t)kp * (nb * 32 + 32) + 3 * nb * 32) * sizeof(float);
+  if (!y2 && !x_copy && T >= 128 && lds <= 64 * 1024 && !(g_debug_flags & 16)) {
+    LaunchTimer timer("proj_layernorm", (hipStream_t)stream);
+    const long long tiles = (long long)((T + 127) / 128) * N;
+    // one persistent workgroup per CU (the kernel holds a tile's accumulators AND its residual values: 256 registers, one
+    // wave per SIMD): the projection matrix is staged once, not once per tile
+    const long long slots = device_cus();
+    dim3 grid((unsigned)(tiles < slots ? tiles : slots));
+    if (nb == 4)
+      hipLaunchKernelGGL((proj_layernorm_rows_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((proj_layernorm_rows_kernel<8>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    return small_status("ps_proj_layernorm_f32");
+  }
   {
     LaunchTimer timer("proj_layernorm", (hipStream_t)stream);
     // few workgroups (the streaming step: one per 16 streams): the kernel is a latency chain, eight waves split K

@@ -765,6 +765,39 @@ def test_fused_streaming_step_kernels(H, dev):
         assert torch.equal(cp[..., :t].cpu(), hx)
 
 
+@pytest.mark.parametrize("n,k,m,t", [(3, 64, 128, 4000), (1, 64, 128, 1501), (5, 20, 100, 900), (2, 32, 256, 777),
+                                     (1, 100, 200, 4100)])
+@pytest.mark.parametrize("res_inside", [False, True])
+def test_proj_layernorm_on_long_rows(H, dev, n, k, m, t, res_inside):
+    """ps_proj_layernorm_f32 on the offline paths' long rows: the row kernel (32 frames x all channels per wave,
+    v_mfma_f32_32x32x2_f32) and, with ps_debug_flags bit 4, the 16-frame kernel of the streaming step -- both against
+    res + LN(W x + b) / LN(W x + b + res) in fp64."""
+    from puresound_amd import _abi
+    hx, res = _rand((n, k, t), 210), _rand((n, m, t), 211)
+    wp, bp = _rand((m, k), 212, -0.3, 0.3), _rand((m,), 213)
+    g1, b1 = _rand((m,), 214, 0.5, 1.5), _rand((m,), 215)
+    p = torch.matmul(wp.double(), hx.double()) + bp.double().reshape(1, -1, 1)
+    if res_inside:
+        p = p + res.double()
+    mu = p.mean(1, keepdim=True)
+    var = ((p - mu) ** 2).mean(1, keepdim=True)
+    ref = (p - mu) / torch.sqrt(var + 1e-5) * g1.double().reshape(1, -1, 1) + b1.double().reshape(1, -1, 1)
+    if not res_inside:
+        ref = ref + res.double()
+    outs = []
+    for flags in (0, 16):
+        old = _abi.lib().ps_debug_flags(flags)
+        try:
+            y, _ = H.proj_layernorm(H.pad_rows(hx.to(dev)), t, H.pack_wt(wp.to(dev)), bp.to(dev), m, g1.to(dev), b1.to(dev),
+                                    1e-5, H.pad_rows(res.to(dev)), res_inside=res_inside)
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
+        assert rel_max(y[..., :t].cpu().double().numpy(), ref.numpy()) < 2e-5, flags
+        outs.append(y[..., :t].cpu())
+    assert rel_max(outs[0].numpy(), outs[1].numpy()) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------
 # bf16 matrix pipe: plain bf16 products (planes = 1) and the fp32-accurate 3-way split (planes = 3)
 # ------------------------------------------------------------------------------------------------
