@@ -398,8 +398,9 @@ class ConvTasNet(_PlanCache, nn.Module):
         self._workspace = None
 
     def set_gemm_precision(self, name: str) -> "ConvTasNet":
-        """"bf16x3" (default) | "fp32" | "fp16x2" | "bf16" for the 1x1 convs of every normal TCN block (see
-        TCN.gemm_precision)."""
+        """"fp16x2" (default: two fp16 terms per operand, three products) | "bf16x3" | "fp32" | "bf16" for the 1x1 convs of
+        every normal TCN block (see TCN.gemm_precision).  The switch is per module; the process-wide
+        set_recurrent_gemm_precision / PS_RECURRENT_GEMM of round 1 no longer exist."""
         if name not in GEMM_PLANES:
             raise ValueError(f"gemm precision must be one of {sorted(GEMM_PLANES)}")
         for stack in self.tcn_list:

@@ -47,7 +47,9 @@ class FreeEncDec(nn.Module):
 
     # -- padded-layout entry points used by the fused wrapper ---------------------------------
     def encode_padded(self, x: torch.Tensor, min_frames=None):
-        """[N,L] -> (padded feats [N,C,ldt], T); rows are zero beyond T and hold at least min_frames(T) frames."""
+        """[N,L] -> (padded feats [N,C,ldt], T); rows hold at least min_frames(T) frames.  Frames in [T, ldt) are
+        UNDEFINED (uninitialised memory no kernel reads as data) unless min_frames(T) > T: then they are zero, as the
+        segment padding of the dual-path maskers needs them."""
         return hip.free_encode(x, self.encoder.weight.detach(), self.hop_length, self.output_active, min_frames)
 
     def feature_bound(self, x: torch.Tensor) -> torch.Tensor:

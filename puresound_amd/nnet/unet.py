@@ -27,7 +27,19 @@ import os
 IMPLICIT_CONV = os.environ.get("PS_IMPLICIT_CONV", "1") == "1"
 
 
-@op_module("unet_fwd", same_shape)
+def _unet_shape(ctor, x, aux, params):
+    """[N, C, F, T] -> the same, or [N, multi_output, C', T] when the up stack emits several outputs (unet.py:253-254)."""
+    mo = int((ctor or {}).get("multi_output", 1) or 1)
+    if mo == 1:
+        return x
+    n, t = x[0], x[-1]
+    per = 1
+    for d in x[1:-1]:
+        per *= d
+    return (n, mo, per, t)
+
+
+@op_module("unet_fwd", _unet_shape)
 class Unet(PlanCache, nn.Module):
     """unet.py:13-296; constructor order as the reference (unet.py:35-53)."""
 
@@ -288,7 +300,7 @@ class Unet(PlanCache, nn.Module):
                 "multi_output": self.multi_output}
 
 
-@op_module("unet_tcn_fwd", same_shape)
+@op_module("unet_tcn_fwd", _unet_shape)
 class UnetTcn(Unet):
     """U-Net with a (gated) TCN bottleneck (unet.py:298-557)."""
 

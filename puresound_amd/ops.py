@@ -128,6 +128,20 @@ _define("lstm_seq_fwd", "(Tensor gx, Tensor whh, Tensor? h0, Tensor? c0) -> (Ten
 # ---------------------------------------------------------------------------------------------------------------------
 # module-backed operators
 # ---------------------------------------------------------------------------------------------------------------------
+def _call_cache(m: torch.nn.Module, kind: str):
+    """(params, cfg) of a module-backed call.  The parameter list is read off the module every time (a load_state_dict
+    with assign=True, .to(), a swapped sub-module all change it); the JSON of the constructor arguments -- a constant of
+    the module -- is serialised once."""
+    cfg = m.__dict__.get("_op_cfg_json")
+    if cfg is None:
+        cfg = json.dumps({"ctor": getattr(m, "_ctor_args", None)}, sort_keys=True)
+        object.__setattr__(m, "_op_cfg_json", cfg)
+    params = module_tensors(m)
+    if params and params[0].device.type == "cuda":
+        _LIVE[(kind, cfg, tuple(p.data_ptr() for p in params))] = m
+    return params, cfg
+
+
 def module_tensors(m: torch.nn.Module) -> List[torch.Tensor]:
     """Parameters then buffers, in registration order (the order `adopt_tensors` assigns them back in)."""
     return [p for _, p in m.named_parameters()] + [b for _, b in m.named_buffers()]
@@ -153,8 +167,8 @@ def _resolve(kind: str, cfg: str, params: Sequence[torch.Tensor]) -> torch.nn.Mo
                                f"arguments are not serialisable")
         m = info["cls"](**info["rebuild"](args["ctor"])).eval()
         adopt_tensors(m, params)
-        if len(_REBUILT) > 64:
-            _REBUILT.clear()
+        while len(_REBUILT) >= 64:   # bounded; the oldest rebuilt module goes first
+            _REBUILT.pop(next(iter(_REBUILT)))
         _REBUILT[key] = m
     return m
 
@@ -206,12 +220,26 @@ def op_module(kind: str, shape: Callable, method: str = "forward", rebuild: Opti
         _KINDS[kind] = dict(cls=cls, method=method, shape=shape, rebuild=rebuild or (lambda a: a))
         op = getattr(getattr(torch.ops, NAMESPACE), kind)
 
-        def routed(self, x, aux=None):
-            params = module_tensors(self)
-            cfg = json.dumps({"ctor": getattr(self, "_ctor_args", None)}, sort_keys=True)
-            if x.device.type == "cuda":
-                _LIVE[(kind, cfg, tuple(p.data_ptr() for p in params))] = self
-            with torch.no_grad():  # forward only: there is no backward kernel, outputs carry no graph
+        names = [p.name for p in inspect.signature(body).parameters.values()
+                 if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)][1:]   # e.g. ["x", "embed"] / ["x", "dvec"]
+
+        def routed(self, *args, **kw):
+            # the reference's own call forms keep working: forward(x), forward(x, e), forward(x, embed=e), forward(x=..)
+            if len(args) > len(names) or any(k not in names for k in kw) or any(n in kw for n in names[:len(args)]):
+                raise TypeError(f"{cls.__name__}.{method}() takes {names}, got {len(args)} positional and {sorted(kw)}")
+            vals = dict(zip(names, args))
+            vals.update(kw)
+            if names[0] not in vals:
+                raise TypeError(f"{cls.__name__}.{method}() is missing {names[0]!r}")
+            x = vals[names[0]]
+            aux = vals.get(names[1]) if len(names) > 1 else None
+            # forward only: no backward kernel is registered, so a caller who expects gradients is told, not handed a
+            # detached tensor (SoTaskWrapModule's training forwards raise for the same reason)
+            if torch.is_grad_enabled() and self.training and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+                raise RuntimeError(f"{cls.__name__}.{method}: the HIP path is inference only (no backward kernels) -- "
+                                   f"call .eval() or run under torch.no_grad()")
+            params, cfg = _call_cache(self, kind)
+            with torch.no_grad():  # outputs carry no graph
                 return op(x, aux, params, cfg)
 
         routed.__doc__ = body.__doc__

@@ -96,6 +96,30 @@ def test_sequence_and_streaming_operators_propagate_shapes_on_the_meta_device():
         torch.ops.puresound_amd.lstm_seq_fwd(torch.zeros(1, 2, 8), torch.zeros(8, 2), None, None)
 
 
+def test_routed_forwards_keep_the_reference_call_forms():
+    """The operator wrapper keeps the forward's own parameter names (forward(x, embed=...), forward(x, dvec=...)), refuses
+    to hand a detached result to a caller that expects gradients, and reports the U-Net's multi-output shape."""
+    masker = PA.ConvTasNet(16, 8, True, tcn_kernel=3, tcn_dim=8, repeat_tcn=1, tcn_dilated_basic=2, per_tcn_stack=2,
+                           tcn_with_embed=[1, 0], tcn_norm="gLN", dconv_norm="gGN", causal=False).eval().to("meta")
+    x, d = torch.empty(2, 16, 50, device="meta"), torch.empty(2, 8, device="meta")
+    name = [p for p in __import__("inspect").signature(masker._hip_forward).parameters][1]
+    assert masker(x, d).shape == masker(x, **{name: d}).shape == (2, 16, 50)
+    with pytest.raises(TypeError):
+        masker(x, nonsense=d)
+    masker.train()
+    with pytest.raises(RuntimeError, match="inference only"):
+        masker(x, d)
+    with torch.no_grad():
+        assert masker(x, d).shape == (2, 16, 50)
+    # the parameter list of a call follows a parameter swap (load_state_dict(assign=True) replaces the tensors)
+    from puresound_amd.ops import _call_cache
+    masker.eval()
+    p1, c1 = _call_cache(masker, "conv_tasnet_fwd")
+    masker.load_state_dict({k: v.clone() for k, v in masker.state_dict().items()}, assign=True)
+    p2, c2 = _call_cache(masker, "conv_tasnet_fwd")
+    assert c1 is c2 and all(a is b for a, b in zip(p2, ops.module_tensors(masker))) and not any(a is b for a, b in zip(p1, p2))
+
+
 def test_operators_work_under_fake_tensor_mode():
     from torch._subclasses.fake_tensor import FakeTensorMode
     enc = PA.FreeEncDec(32, 64, 16)
