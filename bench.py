@@ -31,8 +31,8 @@ HBM_PEAK_GBPS = 8000.0  # same guide: HBM3E, ~8 TB/s
 # need their own rocprofv3 passes -- so it is READ from the summary of those passes committed under profiles/
 # (tools/pmc_summary.py; same command line as this benchmark, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
 # gfx950) and labelled with the file it came from.  It never enters `frac`.
-PMC_FILES = {"fp16x2": "profiles/r02_pmc_hbm_traffic_fp16x2.json", "bf16x3": "profiles/r02_pmc_hbm_traffic_bf16x3.json",
-             "fp32": "profiles/r02_pmc_hbm_traffic_fp32.json"}
+PMC_FILES = {"fp16x2": "profiles/r03_pmc_hbm_traffic_fp16x2.json", "bf16x3": "profiles/r03_pmc_hbm_traffic_bf16x3.json",
+             "fp32": "profiles/r03_pmc_hbm_traffic_fp32.json"}
 
 
 def pmc_traffic(gemm, prefix):

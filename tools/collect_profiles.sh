@@ -1,14 +1,14 @@
 #!/bin/bash
 # Collect the round's judged profiles on the GPU box (run through gpurun from the repo root):
 #   kernel trace + stats of the default bench.py command, PMC HBM-traffic passes (FETCH_SIZE / WRITE_SIZE separately)
-# usage: tools/collect_profiles.sh r02
+# usage: tools/collect_profiles.sh r03
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $out/bench_under_rocprof.log 2>&1
 grep '^{' $out/bench_under_rocprof.log > $out/bench_line_under_rocprof.json
 for gemm in fp16x2 bf16x3 fp32; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_f_$gemm -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --gemm $gemm > /dev/null 2>&1
