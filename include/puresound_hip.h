@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 7
+#define PS_ABI_VERSION 8
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -96,6 +96,14 @@ int ps_free_encode_f32(const float* wav, const float* w, float* feats, int N, in
  * ------------------------------------------------------------------------------------------- */
 int ps_free_decode_f32(const float* feats, const float* mask, int mask_act, const float* w, float* out,
                        int N, int C, int T, int ldt, int win, int hop, int out_mode, void* stream);
+/* The same with a scratch buffer (ps_free_decode_workspace_bytes; 0 = this shape has no use for one): for win = 32,
+ * hop = 16 on long rows the decoder then runs on the matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 products; a tile of
+ * 32 frames per wave, the tiles' boundary samples completed by a second small launch).  Without a workspace, or for any
+ * other shape, it is ps_free_decode_f32. */
+size_t ps_free_decode_workspace_bytes(int N, int T, int win, int hop);
+int ps_free_decode_ws_f32(const float* feats, const float* mask, int mask_act, const float* w, float* out, int N, int C,
+                          int T, int ldt, int win, int hop, int out_mode, void* workspace, size_t workspace_bytes,
+                          void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Conv-STFT encoder / iSTFT decoder (ConvSTFT.forward / .inverse, lobe/encoder.py:358-456; extend_fbins,

@@ -142,6 +142,173 @@ __global__ __launch_bounds__(256) void free_decode_kernel(const float* __restric
   }
 }
 
+// ---- round 3: encoder and decoder on the matrix pipe (win = 32, hop = 16) -----------------------------------------------
+// Both are thin GEMMs -- feats = W [C x 32] . windows [32 x T], frames = W^T [32 x C] . e [C x T] -- and the VALU kernels
+// above spend 32 multiply-adds per 4 bytes moved: 61 us of FMA issue per launch at 32 x 512 x 3999 even at a perfect
+// VALU rate (measured 113 / 187 us; 0.29 / 0.36 of 8 TB/s).  On v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulate:
+// the products are exact, the result differs from the VALU kernels only in summation order) the arithmetic takes 31 us
+// of matrix-pipe time per launch and the kernels are the HBM-bound streams they should be.
+//
+// Encoder: a wave owns a block of 32 channels -- its 16 weight fragments (k pairs of the 32-tap window) stay in registers
+// -- and walks frame tiles of 32; the 528 samples a tile touches are staged once per workgroup in LDS (frame stride 17
+// floats: the B fragment read x[16 (t0 + lane) + j] would otherwise be an 8-way bank conflict); a store instruction
+// covers 32 consecutive frames of two channels (two 128-byte pieces).
+#ifndef PS_EM_TILES
+#define PS_EM_TILES 8
+#endif
+constexpr int EM_TILES = PS_EM_TILES;  // frame tiles per workgroup
+
+__global__ __launch_bounds__(256) void free_encode_mfma_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+                                                               float* __restrict__ feats, int L, int C, int T, int ldt,
+                                                               int relu) {
+  __shared__ float xs[34 * 17];
+  __shared__ float ws[128 * 33];  // the workgroup's 128 filter rows, row stride 33 floats (conflict-free fragment reads)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int n = blockIdx.z;
+  const int c_base = (blockIdx.y * 4 + wave) * 32;
+  const bool cb_live = c_base < C;  // (C is a multiple of 32: launcher)
+  // the 128 rows are 16 KiB contiguous in memory: one coalesced pass into LDS, then every lane picks its row's taps
+  // (read straight from memory a lane's 16 taps are 16 loads that touch 32 cache lines each: a workgroup with one tile
+  //  took 139 us per launch, with four 88)
+  for (int i = tid; i < 128 * 8; i += 256) {
+    const int row = i >> 3, q = i & 7;
+    const f32x4 v = (blockIdx.y * 128 + row) < C ? *reinterpret_cast<const f32x4*>(w + (size_t)(blockIdx.y * 128 + row) * 32 + 4 * q)
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ws[row * 33 + 4 * q + e] = v[e];
+  }
+  __syncthreads();
+  float wa[16];
+#pragma unroll
+  for (int kp = 0; kp < 16; ++kp) wa[kp] = ws[(wave * 32 + lr) * 33 + 2 * kp + lh];
+  const float* x = wav + (size_t)n * L;
+  const int tile0 = blockIdx.x * EM_TILES;
+  float pre[3];
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int i = tid + 256 * q, sidx = 16 * 32 * tile + i;
+      pre[q] = (i < 528 && sidx < L) ? x[sidx] : 0.f;
+    }
+  };
+  fetch(tile0);
+  for (int tile = tile0; tile < tile0 + EM_TILES; ++tile) {
+    const int t0 = tile * 32;
+    if (t0 >= T) break;
+    __syncthreads();  // the previous tile's fragment reads are done
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int i = tid + 256 * q;
+      if (i < 528) xs[(i >> 4) * 17 + (i & 15)] = pre[q];
+    }
+    __syncthreads();
+    if (tile + 1 < tile0 + EM_TILES && (tile + 1) * 32 < T) fetch(tile + 1);
+    if (!cb_live) continue;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kp = 0; kp < 16; ++kp) {
+      const int j = 2 * kp + lh;  // tap of this lane's k
+      const float b = xs[(lr + (j >> 4)) * 17 + (j & 15)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[kp], b, acc, 0, 0, 0);
+    }
+    const int t = t0 + lr;
+    if (t < T) {
+      float* o = feats + ((size_t)n * C + c_base + 4 * lh) * ldt + t;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[r];
+        if (relu) v = relu_keep_nan(v);
+        o[(size_t)((r & 3) + 8 * (r >> 2)) * ldt] = v;
+      }
+    }
+  }
+}
+
+// Decoder: a wave owns one tile of 32 frames and walks all channels (k pairs): the B fragment is feats * act(mask) of 32
+// consecutive frames of two channels (two 128-byte pieces per load), the A fragment the two channels' 32 filter taps
+// (256 contiguous bytes, L2-resident: 64 KiB in all).  The 32 x 32 result holds every frame's 32 output samples; the
+// overlap-add of a frame's head with its left neighbour's tail is one lane shift inside the wave.  Only a tile's FIRST
+// frame needs the previous tile's last tail: the tile stores its partial head there and its own last tail to a small
+// side buffer, and free_decode_fixup_kernel adds the two and applies the output constraint (deterministic: one writer
+// per sample, no atomics).
+#ifndef PS_DM_UC
+#define PS_DM_UC 8
+#endif
+constexpr int DM_UC = PS_DM_UC;  // k pairs whose loads are in flight together per wave
+
+__global__ __launch_bounds__(256) void free_decode_mfma_kernel(const float* __restrict__ feats, const float* __restrict__ mask,
+                                                               int mask_mode, const float* __restrict__ w,
+                                                               float* __restrict__ out, float* __restrict__ tails, int C,
+                                                               int T, int ldt, int ntiles, int out_mode) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int n = blockIdx.y, tile = blockIdx.x * 4 + wave;
+  if (tile >= ntiles) return;
+  const int t = tile * 32 + lr;
+  const bool live = t < T;
+  const int Lout = (T - 1) * 16 + 32;
+  const float* f = feats + (size_t)n * C * ldt + (live ? t : 0);
+  const float* m = mask ? mask + (size_t)n * C * ldt + (live ? t : 0) : nullptr;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int c0 = 0; c0 < C; c0 += 2 * DM_UC) {
+    float e[DM_UC], mv[DM_UC], wv[DM_UC];
+#pragma unroll
+    for (int u = 0; u < DM_UC; ++u) {
+      const int c = c0 + 2 * u + lh;
+      const bool in = c < C;
+      e[u] = (in && live) ? f[(size_t)c * ldt] : 0.f;
+      mv[u] = (m && in && live) ? m[(size_t)c * ldt] : 1.f;
+      wv[u] = in ? w[(size_t)c * 32 + lr] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < DM_UC; ++u) {
+      const float ev = m ? e[u] * mask_act(mv[u], mask_mode) : e[u];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u], ev, acc, 0, 0, 0);
+    }
+  }
+  // lane (frame lr, half lh) holds output samples j = (r & 3) + 8 (r >> 2) + 4 lh of its frame: r < 8 the head (j < 16),
+  // r >= 8 the tail (j - 16 in the same pattern)
+  float o[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float left = __shfl_up(acc[r + 8], 1, 32);  // the left neighbour's tail sample
+    o[r] = lr > 0 ? acc[r] + left : acc[r];
+  }
+  const bool final_here = lr > 0 || tile == 0;  // a tile's first frame still misses the previous tile's tail
+  if (final_here) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = out_constrain(o[r], out_mode);
+  }
+  if (t <= T) {  // frame T (all zero) carries the tail of frame T - 1: samples [16 T, 16 T + 16) = the end of the output
+    float* dst = out + (size_t)n * Lout + 16 * (size_t)t + 4 * lh;
+    *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(dst + 8) = f32x4{o[4], o[5], o[6], o[7]};
+  }
+  if (lr == 31) {
+    float* dst = tails + ((size_t)n * ntiles + tile) * 16 + 4 * lh;
+    *reinterpret_cast<f32x4*>(dst) = f32x4{acc[8], acc[9], acc[10], acc[11]};
+    *reinterpret_cast<f32x4*>(dst + 8) = f32x4{acc[12], acc[13], acc[14], acc[15]};
+  }
+}
+
+__global__ __launch_bounds__(256) void free_decode_fixup_kernel(float* __restrict__ out, const float* __restrict__ tails,
+                                                                int T, int ntiles, int N, int out_mode) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (n, tile >= 1, j < 16)
+  const int j = idx & 15, rest = idx >> 4;
+  const int tile = rest % (ntiles - 1) + 1, n = rest / (ntiles - 1);
+  if (n >= N) return;
+  const int Lout = (T - 1) * 16 + 32;
+  const size_t sidx = (size_t)16 * 32 * tile + j;
+  if ((int)sidx >= Lout) return;
+  float* o = out + (size_t)n * Lout + sidx;
+  *o = out_constrain(*o + tails[((size_t)n * ntiles + tile - 1) * 16 + j], out_mode);
+}
+
 // Run-time (win, hop) fallback: one thread per output sample.
 __global__ __launch_bounds__(256) void free_decode_generic_kernel(const float* __restrict__ feats,
                                                                   const float* __restrict__ mask, int mask_mode,
@@ -359,6 +526,13 @@ extern "C" int ps_free_encode_f32(const float* wav, const float* w, float* feats
   dim3 grid((T + 255) / 256, (C + cchunk - 1) / cchunk, N);
   hipStream_t s = (hipStream_t)stream;
   LaunchTimer timer("free_encode", s);
+  // long rows of the benchmark's filterbank: the matrix-pipe kernel (ps_debug_flags bit 0 keeps the VALU kernels of
+  // rounds 1-2: tests run both)
+  if (win == 32 && hop == 16 && C % 32 == 0 && T >= 64 && !(g_debug_flags & 1)) {
+    dim3 g((T + 32 * EM_TILES - 1) / (32 * EM_TILES), (C + 127) / 128, N);
+    hipLaunchKernelGGL(free_encode_mfma_kernel, g, dim3(256), 0, s, wav, w, feats, L, C, T, ldt, relu);
+    return check_launch("ps_free_encode_f32");
+  }
   if (win == 32)
     hipLaunchKernelGGL(free_encode_kernel<32>, grid, dim3(256), 0, s, wav, w, feats, L, C, win, hop, T, ldt, relu,
                        cchunk);
@@ -400,6 +574,39 @@ extern "C" int ps_free_decode_f32(const float* feats, const float* mask, int mas
                        mask_act, w, out, C, T, ldt, win, hop, out_mode);
   }
   return check_launch("ps_free_decode_f32");
+}
+
+extern "C" size_t ps_free_decode_workspace_bytes(int N, int T, int win, int hop) {
+  if (N <= 0 || T <= 0 || win != 32 || hop != 16) return 0;
+  return (size_t)N * (T / 32 + 1) * 16 * sizeof(float);  // one 16-sample tail per 32-frame tile
+}
+
+extern "C" int ps_free_decode_ws_f32(const float* feats, const float* mask, int mask_act, const float* w, float* out,
+                                     int N, int C, int T, int ldt, int win, int hop, int out_mode, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  const size_t need = ps_free_decode_workspace_bytes(N, T, win, hop);
+  // the matrix-pipe kernel: the benchmark's filterbank on long rows, with the side buffer it needs (ps_debug_flags
+  // bit 0 keeps the VALU kernel; so does a missing or short workspace)
+  if (need == 0 || !workspace || workspace_bytes < need || T < 64 || N > 65535 || ((uintptr_t)out & 15) ||
+      ((uintptr_t)workspace & 15) || (g_debug_flags & 1))
+    return ps_free_decode_f32(feats, mask, mask_act, w, out, N, C, T, ldt, win, hop, out_mode, stream);
+  if (!feats || !w || !out || C <= 0 || ldt < T) {
+    set_error("ps_free_decode_ws_f32: bad argument (N=%d C=%d T=%d)", N, C, T);
+    return PS_E_INVALID;
+  }
+  if (mask_act < PS_ACT_LINEAR || mask_act > PS_ACT_SIGMOID || out_mode < PS_OUT_CLAMP || out_mode > PS_OUT_NONE) {
+    set_error("ps_free_decode_ws_f32: unknown mask_act=%d or out_mode=%d", mask_act, out_mode);
+    return PS_E_INVALID;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  LaunchTimer timer("free_decode", s);
+  const int ntiles = T / 32 + 1;
+  hipLaunchKernelGGL(free_decode_mfma_kernel, dim3((ntiles + 3) / 4, N), dim3(256), 0, s, feats, mask, mask_act, w, out,
+                     (float*)workspace, C, T, ldt, ntiles, out_mode);
+  const long long fix = (long long)N * (ntiles - 1) * 16;
+  hipLaunchKernelGGL(free_decode_fixup_kernel, dim3((unsigned)((fix + 255) / 256)), dim3(256), 0, s, out,
+                     (const float*)workspace, T, ntiles, N, out_mode);
+  return check_launch("ps_free_decode_ws_f32");
 }
 
 extern "C" int ps_overlap_average_f32(const float* tail, int ld_tail, const float* cur, float* out, int B, int win,

@@ -82,8 +82,12 @@ def free_decode(feats: torch.Tensor, t: int, w: torch.Tensor, hop: int, mask: Op
         out = torch.empty(n, (t - 1) * hop + win, dtype=torch.float32, device=feats.device)
     elif tuple(out.shape) != (n, (t - 1) * hop + win) or not out.is_contiguous():
         raise RuntimeError("free_decode: `out` must be a contiguous [N, (T-1)*hop+win] tensor")
-    check(lib().ps_free_decode_f32(ptr(feats), ptr(mask), _abi.PS_ACT[mask_act], ptr(w), ptr(out), n, c, t, ldt,
-                                   win, hop, _abi.PS_OUT[out_mode], stream_ptr(feats.device)), "ps_free_decode_f32")
+    # the matrix-pipe decoder (win = 32, hop = 16, long rows) completes tile boundaries through a small side buffer
+    ws_bytes = lib().ps_free_decode_workspace_bytes(n, t, win, hop)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=feats.device) if ws_bytes else None
+    check(lib().ps_free_decode_ws_f32(ptr(feats), ptr(mask), _abi.PS_ACT[mask_act], ptr(w), ptr(out), n, c, t, ldt,
+                                      win, hop, _abi.PS_OUT[out_mode], ptr(ws), ws_bytes, stream_ptr(feats.device)),
+          "ps_free_decode_ws_f32")
     return out
 
 

@@ -64,14 +64,24 @@ def _rand(shape, seed, lo=-1.0, hi=1.0):
     (2, 1000, 40, 32, 16, False), (3, 4111, 70, 32, 16, True), (2, 600, 24, 16, 8, False),
     (2, 211, 9, 20, 6, True), (1, 32, 5, 32, 16, False), (1, 64000, 512, 32, 16, False),
     # enough frames for the four-frames-per-thread kernel: T = 4001 (a one-frame tail group), T = 4098 (two), odd C
-    (5, 64032, 70, 32, 16, True), (4, 65584, 33, 32, 16, False), (5, 64036, 64, 32, 16, True)])
+    (5, 64032, 70, 32, 16, True), (4, 65584, 33, 32, 16, False), (5, 64036, 64, 32, 16, True),
+    # tile edges of the matrix-pipe kernel (C % 32 == 0): T = 64, 96, 97, 127, 128 and a ragged last workgroup
+    (2, 1040, 32, 32, 16, False), (2, 1552, 64, 32, 16, True), (1, 1568, 128, 32, 16, False), (3, 2048, 96, 32, 16, True),
+    (2, 2064, 512, 32, 16, False), (2, 9000, 128, 32, 16, True)])
 def test_free_encode(H, dev, n, length, c, win, hop, relu):
     wav = _rand((n, length), 1, -0.5, 0.5)
     w = _rand((c, 1, win), 2, -0.2, 0.2)
     ref = O.free_encode(wav, w, hop, relu)
-    feats, t = H.free_encode(wav.to(dev), w.to(dev), hop, relu)
-    assert t == ref.shape[-1] == (length - win) // hop + 1
-    assert rel_max(feats[..., :t].cpu().numpy(), ref.numpy()) < 1e-5
+    from puresound_amd import _abi
+    for flags in (0, 1):  # 0: the matrix-pipe kernel where the shape allows it (32 / 16, C % 32 == 0, T >= 64); bit 0: VALU kernel
+        old = _abi.lib().ps_debug_flags(flags)
+        try:
+            feats, t = H.free_encode(wav.to(dev), w.to(dev), hop, relu)
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
+        assert t == ref.shape[-1] == (length - win) // hop + 1
+        assert rel_max(feats[..., :t].cpu().numpy(), ref.numpy()) < 1e-5, flags
 
 
 @pytest.mark.parametrize("n,c,t,win,hop,mask_act,out_mode", [
@@ -79,6 +89,9 @@ def test_free_encode(H, dev, n, length, c, win, hop, relu):
     (3, 24, 300, 16, 8, "sigmoid", "sigmoid"), (2, 9, 33, 20, 6, "relu", "linear"),
     (1, 8, 1, 32, 16, "linear", "none"), (1, 16, 255, 32, 16, "linear", "none"),
     (1, 16, 256, 32, 16, "linear", "none"), (1, 512, 3999, 32, 16, "relu", "linear"),
+    # tile edges of the matrix-pipe kernel: T a multiple of 32, one more, one less, an odd channel count
+    (2, 64, 64, 32, 16, "relu", "linear"), (2, 33, 96, 32, 16, "linear", "none"), (3, 128, 97, 32, 16, "relu", "linear"),
+    (1, 48, 127, 32, 16, "sigmoid", "sigmoid"), (2, 128, 4000, 32, 16, "relu", "linear"),
     # channel-split workgroups (C >= 64): channel counts that do not divide by four, the 16 / 8 filterbank
     (2, 66, 513, 32, 16, "relu", "linear"), (2, 127, 300, 16, 8, "sigmoid", "none")])
 def test_free_decode(H, dev, n, c, t, win, hop, mask_act, out_mode):
@@ -89,12 +102,19 @@ def test_free_decode(H, dev, n, c, t, win, hop, mask_act, out_mode):
     ref = O.free_decode(enh, w, hop)
     if out_mode != "none":
         ref = O.output_constrain(ref, out_mode)
-    out = H.free_decode(H.pad_rows(feats.to(dev)), t, w.to(dev), hop, H.pad_rows(mask.to(dev)), mask_act, out_mode)
-    assert out.shape == ref.shape
-    assert rel_max(out.cpu().numpy(), ref.numpy()) < 2e-5
-    # no-mask variant == module-level FreeEncDec.inverse
-    out2 = H.free_decode(H.pad_rows(feats.to(dev)), t, w.to(dev), hop)
-    assert rel_max(out2.cpu().numpy(), O.free_decode(feats, w, hop).numpy()) < 2e-5
+    from puresound_amd import _abi
+    for flags in (0, 1):  # 0: the matrix-pipe kernel + boundary fix-up where the shape allows it (32 / 16, T >= 64); bit 0: VALU
+        old = _abi.lib().ps_debug_flags(flags)
+        try:
+            out = H.free_decode(H.pad_rows(feats.to(dev)), t, w.to(dev), hop, H.pad_rows(mask.to(dev)), mask_act, out_mode)
+            # no-mask variant == module-level FreeEncDec.inverse
+            out2 = H.free_decode(H.pad_rows(feats.to(dev)), t, w.to(dev), hop)
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
+        assert out.shape == ref.shape
+        assert rel_max(out.cpu().numpy(), ref.numpy()) < 2e-5, flags
+        assert rel_max(out2.cpu().numpy(), O.free_decode(feats, w, hop).numpy()) < 2e-5, flags
 
 
 @pytest.mark.parametrize("n,k,m,t", [(2, 16, 8, 50), (1, 512, 256, 300), (2, 256, 512, 129), (2, 20, 300, 128),
