@@ -122,6 +122,31 @@ __global__ __launch_bounds__(256) void conv1x1_small_fused_kernel(FusedArgs fa) 
   f32x4 acc[NCB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // The kernel is one chain of memory round trips on a nearly idle chip (the streaming step: 64 frames): what the
+  // epilogue needs -- bias, per-frame term, the FiLM multiplicands / the cell state of this thread's (frame, four rows) --
+  // is requested HERE, next to the GEMM operands, instead of behind the reduction (round 3: one round trip less per launch)
+  constexpr int NE = (NCB * 64 + 255) / 256;  // epilogue elements per thread
+  float e_bias[NE][4], e_res[NE][4], e_x[NE][2];
+#pragma unroll
+  for (int q = 0; q < NE; ++q) {
+    const int idx = threadIdx.x + 256 * q, cb = idx >> 6, ln = idx & 63;
+    const int t = t0 + cb * 16 + (ln & 15), mq = m0 + 4 * (ln >> 4);
+    const bool on = idx < NCB * 64 && t < a.T && mq < a.M;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      e_bias[q][reg] = (on && a.bias) ? a.bias[mq + reg] : 0.f;
+      e_res[q][reg] = (on && a.res) ? a.res[((size_t)n * a.M + mq + reg) * a.ldt + t] : 0.f;
+    }
+    if constexpr (EPI == 1) {
+      const int c0 = mq >> 1;
+      e_x[q][0] = on ? a.x[((size_t)n * a.K + c0) * a.ldt + t] : 0.f;
+      e_x[q][1] = on ? a.x[((size_t)n * a.K + c0 + 1) * a.ldt + t] : 0.f;
+    } else {
+      const int u = mq >> 2, H = a.M >> 2;
+      e_x[q][0] = on ? fa.c_state[((size_t)n * H + u) * fa.ld_state + t] : 0.f;
+      e_x[q][1] = 0.f;
+    }
+  }
   const int nk4 = a.Kp / 4;
   // explicit batches: all loads of UN k-steps are issued before their MFMAs (the loop is latency bound)
   constexpr int UN = 8;
@@ -144,7 +169,10 @@ __global__ __launch_bounds__(256) void conv1x1_small_fused_kernel(FusedArgs fa) 
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) part[w][cb][lane] = acc[cb];
   __syncthreads();
-  for (int idx = threadIdx.x; idx < NCB * 64; idx += 256) {
+#pragma unroll
+  for (int q = 0; q < NE; ++q) {
+    const int idx = threadIdx.x + 256 * q;
+    if (idx >= NCB * 64) continue;
     const int cb = idx >> 6, ln = idx & 63;
     f32x4 s = (part[0][cb][ln] + part[1][cb][ln]) + (part[2][cb][ln] + part[3][cb][ln]);
     const int t = t0 + cb * 16 + (ln & 15);
@@ -152,18 +180,17 @@ __global__ __launch_bounds__(256) void conv1x1_small_fused_kernel(FusedArgs fa) 
     if (t >= a.T || mq >= a.M) continue;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      if (a.bias) s[reg] += a.bias[mq + reg];
-      if (a.res) s[reg] += a.res[((size_t)n * a.M + mq + reg) * a.ldt + t];
+      if (a.bias) s[reg] += e_bias[q][reg];
+      if (a.res) s[reg] += e_res[q][reg];
     }
     if constexpr (EPI == 1) {
       const int c0 = mq >> 1, C = a.M >> 1;
-      const float x0 = a.x[((size_t)n * a.K + c0) * a.ldt + t], x1 = a.x[((size_t)n * a.K + c0 + 1) * a.ldt + t];
-      a.y[((size_t)n * C + c0) * a.ldt + t] = s[0] * x0 + s[1];
-      a.y[((size_t)n * C + c0 + 1) * a.ldt + t] = s[2] * x1 + s[3];
+      a.y[((size_t)n * C + c0) * a.ldt + t] = s[0] * e_x[q][0] + s[1];
+      a.y[((size_t)n * C + c0 + 1) * a.ldt + t] = s[2] * e_x[q][1] + s[3];
     } else {
       const int u = mq >> 2, H = a.M >> 2;
       const size_t so = ((size_t)n * H + u) * fa.ld_state + t;
-      const float cn = sigm(s[1]) * fa.c_state[so] + sigm(s[0]) * tanhf(s[2]);
+      const float cn = sigm(s[1]) * e_x[q][0] + sigm(s[0]) * tanhf(s[2]);
       fa.c_state[so] = cn;
       fa.h_out[so] = sigm(s[3]) * tanhf(cn);
     }

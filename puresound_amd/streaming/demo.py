@@ -158,17 +158,66 @@ class DemoTseNet(nn.Module):
             self._cores = torch.empty(hops, m.input_size, feats.shape[-1], dtype=torch.float32, device=feats.device)
         # block 0's input norm and the output layer do not touch the recurrent state either: one launch each
         x_ln = m.input_norm_all(feats) if m.block0_takes_input_norm() else None
-        for i in range(hops):
-            m._x_in = feats[i:i + 1]
-            m._frame_body(x_ln=None if x_ln is None else x_ln[i:i + 1], core_out=self._cores[i:i + 1])
-            if i in updates:
-                m.update_mem_lstm()
-                m.reset_seg_lstm_status()
+        if x_ln is not None and self._wavefront and m.wavefront_ready():
+            # the masker steps as a wavefront: cell (hop h, block i) needs (h, i-1) and (h-1, i) only, so the cells of an
+            # anti-diagonal run side by side on parallel branches of the graph: hops + n_blocks - 1 dependent steps of
+            # three kernels instead of hops * n_blocks (a Mem-LSTM update drains the pipeline: it touches every block)
+            start = 0
+            for u in list(updates) + [hops - 1]:
+                self._wavefront_run(feats, x_ln, start, u + 1)
+                if u in updates:
+                    m.update_mem_lstm()
+                    m.reset_seg_lstm_status()
+                start = u + 1
+                if start >= hops:
+                    break
+        else:
+            for i in range(hops):
+                m._x_in = feats[i:i + 1]
+                m._frame_body(x_ln=None if x_ln is None else x_ln[i:i + 1], core_out=self._cores[i:i + 1])
+                if i in updates:
+                    m.update_mem_lstm()
+                    m.reset_seg_lstm_status()
         m._output(self._cores, b, out=self._masks)
         frames = hip.free_decode(feats, b, self.encoder.decoder.weight.detach(), self.win_size, self._masks, "linear",
                                  "none")                                                  # [hops, B * win]
         # averaging overlap-add of all hops, the new tail and the new window queue: one launch
         hip.stream_overlap(frames, self._wins, self._tail, self._blocks, self.queue, h)
+
+    _wavefront = True  # chunk body: (hop, block) cells as a wavefront over parallel graph branches (False: hop after hop)
+
+    def _wavefront_run(self, feats: torch.Tensor, x_ln: torch.Tensor, h0: int, h1: int) -> None:
+        """Hops [h0, h1) of the chunk through all blocks as a wavefront: the cells (hop d - i, block i) of anti-diagonal d run
+        side by side, block i on its own stream (the blocks' outputs are double buffered by hop parity)."""
+        m = self.masker
+        nb = m.n_blocks
+        dev = feats.device
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_wf_streams", None) is None or len(self._wf_streams) != nb:
+            self._wf_streams = [torch.cuda.Stream(dev) for _ in range(nb)]
+            self._wf_y = None
+        if self._wf_y is None or self._wf_y[0][0][0].shape != feats[0:1].shape:
+            mk = lambda: torch.empty_like(feats[0:1])  # noqa: E731
+            self._wf_y = [[(mk(), mk()) for _ in range(2)] for _ in range(nb - 1)]   # [block][hop parity] -> (y, y2)
+        # fork / join per anti-diagonal: the cells of step d go out on their blocks' streams and meet on the launch stream
+        # again, so every dependency ((h, i-1) and (h-1, i) before (h, i); the reader of a buffer before its next writer)
+        # is covered by the join of the step before.  (Cross edges between the side streams themselves -- an event wait
+        # per dependency instead of a join per step -- made hipStreamEndCapture crash in ROCm 7.0's runtime.)
+        for d in range(h0, h1 + nb - 1):
+            cells = [(d - i, i) for i in range(nb) if h0 <= d - i < h1]
+            if len(cells) == 1:     # the ramps of the wavefront: nothing to run beside it
+                h, i = cells[0]
+                cur = (feats[h:h + 1], x_ln[h:h + 1]) if i == 0 else self._wf_y[i - 1][h & 1]
+                m._cell(i, cur[0], cur[1], self._cores[h:h + 1], None if i == nb - 1 else self._wf_y[i][h & 1])
+                continue
+            for h, i in cells:
+                s = self._wf_streams[i]
+                s.wait_stream(main)
+                with torch.cuda.stream(s):
+                    cur = (feats[h:h + 1], x_ln[h:h + 1]) if i == 0 else self._wf_y[i - 1][h & 1]
+                    m._cell(i, cur[0], cur[1], self._cores[h:h + 1], None if i == nb - 1 else self._wf_y[i][h & 1])
+            for h, i in cells:
+                main.wait_stream(self._wf_streams[i])
 
     _CHUNK_GRAPH_CAP = 24  # captured (hops, update pattern) variants kept; the oldest goes first
 

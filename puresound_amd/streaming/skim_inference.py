@@ -203,6 +203,35 @@ class StreamingSkiM(SkiM):
         ln = f._plan_get(frames.device, f._build)["norm"]
         return hip.chan_layernorm(frames, self.streams, ln["gamma"], ln["beta"], ln["eps"])
 
+    def wavefront_ready(self) -> bool:
+        """Every block is the fused causal FiLM form (film kernel, gates + cell, projection + LayerNorm + the next block's
+        input norm): then block i of hop h depends only on block i-1 of hop h and block i of hop h-1, and the demo harness
+        runs the (hop, block) cells of a chunk as a wavefront on parallel graph branches."""
+        if not self.causal or self._embed_static is None or self.input_size % 2:
+            return False
+        return all(self.block_with_embed[i] and isinstance(self.seg_input_fusion[i], FiLM)
+                   and self.seg_input_fusion[i].inp_norm for i in range(self.n_blocks))
+
+    def _cell(self, i: int, cur: torch.Tensor, cur_ln: torch.Tensor, core_out, y_bufs):
+        """Block i of one hop on its own (wavefront_ready() form): cur / cur_ln = the block's input and its input norm;
+        the output goes to core_out (last block) or y_bufs = (y, y2) static buffers.  Same three kernels as _frame_body."""
+        b = self.streams
+        c_in, hid = self.input_size, self.hidden_size
+        rnn, proj, norm = self.seg_lstm[i].step_plan(cur_ln.device)
+        xh = self._xh[i]
+        x_rows, h_rows = xh[:, :c_in, :], xh[:, c_in:, :]
+        self.seg_input_fusion[i].step_normed(cur_ln, b, x_rows)
+        h_new = self._h_new[i]
+        hip.lstm_gates_cell(xh, b, rnn["w_units"], rnn["bias_units"], self._seg_c[i], h_new, hid)
+        norm2 = None
+        if i + 1 < self.n_blocks:
+            nxt = self.seg_input_fusion[i + 1]
+            ln = nxt._plan_get(cur_ln.device, nxt._build)["norm"]
+            norm2 = (ln["gamma"], ln["beta"], ln["eps"])
+        last = core_out if i == self.n_blocks - 1 else y_bufs[0]
+        hip.proj_layernorm(h_new, b, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"], norm["eps"], x_rows,
+                           norm2, x_copy=h_rows, out=last, out2=None if norm2 is None else y_bufs[1])
+
     def _frame_body(self, out: Optional[torch.Tensor] = None, x_ln: Optional[torch.Tensor] = None,
                     core_out: Optional[torch.Tensor] = None):
         """One frame of every stream through all blocks; reads _x_in / _embed_static, updates the seg states in
