@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 8
+#define PS_ABI_VERSION 9
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -360,6 +360,14 @@ int ps_lstm_gates_cell_f32(const float* xh, const float* wt_units, const float* 
 int ps_proj_layernorm_f32(const float* x, const float* wt, const float* bias, const float* gamma, const float* beta,
                           float eps, const float* res, float* y, const float* gamma2, const float* beta2, float eps2,
                           float* y2, float* x_copy, int res_inside, int N, int K, int M, int T, int ldt, void* stream);
+/* The same on long rows with the partial maxima of |y| as a by-product: y_amax [N][ps_proj_layernorm_amax_parts(T)] is what
+ * a following ps_conv1x1_f16x2_f32 takes as x_amax (the LSTM input projections of DPRNN / SkiM in the fp16x2 arithmetic).
+ * Only the row kernel produces them (T >= 128, y2 == x_copy == NULL); otherwise PS_E_UNSUPPORTED. */
+int ps_proj_layernorm_amax_parts(int T);
+int ps_proj_layernorm_amax_f32(const float* x, const float* wt, const float* bias, const float* gamma, const float* beta,
+                               float eps, const float* res, float* y, const float* gamma2, const float* beta2, float eps2,
+                               float* y2, float* x_copy, int res_inside, int N, int K, int M, int T, int ldt, float* y_amax,
+                               void* stream);
 
 /* Streaming harness overlap-add (egs/tse/demo/utils.py:121-128): out[b][j] = (tail[b][j] + cur[b][j]) / 2 for
  * j < overlap (tail = the last `overlap` samples of the running output, row stride ld_tail), cur[b][j] otherwise. */

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PURESOUND_HIP_LIB: an experimental build of the same library (tools/build_variant.sh); kernel experiments only
 LIB_PATH = os.environ.get("PURESOUND_HIP_LIB") or os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -99,6 +99,9 @@ SIGNATURES = {
     "ps_lstm_gates_cell_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_proj_layernorm_f32": (C.c_int, [_vp] * 5 + [C.c_float, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp] + [C.c_int] * 6
                               + [_vp]),
+    "ps_proj_layernorm_amax_parts": (C.c_int, [C.c_int]),
+    "ps_proj_layernorm_amax_f32": (C.c_int, [_vp] * 5 + [C.c_float, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp] + [C.c_int] * 6
+                                   + [_vp, _vp]),
     "ps_self_attention_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 9 + [_vp]),
     "ps_add_position_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 7 + [_vp]),
     "ps_overlap_average_f32": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),

@@ -217,6 +217,7 @@ struct ProjLnArgs {
   float eps, eps2;
   int K, Kp, M, T, ldt;
   int N;  // (the persistent row kernel walks utterances itself)
+  float* y_amax;  // row kernel only: [N][4 * ceil(T / 128)] partial maxima of |y| (the next fp16x2 GEMM's input range)
 };
 
 constexpr int PLN_MAXM = 256;
@@ -368,7 +369,10 @@ __global__ __launch_bounds__(256) void proj_layernorm_rows_kernel(ProjLnArgs a) 
   const int tb = (a.T + 127) / 128;  // 128-frame blocks per utterance
   for (int tile = blockIdx.x; tile < tb * a.N; tile += gridDim.x) {
   const int n = tile / tb, t0 = (tile % tb) * 128 + wave * 32;
-  if (t0 >= a.T) continue;
+  if (t0 >= a.T) {
+    if (a.y_amax && lane == 0) a.y_amax[(size_t)n * tb * 4 + (tile % tb) * 4 + wave] = 0.f;
+    continue;
+  }
   const int t = t0 + lr;
   const bool live = t < a.T;
   f32x16 acc[NB];
@@ -437,6 +441,7 @@ __global__ __launch_bounds__(256) void proj_layernorm_rows_kernel(ProjLnArgs a) 
     }
   q += __shfl_xor(q, 32, 64);
   const float rstd = 1.f / sqrtf(q / (float)a.M + a.eps);
+  float amx = 0.f;
 #pragma unroll
   for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -451,9 +456,14 @@ __global__ __launch_bounds__(256) void proj_layernorm_rows_kernel(ProjLnArgs a) 
           const size_t off = row0 + (size_t)c * a.ldt;
           if (!a.res_inside) v += rv[j][rq * 4 + r3];
           a.y[off] = v;
+          amx = fmaxf(amx, fabsf(v));
         }
       }
     }
+  if (a.y_amax) {
+    amx = wave_max(amx);
+    if (lane == 0) a.y_amax[(size_t)n * tb * 4 + (tile % tb) * 4 + wave] = amx;
+  }
   }  // tiles
 }
 
@@ -572,10 +582,20 @@ extern "C" int ps_lstm_gates_cell_f32(const float* xh, const float* wt_units, co
   return small_status("ps_lstm_gates_cell_f32");
 }
 
+extern "C" int ps_proj_layernorm_amax_parts(int T) { return T > 0 ? 4 * ((T + 127) / 128) : 0; }
+
 extern "C" int ps_proj_layernorm_f32(const float* x, const float* wt, const float* bias, const float* gamma,
                                      const float* beta, float eps, const float* res, float* y, const float* gamma2,
                                      const float* beta2, float eps2, float* y2, float* x_copy, int res_inside, int N,
                                      int K, int M, int T, int ldt, void* stream) {
+  return ps_proj_layernorm_amax_f32(x, wt, bias, gamma, beta, eps, res, y, gamma2, beta2, eps2, y2, x_copy, res_inside, N, K,
+                                    M, T, ldt, nullptr, stream);
+}
+
+extern "C" int ps_proj_layernorm_amax_f32(const float* x, const float* wt, const float* bias, const float* gamma,
+                                          const float* beta, float eps, const float* res, float* y, const float* gamma2,
+                                          const float* beta2, float eps2, float* y2, float* x_copy, int res_inside, int N,
+                                          int K, int M, int T, int ldt, float* y_amax, void* stream) {
   if (!x || !wt || !gamma || !beta || !y || N <= 0 || K <= 0 || M <= 0 || T <= 0 || ldt < T || N > 65535 ||
       (y2 && (!gamma2 || !beta2))) {
     set_error("ps_proj_layernorm_f32: bad argument (N=%d K=%d M=%d T=%d)", N, K, M, T);
@@ -585,7 +605,7 @@ extern "C" int ps_proj_layernorm_f32(const float* x, const float* wt, const floa
     set_error("ps_proj_layernorm_f32: M=%d > %d output channels", M, PLN_MAXM);
     return PS_E_UNSUPPORTED;
   }
-  ProjLnArgs a{x, wt, bias, gamma, beta, res, y, gamma2, beta2, y2, x_copy, res_inside, eps, eps2, K, (K + 15) / 16 * 16, M, T, ldt, N};
+  ProjLnArgs a{x, wt, bias, gamma, beta, res, y, gamma2, beta2, y2, x_copy, res_inside, eps, eps2, K, (K + 15) / 16 * 16, M, T, ldt, N, y_amax};
   // long rows without the streaming step's extras: the row kernel (ps_debug_flags bit 4 keeps the 16-frame kernel: tests
   // compare the two on the same data)
   const int kp = (K + 15) / 16 * 16;
@@ -603,6 +623,11 @@ extern "C" int ps_proj_layernorm_f32(const float* x, const float* wt, const floa
     else
       hipLaunchKernelGGL((proj_layernorm_rows_kernel<8>), grid, dim3(256), lds, (hipStream_t)stream, a);
     return small_status("ps_proj_layernorm_f32");
+  }
+  if (y_amax) {
+    set_error("ps_proj_layernorm_amax_f32: the maxima are an output of the row kernel only (T >= 128, no second norm / copy, "
+              "K * M within its LDS budget); got N=%d K=%d M=%d T=%d", N, K, M, T);
+    return PS_E_UNSUPPORTED;
   }
   {
     LaunchTimer timer("proj_layernorm", (hipStream_t)stream);

@@ -456,7 +456,7 @@ def lstm_gates_cell(xh: torch.Tensor, t: int, wt_units: torch.Tensor, bias_units
 def proj_layernorm(x: torch.Tensor, t: int, wt: torch.Tensor, bias: Optional[torch.Tensor], m: int,
                    gamma: torch.Tensor, beta: torch.Tensor, eps: float, res: Optional[torch.Tensor],
                    norm2: Optional[tuple] = None, x_copy: Optional[torch.Tensor] = None, res_inside: bool = False,
-                   out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None):
+                   out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, want_amax: bool = False):
     """y = res + LN(W x + b), or LN(W x + b + res) with res_inside (+ y2 = LN2(y), + copy of x); returns (y, y2);
     y is written into `out` (contiguous [N, m, ldt]) when given."""
     require_device(x, "proj_layernorm")
@@ -466,6 +466,12 @@ def proj_layernorm(x: torch.Tensor, t: int, wt: torch.Tensor, bias: Optional[tor
     y = out if out is not None else torch.empty(n, m, ldt, dtype=torch.float32, device=x.device)
     y2 = (out2 if out2 is not None else torch.empty_like(y)) if norm2 is not None else None
     g2, b2, e2 = norm2 if norm2 is not None else (None, None, 0.0)
+    if want_amax:  # (long rows only: the row kernel; the caller falls back to absmax() when this raises PS_E_UNSUPPORTED)
+        amax = torch.empty(n, lib().ps_proj_layernorm_amax_parts(t), dtype=torch.float32, device=x.device)
+        check(lib().ps_proj_layernorm_amax_f32(ptr(x), ptr(wt), ptr(bias), ptr(gamma), ptr(beta), float(eps), ptr(res), ptr(y),
+                                               ptr(g2), ptr(b2), float(e2), ptr(y2), ptr(x_copy), int(res_inside), n, k, m, t,
+                                               ldt, ptr(amax), stream_ptr(x.device)), "ps_proj_layernorm_amax_f32")
+        return y, y2, amax
     check(lib().ps_proj_layernorm_f32(ptr(x), ptr(wt), ptr(bias), ptr(gamma), ptr(beta), float(eps), ptr(res), ptr(y),
                                       ptr(g2), ptr(b2), float(e2), ptr(y2), ptr(x_copy), int(res_inside), n, k, m, t, ldt,
                                       stream_ptr(x.device)), "ps_proj_layernorm_f32")

@@ -4,6 +4,8 @@ A plan holds the packed / transposed fp32 copies of a module's parameters that t
 fingerprint of the parameters so that load_state_dict / .to(device) / in-place edits invalidate it.  Plans hold
 raw device pointers through the tensors they keep alive; they are never pickled.
 """
+from typing import Optional
+
 import torch
 import torch.nn as nn
 
@@ -20,9 +22,10 @@ FUSE_PROJ_LN_MAX_FRAMES = int(os.environ.get("PS_FUSE_PROJ_LN_MAX_FRAMES", "8192
 # "fp32" = v_mfma_f32 on fp32 operands, "bf16x3" = fp32-accurate 3 x bf16 split, "bf16" = operands rounded to bf16 (what
 # BASELINE.json names for the DPRNN configuration).  A per-module attribute, like TCN.gemm_precision: every PlanCache
 # module carries `gemm_precision` and hands it to the LSTM plans it builds (no process-wide switch).
-# "fp16x2" (the TCN blocks' default) needs a bound on the GEMM's input that these projections do not have: it selects the
-# six-product split here.
-_PLANES = {"fp32": 0, "bf16": 1, "bf16x3": 3, "fp16x2": 3}
+# "fp16x2" (the TCN blocks' default: two fp16 terms, three products) needs the range of the GEMM's input per utterance:
+# lstm_path takes it from the caller (`amax`: the partial maxima the projection + LayerNorm row kernel of the previous
+# recurrence left behind) or measures it (hip.absmax, one pass over the rows: the first GEMM of a masker).
+_PLANES = {"fp32": 0, "bf16": 1, "bf16x3": 3, "fp16x2": 2}
 
 
 def param_signature(module: nn.Module, device) -> tuple:
@@ -40,8 +43,8 @@ class PlanCache:
     gemm_precision = "fp32"  # arithmetic of the LSTM input projections built by this module (see _PLANES)
 
     def set_gemm_precision(self, name: str):
-        """"fp32" | "bf16x3" (= "fp16x2" here) | "bf16" for the LSTM input projections of this module and of every module
-        below it."""
+        """"fp32" | "bf16x3" | "fp16x2" | "bf16" for the LSTM input projections of this module and of every module below
+        it."""
         if name not in _PLANES:
             raise ValueError(f"gemm precision must be one of {sorted(_PLANES)}")
         for m in self.modules():
@@ -105,13 +108,26 @@ def layernorm_plan(ln: nn.Module, device) -> dict:
 
 
 def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int, q_stride: int, steps: int,
-              step_stride: int, h0=None, c0=None, want_state: bool = False, state_shift: int = 0, state_out=None):
-    """x + LN(proj(LSTM(x))) on padded [N,C,ldt] (dprnn.py:154-172, skim.py:215-227) -> (x', final states)."""
+              step_stride: int, h0=None, c0=None, want_state: bool = False, state_shift: int = 0, state_out=None,
+              amax: Optional[list] = None):
+    """x + LN(proj(LSTM(x))) on padded [N,C,ldt] (dprnn.py:154-172, skim.py:215-227) -> (x', final states).
+    `amax`: a one-element list carried from recurrence to recurrence in the fp16x2 arithmetic -- on entry the partial maxima
+    of |x| per utterance (or None: measured here), on return those of x' (None when the kernel that made x' has none)."""
     n, _, ldt = x.shape
     dev = x.device
     planes = rnn["planes"]
     gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev)
-    if planes and rnn["I"] >= 64:
+    x_amax = amax[0] if amax is not None else None
+    if amax is not None:
+        amax[0] = None
+    if planes == 2 and rnn["I"] >= 64:
+        if "wih_f16x2" not in rnn:
+            rnn["wih_f16x2"] = hip.pack_wt_f16x2(rnn["wih_rows"])
+        wf, we = rnn["wih_f16x2"]
+        hip.conv1x1_f16x2(x, t, wf, we, rnn["rows"], None, rnn["bias"], out=gx,
+                          x_amax=x_amax if x_amax is not None else hip.absmax(x, t))
+    elif planes and rnn["I"] >= 64:
+        planes = 3 if planes == 2 else planes
         if planes not in rnn["wih_planes"]:
             rnn["wih_planes"][planes] = hip.pack_wt_bf16(rnn["wih_rows"], planes)
         hip.conv1x1_bf16(x, t, rnn["wih_planes"][planes], rnn["rows"], None, rnn["bias"], out=gx)
@@ -122,6 +138,13 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
     # the fused projection + LayerNorm kernel is the short-row kernel (16-frame workgroups): on long rows (the 2-D
     # maps of DPCRN / DPARN: F * ld frames) the MFMA GEMM plus a LayerNorm pass is faster
     if proj["M"] <= 256 and FUSE_PROJ_LN and t <= FUSE_PROJ_LN_MAX_FRAMES:
+        if amax is not None and rnn["planes"] == 2 and t >= 128:
+            try:   # the row kernel hands the next GEMM its input range for free
+                y, _, amax[0] = hip.proj_layernorm(hseq, t, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"],
+                                                   norm["eps"], x, want_amax=True)
+                return y, state
+            except RuntimeError:
+                amax[0] = None
         y, _ = hip.proj_layernorm(hseq, t, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"], norm["eps"], x)
         return y, state
     p, _ = hip.conv1x1(hseq, t, proj["wt"], proj["M"], None, proj["bias"],

@@ -88,13 +88,15 @@ class DPRNN(PlanCache, nn.Module):
         k = self.seg_size
         s = tp // k
         states = []
+        amax = [None]   # fp16x2 input projections: every recurrence hands the next one the range of its output
         for i, blk in enumerate(p["blocks"]):
             if embed is not None and self.block_with_embed[i]:
                 x = self.input_film[i].forward_padded(x, tp, embed, self.embed_norm)
-            x, _ = lstm_path(x, tp, *blk["intra"], q=s, q_stride=k, steps=k, step_stride=1)
+                amax[0] = None
+            x, _ = lstm_path(x, tp, *blk["intra"], q=s, q_stride=k, steps=k, step_stride=1, amax=amax)
             h0, c0 = init_states[i] if init_states is not None else (None, None)
             x, st = lstm_path(x, tp, *blk["inter"], q=k, q_stride=1, steps=s, step_stride=k, h0=h0, c0=c0,
-                              want_state=want_states)
+                              want_state=want_states, amax=amax)
             states.append(st)
         return x, states
 

@@ -85,6 +85,14 @@ def cfg4(dev, steps=10, warmup=3, batch=32, gemm="fp32", graph=True):
         msg, _ = _timed(lambda: fast(noisy), steps, 3)
         out["hipgraph_ms"] = msg
         out["hipgraph_us_per_serial_step"] = msg * 1e3 / (6 * (20 + 200))
+    if gemm == "fp32":
+        # the same forward with the LSTM input projections in the fp16x2 arithmetic (fp32-class: l2_rel against the run above)
+        ref = model.inference(noisy)
+        model.masker.set_gemm_precision("fp16x2")
+        ms2, y = _timed(lambda: model.inference(noisy), steps, warmup)
+        out["fp16x2_projections"] = {"ms": ms2, "samples_s": batch * L / ms2 * 1e3,
+                                     "l2_rel_vs_fp32": float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref))}
+        model.masker.set_gemm_precision("fp32")
     return out
 
 
