@@ -46,6 +46,7 @@ def cfg3(dev, steps=5, warmup=2, modes=("fp16x2", "bf16"), batch=32):
     BASELINE names for this config (bf16 products and hidden rows, fp32 accumulation); l2_rel is taken against an
     exact-fp32 run of the same batch."""
     model = _build("cfg3_short", dev)
+    model.hip_streams = 1   # (one stream: every launch covers the whole batch, as in bench.py's timed path; two lanes: 14.2 ms)
     noisy, enroll = _waves(batch, 1234, dev), _waves(batch, 1235, dev)
 
     def set_mode(prec):
@@ -67,6 +68,7 @@ def cfg3(dev, steps=5, warmup=2, modes=("fp16x2", "bf16"), batch=32):
 def cfg4_model(dev, gemm="fp32"):
     model = _build("cfg4_short", dev)
     model.masker.set_gemm_precision(gemm)
+    model.hip_streams = int(os.environ.get("PS_CFG4_STREAMS", "1"))
     return model
 
 
