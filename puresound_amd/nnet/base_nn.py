@@ -322,7 +322,7 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         return _align_waveform(enh_wav, ref_wav)
 
     # -- speaker branch (base_nn.py:697-705, 724-738) ---------------------------------------------------
-    def _speaker_embedding_from_feats(self, x: torch.Tensor, t: int) -> torch.Tensor:
+    def _speaker_embedding_from_feats(self, x: torch.Tensor, t: int, x_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
         """speaker_net layer by layer on padded enrolment features (base_nn.py:697-705): Magnitude, TCN (consecutive
         plain blocks go through the fused driver together), GatedTCN, AttentiveStatisticsPooling, then the k=1
         projection conv(s) on the pooled vector -> dvec [N, E]."""
@@ -340,6 +340,7 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
                 i += 1
             elif isinstance(lay, Magnitude):
                 x = lay.forward_padded(x, t)
+                x_amax = None
                 i += 1
             elif isinstance(lay, TCN):
                 run = []
@@ -351,7 +352,16 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
                 plans = [m.plan(x.device) for m in run]
                 if all(p["fused"] for p in plans):
                     blocks = (TcnBlock * len(plans))(*[p["block"] for p in plans])
-                    x = hip.conv_tasnet(blocks, len(plans), x, t, run[0].in_channels, run[0].hid_channels, None, False)
+                    # (x_amax: a bound on the features for fp16x2 blocks -- without one the driver measures them: 93 us)
+                    # the driver's scratch (three hidden maps: 415 MB at 32 x 4 s) is kept, not re-allocated and
+                    # zero-filled per call as hip.conv_tasnet does for callers without one
+                    need = hip.lib().ps_conv_tasnet_workspace_bytes(x.shape[0], run[0].in_channels, run[0].hid_channels, t)
+                    ws = self.__dict__.get("_spk_workspace")
+                    if ws is None or ws.numel() < need or ws.device != x.device:
+                        ws = torch.zeros(need, dtype=torch.uint8, device=x.device)
+                        object.__setattr__(self, "_spk_workspace", ws)
+                    x = hip.conv_tasnet(blocks, len(plans), x, t, run[0].in_channels, run[0].hid_channels, None, False,
+                                        workspace=ws, x_amax=x_amax)
                 else:
                     for m in run:
                         x = m.forward_padded_staged(x, t, None)
@@ -380,7 +390,8 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             x, t = enc.encode_padded(enroll)
         else:
             raise NotImplementedError(f"HIP speaker branch: no kernel path for a {type(enc).__name__} enrolment encoder")
-        return self._speaker_embedding_from_feats(x, t)
+        bound = enc.feature_bound(enroll) if isinstance(enc, FreeEncDec) else None
+        return self._speaker_embedding_from_feats(x, t, bound)
 
     @torch.no_grad()
     def inference_tse_embedding(self, enroll: Optional[torch.Tensor] = None) -> torch.Tensor:
