@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 9
+#define PS_ABI_VERSION 10
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -328,6 +328,11 @@ typedef struct {
   int N, H, D, Q, q_stride, steps, step_stride, ldt, ldq, state_shift;
 } ps_lstm_args;
 int ps_lstm_f32(const ps_lstm_args* args, void* stream);
+/* The same recurrence with the product W_hh h in the fp16x2 arithmetic of ps_conv1x1_f16x2_f32 (two fp16 terms per
+ * operand, three MFMA products, fp32 accumulation on top of the fp32 pre-activations; error <= 2^-21 of sum |W||h| per
+ * gate and step) where a kernel for it exists -- H = 64 and 20 consecutive 16-byte-aligned steps per sequence, the
+ * intra-segment pass of DPRNN(seg_size=20) (dprnn.py:154-160) -- and exactly ps_lstm_f32 for every other shape. */
+int ps_lstm_f16x2_f32(const ps_lstm_args* args, void* stream);
 
 /* 50 % overlapped segmentation of the dual-path maskers (SplitMerge.split / merge, lobe/trivial.py:178-241; SkiM.split /
  * merge, skim.py:334-408) on rows of frames:

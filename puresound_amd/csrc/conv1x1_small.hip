@@ -332,8 +332,10 @@ __global__ __launch_bounds__(64 * NW) void proj_layernorm_kernel(ProjLnArgs a) {
 // consecutive frames, so every global access is two 128-byte pieces, the projection matrix sits in LDS ([k][m], rows
 // padded by 32 floats: the two half-waves read different banks), and a frame's LayerNorm needs the lane's own registers
 // and ONE exchange with lane ^ 32.  Two-pass variance as the reference.
+// Three workgroups per CU for M <= 128 (166 registers; 40 KiB of LDS each): one wave per SIMD left the tile's two load
+// latencies, its 128 MFMAs and its 64 stores strictly in sequence (67 us per launch on config 4's rows, 51 with three).
 template <int NB>
-__global__ __launch_bounds__(256) void proj_layernorm_rows_kernel(ProjLnArgs a) {
+__global__ __launch_bounds__(256, NB == 4 ? 3 : 1) void proj_layernorm_rows_kernel(ProjLnArgs a) {
   constexpr int MB = NB * 32, LDW = MB + 32;
   extern __shared__ __attribute__((aligned(16))) float pl_smem[];
   float* wl = pl_smem;                 // [Kp][LDW]
@@ -380,25 +382,32 @@ __global__ __launch_bounds__(256) void proj_layernorm_rows_kernel(ProjLnArgs a) 
   for (int j = 0; j < NB; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  const float* xp = a.x + (size_t)n * a.K * a.ldt + t;  // (frames beyond T inside the row are padding: computed, not stored)
+  // addressing: every row address is a wave-uniform pointer (utterance, compile-time channel -> scalar registers) plus
+  // ONE per-lane 32-bit offset, so the 64 + 64 + 32 loads / stores of a tile share a single address register (as
+  // 64-bit per-access offsets they took the kernel to 418 registers and one wave per SIMD)
+  const unsigned ldt = (unsigned)a.ldt;
+  const unsigned lo_x = (unsigned)lh * ldt + (unsigned)t;      // activation row k0 + 2u + lh
+  const unsigned lo_y = 4u * (unsigned)lh * ldt + (unsigned)t;  // channel 32 j + (r & 3) + 8 (r >> 2) + 4 lh
+  const float* xn = a.x + (size_t)n * a.K * ldt;  // (frames beyond T inside the row are padding: computed, not stored)
+  const float* rn = a.res ? a.res + (size_t)n * a.M * ldt : nullptr;
+  float* yn = a.y + (size_t)n * a.M * ldt;
   // the residual values of the tile are requested up front, next to the activations: behind the MFMAs they would be 16 NB
   // dependent loads per lane with nothing left to hide them (the first version: 40 us per tile)
-  const size_t row0 = (size_t)n * a.M * a.ldt + t;
   float rv[NB][16];
 #pragma unroll
   for (int j = 0; j < NB; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int c = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      rv[j][r] = (a.res && live && c < a.M) ? a.res[row0 + (size_t)c * a.ldt] : 0.f;
+      const int cu = 32 * j + (r & 3) + 8 * (r >> 2);
+      rv[j][r] = (rn && live && cu + 4 * lh < a.M) ? (rn + (size_t)cu * ldt)[lo_y] : 0.f;
     }
   constexpr int KU = 16;                                // k-pairs whose activation loads are in flight together
   for (int k0 = 0; k0 < a.Kp; k0 += 2 * KU) {
     float bv[KU];
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      const int k = k0 + 2 * u + lh;
-      bv[u] = (k < a.K && t < a.ldt) ? xp[(size_t)k * a.ldt] : 0.f;
+      const int ku = k0 + 2 * u;
+      bv[u] = (ku + lh < a.K && t < a.ldt) ? (xn + (size_t)ku * ldt)[lo_x] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
@@ -453,9 +462,8 @@ __global__ __launch_bounds__(256) void proj_layernorm_rows_kernel(ProjLnArgs a) 
         const int c = c0 + r3;
         if (live && c < a.M) {
           float v = (acc[j][rq * 4 + r3] - mean) * rstd * g4[r3] + be4[r3];
-          const size_t off = row0 + (size_t)c * a.ldt;
           if (!a.res_inside) v += rv[j][rq * 4 + r3];
-          a.y[off] = v;
+          (yn + (size_t)(c0 - 4 * lh + r3) * ldt)[lo_y] = v;
           amx = fmaxf(amx, fabsf(v));
         }
       }
@@ -616,7 +624,7 @@ extern "C" int ps_proj_layernorm_amax_f32(const float* x, const float* wt, const
     const long long tiles = (long long)((T + 127) / 128) * N;
     // one persistent workgroup per CU (the kernel holds a tile's accumulators AND its residual values: 256 registers, one
     // wave per SIMD): the projection matrix is staged once, not once per tile
-    const long long slots = device_cus();
+    const long long slots = (long long)device_cus() * (nb == 4 ? 3 : 1);  // persistent: as many as are resident
     dim3 grid((unsigned)(tiles < slots ? tiles : slots));
     if (nb == 4)
       hipLaunchKernelGGL((proj_layernorm_rows_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream, a);

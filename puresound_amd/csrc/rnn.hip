@@ -320,6 +320,306 @@ __global__ __launch_bounds__(H * 4) void lstm_mfma_kernel(LstmK k) {
   }
 }
 
+// ---- whole-segment MFMA recurrence (intra-segment pass: many short sequences of consecutive frames) ---------------
+// The 16-sequence kernel above fetches the gate pre-activations in 16-byte groups of 4 steps, one group ahead: with
+// q_stride = K frames (K = 20: 80 bytes) each 128-byte line of a gate row holds 1.6 whole sequences and is visited
+// by all five groups, ~6 us apart; 64 resident workgroups per XCD keep 21 MB of such lines in flight against a 4 MB
+// L2, so every visit misses: 645 MB fetched for 131 MB of pre-activations (profiles/r03_pmc_cfg4_traffic.txt) and the
+// pass runs at the fabric's rate, not the recurrence's.  Here a workgroup fetches ALL the steps of its 16 sequences
+// before the first one (the five groups of a line leave back to back and merge in the vector L1 / L2), keeps them
+// in registers -- STEPS x 16 values per lane, the reason for one wave per SIMD (__launch_bounds__(256, 1): 512
+// registers) -- and stages h' in LDS so that it leaves as whole 16-sequence x STEPS-frame rows of 16-byte stores.
+template <int H, int STEPS, bool BIDIR>
+__global__ __launch_bounds__(H * 4, 1) void lstm_seg_kernel(LstmK k) {
+  static_assert(H == 64 && STEPS % 4 == 0, "16 units per wave, 4 waves; steps in 16-byte groups");
+  constexpr int KB = H / 4, NG = STEPS / 4;
+  constexpr int LDH = 16 * STEPS + 4;  // staged h' row: [unit][seq * STEPS + frame], 16-byte aligned rows
+  __shared__ __attribute__((aligned(16))) float hbuf[2][H * 16];
+  __shared__ __attribute__((aligned(16))) float hstage[H * LDH];
+  __shared__ long long seq_off[16];
+  const ps_lstm_args& a = k.a;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = lane & 15, quad = lane >> 4;
+  const int d = blockIdx.z;
+  const int b = blockIdx.x * 16 + col;
+  const bool valid = b < a.N * a.Q;
+  const int n = valid ? b / a.Q : 0, q = valid ? b % a.Q : 0;
+  const int G = 4 * H;
+  const int unit0 = 16 * w + 4 * quad;
+  const bool rev = BIDIR && d == 1;  // (one direction: the loads land in their final registers, no selects)
+  const size_t ldt = a.ldt;
+
+  if (threadIdx.x < 16) seq_off[threadIdx.x] = valid ? (long long)((size_t)(n * a.D + d) * H * ldt + (size_t)q * a.q_stride) : -1;
+
+  // every step's pre-activations: pre[s][g][r], s in processing order (frame STEPS-1-s for the reverse direction)
+  float pre[STEPS][4][4];
+  {
+    const float* gp = a.gx + ((size_t)(n * a.D + d) * G + unit0) * ldt + (size_t)q * a.q_stride;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+          const int jj = rev ? NG - 1 - j : j;
+          const f32x4 v = valid ? *reinterpret_cast<const f32x4*>(gp + (size_t)(g * H + r) * ldt + 4 * jj)
+                                : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pre[4 * j + e][g][r] = rev ? v[3 - e] : v[e];
+        }
+  }
+
+  float wf[4][KB];
+  {
+    const float* wt = a.whh_t + (size_t)d * H * G;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int kk = 16 * (kb >> 2) + 4 * quad + (kb & 3);
+        wf[g][kb] = wt[(size_t)kk * G + g * H + 16 * w + col];
+      }
+  }
+
+  float c[4] = {0.f, 0.f, 0.f, 0.f}, h[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid && (a.h0 || a.c0)) {
+    const int bs = b - a.state_shift;
+    if (bs >= 0) {
+      const int nn = bs / a.Q, qq = bs % a.Q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t off = ((size_t)(nn * a.D + d) * H + unit0 + r) * a.ldq + qq;
+        if (a.h0) h[r] = a.h0[off];
+        if (a.c0) c[r] = a.c0[off];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) hbuf[0][((w * 4 + r) * 4 + quad) * 16 + col] = h[r];
+  __syncthreads();
+
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const float* hb = hbuf[s & 1];
+    float bf[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) bf[kb] = hb[kb * 64 + lane];
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{pre[s][g][0], pre[s][g][1], pre[s][g][2], pre[s][g][3]};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][kb], bf[kb], acc[g], 0, 0, 0);
+    float* hn = hbuf[(s + 1) & 1];
+    const int f = rev ? STEPS - 1 - s : s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gi = fast_sigmoid(acc[0][r]);
+      const float gf = fast_sigmoid(acc[1][r]);
+      const float gg = fast_tanh(acc[2][r]);
+      const float go = fast_sigmoid(acc[3][r]);
+      c[r] = gf * c[r] + gi * gg;
+      h[r] = go * fast_tanh(c[r]);
+      hn[((w * 4 + r) * 4 + quad) * 16 + col] = h[r];
+      hstage[(unit0 + r) * LDH + col * STEPS + f] = h[r];
+    }
+    __syncthreads();
+  }
+
+  // h' rows: 16 sequences x STEPS frames per unit, 16 bytes per store (the last barrier of the loop covers hstage)
+  for (int p = threadIdx.x; p < H * 16 * NG; p += H * 4) {
+    const int unit = p / (16 * NG), rem = p % (16 * NG);
+    const int sq = rem / NG, gr = rem % NG;
+    const long long off = seq_off[sq];
+    if (off >= 0)
+      *reinterpret_cast<f32x4*>(a.hout + off + (size_t)unit * ldt + 4 * gr) =
+          *reinterpret_cast<const f32x4*>(&hstage[unit * LDH + sq * STEPS + 4 * gr]);
+  }
+  if (valid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t off = ((size_t)(n * a.D + d) * H + unit0 + r) * a.ldq + q;
+      if (a.h_last) a.h_last[off] = h[r];
+      if (a.c_last) a.c_last[off] = c[r];
+    }
+  }
+}
+
+// ---- the same with the recurrent product W_hh h in two fp16 terms per operand (ps_lstm_f16x2_f32) -----------------
+// 64 v_mfma_f32_16x16x4_f32 per step (2048 cycles of the matrix pipe, two thirds of the step) become 24
+// v_mfma_f32_16x16x32_f16 (384 cycles): W_hh * 2^e = W_hi + W_lo once per workgroup (e puts the largest |weight| into
+// [2^12, 2^13)), h * 2^10 = h_hi + h_lo every step (|h| < 1), three products hi*hi + hi*lo + lo*hi accumulated in
+// fp32 on top of the (scaled) fp32 pre-activations; the scale comes out again, exactly, before the cell non-linearities.
+// Dropped: the lo*lo term and the fp16 rounding of the two lo parts, together <= 2^-21 of sum_k |W_k| |h_k| per gate -- the
+// class of the fp16x2 GEMM that produced the pre-activations.  C/D layout as the 16x16x4 instruction, so the cell and
+// the staging are the fp32 kernel's; h' crosses LDS as [plane][sequence][k] halves (8-byte writes, 16-byte reads).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int H, int STEPS, bool BIDIR>
+__global__ __launch_bounds__(H * 4, 1) void lstm_seg_f16x2_kernel(LstmK k) {
+  static_assert(H == 64 && STEPS % 4 == 0, "16 units per wave, 4 waves; steps in 16-byte groups");
+  constexpr int NG = STEPS / 4;
+  constexpr int LDH = 16 * STEPS + 4;
+  constexpr int LDK = H + 8;  // halves per (plane, sequence) row: 144 bytes, conflict-free 8-byte writes / 16-byte reads
+  __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][16][LDK];
+  __shared__ __attribute__((aligned(16))) float hstage[H * LDH];
+  __shared__ long long seq_off[16];
+  __shared__ float wmax[4];
+  const ps_lstm_args& a = k.a;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = lane & 15, quad = lane >> 4;
+  const int d = blockIdx.z;
+  const int b = blockIdx.x * 16 + col;
+  const bool valid = b < a.N * a.Q;
+  const int n = valid ? b / a.Q : 0, q = valid ? b % a.Q : 0;
+  const int G = 4 * H;
+  const int unit0 = 16 * w + 4 * quad;
+  const bool rev = BIDIR && d == 1;  // (one direction: the loads land in their final registers, no selects)
+  const size_t ldt = a.ldt;
+
+  if (threadIdx.x < 16) seq_off[threadIdx.x] = valid ? (long long)((size_t)(n * a.D + d) * H * ldt + (size_t)q * a.q_stride) : -1;
+
+  // A fragments: gate g, k-step ks: lane (row = lane & 15 -> unit 16 w + row, k-group = lane >> 4) holds k = 32 ks + 8 kgroup + e
+  f16x8 whi[4][2], wlo[4][2];
+  float inv;
+  {
+    const float* wt = a.whh_t + (size_t)d * H * G;
+    float wv[4][2][8];
+    float m = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          wv[g][ks][e] = wt[(size_t)(32 * ks + 8 * quad + e) * G + g * H + 16 * w + col];
+          m = fmaxf(m, fabsf(wv[g][ks][e]));
+        }
+    m = wave_max(m);
+    if (lane == 0) wmax[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    int ex = 0;
+    if (m > 0.f) frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
+    ex = ex < -27 ? -27 : ex;     // (tiny matrices: keep the scaled pre-activations far from overflow)
+    const float S = ldexpf(1.f, 13 - ex);
+    inv = 1.f / (S * 1024.f);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float ws = wv[g][ks][e] * S;
+          const _Float16 hi = (_Float16)ws;
+          whi[g][ks][e] = hi;
+          wlo[g][ks][e] = (_Float16)(ws - (float)hi);
+        }
+  }
+  asm volatile("" ::: "memory");  // (the 320 pre-activation loads stay behind the 64 fp32 weights they would crowd out)
+
+  float pre[STEPS][4][4];
+  {
+    const float* gp = a.gx + ((size_t)(n * a.D + d) * G + unit0) * ldt + (size_t)q * a.q_stride;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+          const int jj = rev ? NG - 1 - j : j;
+          const f32x4 v = valid ? *reinterpret_cast<const f32x4*>(gp + (size_t)(g * H + r) * ldt + 4 * jj)
+                                : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pre[4 * j + e][g][r] = rev ? v[3 - e] : v[e];
+        }
+  }
+
+  float c[4] = {0.f, 0.f, 0.f, 0.f}, h[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid && (a.h0 || a.c0)) {
+    const int bs = b - a.state_shift;
+    if (bs >= 0) {
+      const int nn = bs / a.Q, qq = bs % a.Q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t off = ((size_t)(nn * a.D + d) * H + unit0 + r) * a.ldq + qq;
+        if (a.h0) h[r] = a.h0[off];
+        if (a.c0) c[r] = a.c0[off];
+      }
+    }
+  }
+  auto put_h = [&](int buf) {  // this lane's 4 units of sequence `col`: two 8-byte writes
+    f16x4 hi4, lo4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float hs = h[r] * 1024.f;
+      const _Float16 hi = (_Float16)hs;
+      hi4[r] = hi;
+      lo4[r] = (_Float16)(hs - (float)hi);
+    }
+    *reinterpret_cast<f16x4*>(&hb[buf][0][col][unit0]) = hi4;
+    *reinterpret_cast<f16x4*>(&hb[buf][1][col][unit0]) = lo4;
+  };
+  put_h(0);
+  __syncthreads();
+
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    f16x8 bh[2][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bh[pl][ks] = *reinterpret_cast<const f16x8*>(&hb[s & 1][pl][col][32 * ks + 8 * quad]);
+    f32x4 acc[4];  // starts at zero: the fp32 pre-activation joins after the scale has come out (one fma per value)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[g][ks], bh[0][ks], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[g][ks], bh[1][ks], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[g][ks], bh[0][ks], acc[g], 0, 0, 0);
+    const int f = rev ? STEPS - 1 - s : s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gi = fast_sigmoid(fmaf(acc[0][r], inv, pre[s][0][r]));
+      const float gf = fast_sigmoid(fmaf(acc[1][r], inv, pre[s][1][r]));
+      const float gg = fast_tanh(fmaf(acc[2][r], inv, pre[s][2][r]));
+      const float go = fast_sigmoid(fmaf(acc[3][r], inv, pre[s][3][r]));
+      c[r] = gf * c[r] + gi * gg;
+      h[r] = go * fast_tanh(c[r]);
+      hstage[(unit0 + r) * LDH + col * STEPS + f] = h[r];
+    }
+    put_h((s + 1) & 1);
+    __syncthreads();
+  }
+
+  for (int p = threadIdx.x; p < H * 16 * NG; p += H * 4) {
+    const int unit = p / (16 * NG), rem = p % (16 * NG);
+    const int sq = rem / NG, gr = rem % NG;
+    const long long off = seq_off[sq];
+    if (off >= 0)
+      *reinterpret_cast<f32x4*>(a.hout + off + (size_t)unit * ldt + 4 * gr) =
+          *reinterpret_cast<const f32x4*>(&hstage[unit * LDH + sq * STEPS + 4 * gr]);
+  }
+  if (valid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t off = ((size_t)(n * a.D + d) * H + unit0 + r) * a.ldq + q;
+      if (a.h_last) a.h_last[off] = h[r];
+      if (a.c_last) a.c_last[off] = c[r];
+    }
+  }
+}
+
 // ---- 4-sequence MFMA recurrence (v_mfma_f32_4x4x1_16B_f32) -------------------------------------------------------
 // For passes with few, long sequences (the inter-segment pass: N*K sequences of S steps) the 16-sequence kernel above
 // leaves most CUs idle and walks the steps at ~2 us each.  Here a workgroup owns only 4 sequences.  The instruction
@@ -562,7 +862,13 @@ static int launch_status(const char* who) {
 
 using namespace ps;
 
-extern "C" int ps_lstm_f32(const ps_lstm_args* args, void* stream) {
+static int lstm_launch(const ps_lstm_args* args, void* stream, bool f16x2);
+
+extern "C" int ps_lstm_f32(const ps_lstm_args* args, void* stream) { return lstm_launch(args, stream, false); }
+
+extern "C" int ps_lstm_f16x2_f32(const ps_lstm_args* args, void* stream) { return lstm_launch(args, stream, true); }
+
+static int lstm_launch(const ps_lstm_args* args, void* stream, bool f16x2) {
   if (!args) {
     set_error("ps_lstm_f32: null args");
     return PS_E_INVALID;
@@ -609,7 +915,17 @@ extern "C" int ps_lstm_f32(const ps_lstm_args* args, void* stream) {
     LaunchTimer timer("lstm", (hipStream_t)stream);
     if (wide) {
       dim3 mgrid((unsigned)((seqs + 15) / 16), 1, a.D);
-      if (a.H == 64 && contig)
+      // whole segments of 20 consecutive frames (DPRNN's intra pass at K = 20): all steps fetched up front
+      const bool seg = a.H == 64 && contig && a.steps == 20 && !(g_debug_flags & 256);
+      if (seg && f16x2 && a.D == 1)
+        hipLaunchKernelGGL((lstm_seg_f16x2_kernel<64, 20, false>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
+      else if (seg && f16x2)
+        hipLaunchKernelGGL((lstm_seg_f16x2_kernel<64, 20, true>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
+      else if (seg && a.D == 1)
+        hipLaunchKernelGGL((lstm_seg_kernel<64, 20, false>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
+      else if (seg)
+        hipLaunchKernelGGL((lstm_seg_kernel<64, 20, true>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
+      else if (a.H == 64 && contig)
         hipLaunchKernelGGL((lstm_mfma_kernel<64, true>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
       else if (a.H == 64)
         hipLaunchKernelGGL((lstm_mfma_kernel<64, false>), mgrid, dim3(256), 0, (hipStream_t)stream, k);

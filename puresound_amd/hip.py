@@ -330,9 +330,10 @@ def attn_weights(logits: torch.Tensor, t: int, lengths: Optional[torch.Tensor] =
 
 def lstm(gx: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int, q: int, q_stride: int, steps: int,
          step_stride: int, h0: Optional[torch.Tensor] = None, c0: Optional[torch.Tensor] = None,
-         want_state: bool = False, state_shift: int = 0, state_out: Optional[tuple] = None):
+         want_state: bool = False, state_shift: int = 0, state_out: Optional[tuple] = None, f16x2: bool = False):
     """LSTM recurrence over gate pre-activations gx padded [N,D*4H,ldt] -> hout [N,D*H,ldt]
-    (+ final (h, c) in state layout [N,D*H,ldq] when want_state / state_out)."""
+    (+ final (h, c) in state layout [N,D*H,ldq] when want_state / state_out).  f16x2: ps_lstm_f16x2_f32 (the
+    recurrent product in two fp16 terms per operand where a kernel for it exists, else the fp32 kernels)."""
     require_device(gx, "lstm")
     n, rows, ldt = gx.shape
     if rows != dirs * 4 * hidden or tuple(whh_t.shape) != (dirs, hidden, 4 * hidden):
@@ -362,7 +363,10 @@ def lstm(gx: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int, q: int, 
     a.h0, a.c0, a.h_last, a.c_last = ptr(h0), ptr(c0), ptr(h_last), ptr(c_last)
     a.N, a.H, a.D, a.Q, a.q_stride, a.steps, a.step_stride = n, hidden, dirs, q, q_stride, steps, step_stride
     a.ldt, a.ldq, a.state_shift = ldt, ldq, state_shift
-    check(lib().ps_lstm_f32(C.byref(a), stream_ptr(gx.device)), "ps_lstm_f32")
+    if f16x2:
+        check(lib().ps_lstm_f16x2_f32(C.byref(a), stream_ptr(gx.device)), "ps_lstm_f16x2_f32")
+    else:
+        check(lib().ps_lstm_f32(C.byref(a), stream_ptr(gx.device)), "ps_lstm_f32")
     return (hout, (h_last, c_last)) if h_last is not None else (hout, None)
 
 

@@ -134,7 +134,7 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
     else:
         hip.conv1x1(x, t, rnn["wih"], rnn["rows"], None, rnn["bias"], out=gx)
     hseq, state = hip.lstm(gx, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride, h0, c0, want_state,
-                           state_shift, state_out)
+                           state_shift, state_out, f16x2=rnn["planes"] == 2)
     # the fused projection + LayerNorm kernel is the short-row kernel (16-frame workgroups): on long rows (the 2-D
     # maps of DPCRN / DPARN: F * ld frames) the MFMA GEMM plus a LayerNorm pass is faster
     if proj["M"] <= 256 and FUSE_PROJ_LN and t <= FUSE_PROJ_LN_MAX_FRAMES:

@@ -587,6 +587,51 @@ def test_lstm_kernel(H, dev, hid, bi, mode):
         assert rel_max(back(cl).numpy(), cn.numpy()) < 2e-5, flags
 
 
+@pytest.mark.parametrize("bi,wscale", [(False, 1.0), (True, 1.0), (False, 1.5), (False, 1e-3)])
+def test_lstm_whole_segment_kernel(H, dev, bi, wscale):
+    """Intra pass at K = 20 (BASELINE config 4's shape): the whole-segment kernel (all 20 steps of 16 sequences held in
+    registers, h' staged in LDS) against the oracle and against the 4-step-group kernel it replaces (debug bit 8 of the
+    second byte); 18 sequences = one full and one ragged workgroup, both directions, initial and final states."""
+    from puresound_amd.nnet._plans import lstm_plan
+    from puresound_amd import _abi
+    hid, n, c, k, s = 64, 2, 12, 20, 9
+    m, sd = _lstm_sd(c, hid, bi, 160)
+    if wscale != 1.0:   # saturating / vanishing recurrent weights: the fp16x2 kernel's per-matrix scale
+        sd = {kk: (v * wscale if "weight_hh" in kk else v) for kk, v in sd.items()}
+        m.load_state_dict(sd)
+    x = _rand((n, c, s * k), 161)
+    d = 2 if bi else 1
+    seqs = x.transpose(1, 2).reshape(n * s, k, c)
+    h0 = _rand((d, n * s, hid), 162, -0.5, 0.5)
+    c0 = _rand((d, n * s, hid), 163, -0.5, 0.5)
+    ref, (hn, cn) = DP.lstm(seqs, sd, "", bi, (h0, c0))
+    p = lstm_plan(m.to(dev), torch.device(dev))
+    t = s * k
+    gx, _ = H.conv1x1(H.pad_rows(x.to(dev)), t, p["wih"], p["rows"], None, p["bias"])
+    to_state = lambda v: H.pad_rows(v.reshape(d, n, s, hid).permute(1, 0, 3, 2).reshape(n, d * hid, s).to(dev))  # noqa: E731
+    back = lambda v: v[..., :s].cpu().reshape(n, d, hid, s).permute(1, 0, 3, 2).reshape(d, n * s, hid)  # noqa: E731
+    outs = []
+    tol = 2e-5
+    # (flags, f16x2): whole-segment fp32, the 4-step-group kernel, whole-segment with the fp16x2 recurrent product
+    for flags, f16x2 in ((4, False), (4 | 256, False), (4, True)):
+        old = _abi.lib().ps_debug_flags(flags)
+        try:
+            hout, (hl, cl) = H.lstm(gx, p["whh_t"], hid, d, s, k, k, 1, to_state(h0), to_state(c0), want_state=True,
+                                    f16x2=f16x2)
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
+        got = hout[..., :t].cpu().transpose(1, 2).reshape(n * s, k, d * hid)
+        e = (rel_max(got.numpy(), ref.numpy()), rel_max(back(hl).numpy(), hn.numpy()), rel_max(back(cl).numpy(), cn.numpy()))
+        assert max(e) < tol, (flags, f16x2, e)
+        outs.append(hout[..., :t].clone())
+    e01 = rel_max(outs[0].cpu().numpy(), outs[1].cpu().numpy())
+    e02 = rel_max(outs[0].cpu().numpy(), outs[2].cpu().numpy())
+    assert e01 < tol / 2, e01         # same arithmetic, other data movement (4e-7; larger weights amplify)
+    print("whole-segment LSTM: group-kernel vs segment", e01, "fp16x2 vs fp32", e02)
+    assert e02 < tol / 2, e02         # fp16x2 product: fp32-class
+
+
 @pytest.mark.parametrize("n,c,t", [(2, 16, 77), (1, 128, 300), (2, 512, 65)])
 def test_chan_layernorm_kernel(H, dev, n, c, t):
     x, res, mul = _rand((n, c, t), 71, -2, 2), _rand((n, c, t), 72), _rand((n, c, t), 73)

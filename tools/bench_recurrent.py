@@ -157,7 +157,7 @@ if __name__ == "__main__":
     ap.add_argument("--chunks", type=int, default=500)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="ps_debug_flags (kernel variant switches)")
-    ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+    ap.add_argument("--gemm", default="fp32", choices=["fp32", "fp16x2", "bf16x3", "bf16"],
                     help="arithmetic of the LSTM input projections (per module: masker.set_gemm_precision)")
     a = ap.parse_args()
     if a.flags:

@@ -1,14 +1,12 @@
 #!/bin/bash
-# usage: tools/prof_recurrent.sh TAG WHICH  -> rocprofv3 kernel trace of tools/bench_recurrent.py (cfg4 or cfg5)
-TAG=$1; WHICH=$2; FLAGS=${3:-0}
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 tools/bench_recurrent.py --which $WHICH --chunks 60 --steps 5 --flags $FLAGS > gpurun_out/benchrec_$TAG.log 2>&1
-tail -3 gpurun_out/benchrec_$TAG.log
-f=$(ls gpurun_out/prof_$TAG/*/*kernel_stats.csv | head -1)
-python3 - "$f" <<'PY'
-import csv,sys
-rows=list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r:-float(r['TotalDurationNs']))
-for r in rows[:14]:
-    print(f"{r['Name'][:70]:70s} calls={r['Calls']:>7s} avg_us={float(r['AverageNs'])/1e3:9.2f} tot_ms={float(r['TotalDurationNs'])/1e6:9.2f} {r['Percentage']}%")
-PY
+# kernel traces of configs 4 and 5 (GPU box): tools/prof_recurrent.sh TAG -> gpurun_out/prof_<TAG>_cfg{4,5}_kernel_stats.csv
+tag=${1:-r03}
+root=$(pwd); cd /tmp && export TMPDIR=/tmp && cd "$root"
+for c in cfg4 cfg5; do
+  out=gpurun_out/prof_${tag}_$c; rm -rf $out
+  extra="--gemm fp16x2"; [ $c = cfg5 ] && extra="--chunks 300"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 tools/bench_recurrent.py --which $c $extra > gpurun_out/prof_${tag}_$c.log 2>&1
+  cp $(ls $out/*/*kernel_stats.csv | head -1) gpurun_out/prof_${tag}_${c}_kernel_stats.csv
+  grep '^{' gpurun_out/prof_${tag}_$c.log > gpurun_out/prof_${tag}_${c}_line.json
+  rm -rf $out
+done
