@@ -475,6 +475,150 @@ __global__ __launch_bounds__(256, NB == 4 ? 3 : 1) void proj_layernorm_rows_kern
   }  // tiles
 }
 
+// The same for K = 64 input channels and M = 128 (the projection behind a unidirectional 64-unit LSTM): a tile's 32
+// k-pairs of activations fit in registers, so the loads of the NEXT tile are issued right behind the tile's last MFMA
+// and land under its LayerNorm and stores, and the residual loads are issued in front of the MFMAs and land under them.
+// All row accesses are buffer instructions: one resource per utterance, the row as a scalar offset (compile-time
+// channel x ldt), ONE per-lane offset register, lanes past T switched off by an out-of-range offset -- the flat-address
+// version of this kernel spent 2300 vector instructions per tile on 64-bit address arithmetic, exec-mask branches and
+// scalar registers spilled into vector lanes, three times its MFMA issue time.  K = 64 and M = 128 exactly: no masks.
+__global__ __launch_bounds__(256, 2) void proj_layernorm_rows64_kernel(ProjLnArgs a) {
+  constexpr int NB = 4, MB = NB * 32, LDW = MB + 32, KP2 = 32;
+  constexpr unsigned OOB = 0x7ffffff0u;  // past every resource's num_records: loads return 0, stores are dropped
+  extern __shared__ __attribute__((aligned(16))) float pl_smem[];
+  float* wl = pl_smem;                // [64][LDW]
+  float* gl = wl + (size_t)64 * LDW;  // gamma[MB] | beta[MB] | bias[MB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the buffer resources below depend on it)
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ldt = a.ldt;
+  const int tb = (a.T + 127) / 128;
+  const int ntiles = tb * a.N;
+  const int xslab = a.K * ldt * 4, yslab = a.M * ldt * 4;  // bytes per utterance (< 2^31: checked by the launcher)
+
+  float bv[KP2];
+  auto load_bv = [&](int tile) {  // activations of this wave's 32 frames of `tile`: row k = 2u + lh
+    const bool ok = tile < ntiles;
+    const int n = ok ? tile / tb : 0, t0 = (ok ? (tile % tb) * 128 : 0) + wave * 32, t = t0 + lr;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x) + (size_t)n * a.K * ldt, 0, (ok && t0 < a.T) ? xslab : 0, 0x00020000);
+    // (frames beyond T inside the row are padding: computed, not stored; rows k >= K lie past num_records)
+    const unsigned vo = t < ldt ? (unsigned)(lh * ldt + t) * 4u : OOB;
+#pragma unroll
+    for (int u = 0; u < KP2; ++u)
+      bv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vo, 2 * u * ldt * 4, 0));
+  };
+  load_bv(blockIdx.x);  // (in flight while the weights are staged)
+
+  {
+    constexpr int V4 = MB / 4;
+    const int nv = 64 * V4;
+    for (int i0 = tid; i0 < nv; i0 += 256 * 8) {
+      f32x4 wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u;
+        const int k = i / V4, m4 = i % V4;
+        wv[u] = (i < nv && k < a.Kp) ? *reinterpret_cast<const f32x4*>(a.wt + (size_t)k * 256 + 4 * m4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < nv) *reinterpret_cast<f32x4*>(wl + (i / V4) * LDW + 4 * (i % V4)) = wv[u];
+      }
+    }
+  }
+  for (int m = tid; m < MB; m += 256) {
+    gl[m] = m < a.M ? a.gamma[m] : 0.f;
+    gl[MB + m] = m < a.M ? a.beta[m] : 0.f;
+    gl[2 * MB + m] = (m < a.M && a.bias) ? a.bias[m] : 0.f;
+  }
+  __syncthreads();
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / tb, t0 = (tile % tb) * 128 + wave * 32;
+    if (t0 >= a.T) {  // (wave-uniform; its activations were requested from an empty resource)
+      if (a.y_amax && lane == 0) a.y_amax[(size_t)n * tb * 4 + (tile % tb) * 4 + wave] = 0.f;
+      load_bv(tile + gridDim.x);
+      continue;
+    }
+    const int t = t0 + lr;
+    const bool live = t < a.T;
+    const unsigned vo = live ? (unsigned)(4 * lh * ldt + t) * 4u : OOB;  // channel 32 j + (r & 3) + 8 (r >> 2) + 4 lh
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res ? a.res : a.y) + (size_t)n * a.M * ldt, 0, a.res ? yslab : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr =
+        __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)n * a.M * ldt, 0, yslab, 0x00020000);
+    float rv[NB][16];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = 32 * j + (r & 3) + 8 * (r >> 2);
+        rv[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, vo, cu * ldt * 4, 0));
+      }
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < KP2; ++u) {
+      const float* wr = wl + (2 * u + lh) * LDW + lr;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[j * 32], bv[u], acc[j], 0, 0, 0);
+    }
+    load_bv(tile + gridDim.x);
+
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int c0 = 32 * j + 8 * rq + 4 * lh;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(gl + 2 * MB + c0);
+#pragma unroll
+        for (int r3 = 0; r3 < 4; ++r3) {
+          float v = acc[j][rq * 4 + r3] + b4[r3];
+          if (a.res_inside) v += rv[j][rq * 4 + r3];
+          acc[j][rq * 4 + r3] = v;
+          s += v;
+        }
+      }
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s / (float)a.M;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float dv = acc[j][r] - mean;
+        q += dv * dv;
+      }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.f / sqrtf(q / (float)a.M + a.eps);
+    float amx = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int c0 = 32 * j + 8 * rq + 4 * lh;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gl + c0), be4 = *reinterpret_cast<const f32x4*>(gl + MB + c0);
+#pragma unroll
+        for (int r3 = 0; r3 < 4; ++r3) {
+          float v = (acc[j][rq * 4 + r3] - mean) * rstd * g4[r3] + be4[r3];
+          if (!a.res_inside) v += rv[j][rq * 4 + r3];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, vo, (32 * j + 8 * rq + r3) * ldt * 4, 0);
+          amx = fmaxf(amx, live ? fabsf(v) : 0.f);
+        }
+      }
+    if (a.y_amax) {
+      amx = wave_max(amx);
+      if (lane == 0) a.y_amax[(size_t)n * tb * 4 + (tile % tb) * 4 + wave] = amx;
+    }
+  }
+}
+
 int conv1x1_small_launch(const float* x, const float* wt, float* y, int N, int K, int M, int T, int ldt,
                          const ps_prologue* pro, const float* bias, const float* bias_n, const float* res,
                          hipStream_t stream) {
@@ -626,7 +770,12 @@ extern "C" int ps_proj_layernorm_amax_f32(const float* x, const float* wt, const
     // wave per SIMD): the projection matrix is staged once, not once per tile
     const long long slots = (long long)device_cus() * (nb == 4 ? 3 : 1);  // persistent: as many as are resident
     dim3 grid((unsigned)(tiles < slots ? tiles : slots));
-    if (nb == 4)
+    if (K == 64 && M == 128 && (long long)M * ldt * 4 < (1ll << 31) && !(g_debug_flags & 512)) {  // (debug bit 9: the unpipelined kernel, for the tests)
+      const long long slots2 = (long long)device_cus() * 2;
+      const size_t lds64 = ((size_t)64 * (4 * 32 + 32) + 3 * 4 * 32) * sizeof(float);
+      hipLaunchKernelGGL(proj_layernorm_rows64_kernel, dim3((unsigned)(tiles < slots2 ? tiles : slots2)), dim3(256), lds64,
+                         (hipStream_t)stream, a);
+    } else if (nb == 4)
       hipLaunchKernelGGL((proj_layernorm_rows_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream, a);
     else
       hipLaunchKernelGGL((proj_layernorm_rows_kernel<8>), grid, dim3(256), lds, (hipStream_t)stream, a);
