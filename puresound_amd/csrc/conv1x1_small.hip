@@ -763,22 +763,36 @@ extern "C" int ps_proj_layernorm_amax_f32(const float* x, const float* wt, const
   const int kp = (K + 15) / 16 * 16;
   const int nb = M <= 128 ? 4 : 8;
   const size_t lds = ((size_t)kp * (nb * 32 + 32) + 3 * nb * 32) * sizeof(float);
-  if (!y2 && !x_copy && T >= 128 && lds <= 64 * 1024 && !(g_debug_flags & 16)) {
+  if (!y2 && !x_copy && T >= 128 && lds <= 128 * 1024 && !(g_debug_flags & 16)) {
     LaunchTimer timer("proj_layernorm", (hipStream_t)stream);
     const long long tiles = (long long)((T + 127) / 128) * N;
     // one persistent workgroup per CU (the kernel holds a tile's accumulators AND its residual values: 256 registers, one
     // wave per SIMD): the projection matrix is staged once, not once per tile
-    const long long slots = (long long)device_cus() * (nb == 4 ? 3 : 1);  // persistent: as many as are resident
+    // persistent: as many workgroups as are resident (three per CU by registers for M <= 128, fewer by LDS for wide K)
+    const long long per_cu = nb == 4 ? (lds <= 48 * 1024 ? 3 : lds <= 76 * 1024 ? 2 : 1) : 1;
+    const long long slots = (long long)device_cus() * per_cu;
     dim3 grid((unsigned)(tiles < slots ? tiles : slots));
     if (K == 64 && M == 128 && (long long)M * ldt * 4 < (1ll << 31) && !(g_debug_flags & 512)) {  // (debug bit 9: the unpipelined kernel, for the tests)
       const long long slots2 = (long long)device_cus() * 2;
       const size_t lds64 = ((size_t)64 * (4 * 32 + 32) + 3 * 4 * 32) * sizeof(float);
       hipLaunchKernelGGL(proj_layernorm_rows64_kernel, dim3((unsigned)(tiles < slots2 ? tiles : slots2)), dim3(256), lds64,
                          (hipStream_t)stream, a);
-    } else if (nb == 4)
-      hipLaunchKernelGGL((proj_layernorm_rows_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream, a);
-    else
-      hipLaunchKernelGGL((proj_layernorm_rows_kernel<8>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+      static const bool big_lds = [] {  // dynamic LDS beyond 64 KiB has to be asked for, once per kernel
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_layernorm_rows_kernel<4>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_layernorm_rows_kernel<8>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+      }();
+      if (!big_lds && lds > 64 * 1024) {
+        set_error("ps_proj_layernorm_f32: %zu bytes of LDS refused by the runtime", lds);
+        return PS_E_UNSUPPORTED;
+      }
+      if (nb == 4)
+        hipLaunchKernelGGL((proj_layernorm_rows_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream, a);
+      else
+        hipLaunchKernelGGL((proj_layernorm_rows_kernel<8>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    }
     return small_status("ps_proj_layernorm_f32");
   }
   if (y_amax) {

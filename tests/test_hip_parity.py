@@ -831,7 +831,7 @@ def test_fused_streaming_step_kernels(H, dev):
 
 
 @pytest.mark.parametrize("n,k,m,t", [(3, 64, 128, 4000), (1, 64, 128, 1501), (5, 20, 100, 900), (2, 32, 256, 777),
-                                     (1, 100, 200, 4100)])
+                                     (1, 100, 200, 4100), (2, 128, 128, 1000), (1, 96, 256, 700)])
 @pytest.mark.parametrize("res_inside", [False, True])
 def test_proj_layernorm_on_long_rows(H, dev, n, k, m, t, res_inside):
     """ps_proj_layernorm_f32 on the offline paths' long rows: the row kernel (32 frames x all channels per wave,
