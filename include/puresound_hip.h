@@ -56,8 +56,9 @@ const char* ps_last_error(void);
  * "unpad_rows", "frame", "complex_mask", "istft_ola", "attn_stats_pool", "lstm", "lstm_cell", "chan_layernorm", "unfold_taps", "gated_product", "segment_overlap",
  * "film_conv", "lstm_gates_cell", "proj_layernorm", "overlap_average", "stream_windows", "stream_overlap", "conv1x1_bf16", "unfold2d", "conv2d", "activation", "add", "magnitude", "real_mask", "norm_activation", "self_attention", "add_position",
  * "film_apply").  Not for use under stream capture. */
-int ps_debug_flags(int flags); /* test/profiling hooks; bits 8..23: cap of the conv1x1 persistent grid (0 = off);
-                                  <0 reads; returns the old value */
+int ps_debug_flags(int flags); /* test/profiling hooks; bits 0..7, 20..30: kernel-variant switches (named where they are
+                                  tested); bits 8..19: cap of the conv1x1 persistent grid (0 = off); <0 reads; returns
+                                  the old value */
 int ps_debug_buffer(void* device_buffer); /* 6 x u64 per conv1x1 workgroup: s_memtime stamps + HW ids */
 int ps_profile_enable(int on);
 int ps_profile_read(const char* kernel, double* total_ms, int* launches);

@@ -670,7 +670,7 @@ extern "C" int ps_conv1x1_f32(const float* x, const float* wt, float* y, int N, 
   int grid = a.ntiles < persistent_grid() ? a.ntiles : persistent_grid();
   // test hook (ps_debug_flags bits 8..23): cap the persistent grid so that a workgroup's run spans many
   // tiles / utterances even on small problems
-  if ((g_debug_flags >> 8) & 0xffff) grid = grid < ((g_debug_flags >> 8) & 0xffff) ? grid : ((g_debug_flags >> 8) & 0xffff);
+  if ((g_debug_flags >> 8) & 0xfff) grid = grid < ((g_debug_flags >> 8) & 0xfff) ? grid : ((g_debug_flags >> 8) & 0xfff);
   const bool tr = a.pro.norm != PS_NORM_NONE || a.pro.prelu || a.pro.pre_relu || a.pro.post_tanh;
   {
     LaunchTimer timer("conv1x1", (hipStream_t)stream);

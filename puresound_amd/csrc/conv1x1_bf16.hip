@@ -1447,7 +1447,7 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
   const long long nsuper = (long long)st_per * a.tiles_m * N;
   const int cus = bf16_cus();
   int G = (int)(nsuper < cus ? nsuper : cus);
-  const int cap = (g_debug_flags >> 8) & 0xffff;  // grid cap (tests, experiments)
+  const int cap = (g_debug_flags >> 8) & 0xfff;  // grid cap (tests, experiments)
   if (cap && G > cap) G = cap;
   const long long per_wg = (nsuper + G - 1) / G, per_utt = (long long)st_per * a.tiles_m;
   const bool big = 2 * nsuper >= cus || (g_debug_flags & (1 << 28));  // bit 28: ping-pong kernel at any size (tests)

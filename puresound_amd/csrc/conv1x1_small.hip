@@ -332,15 +332,16 @@ __global__ __launch_bounds__(64 * NW) void proj_layernorm_kernel(ProjLnArgs a) {
 // consecutive frames, so every global access is two 128-byte pieces, the projection matrix sits in LDS ([k][m], rows
 // padded by 32 floats: the two half-waves read different banks), and a frame's LayerNorm needs the lane's own registers
 // and ONE exchange with lane ^ 32.  Two-pass variance as the reference.
-// Three workgroups per CU for M <= 128 (166 registers; 40 KiB of LDS each): one wave per SIMD left the tile's two load
-// latencies, its 128 MFMAs and its 64 stores strictly in sequence (67 us per launch on config 4's rows, 51 with three).
+// Two workgroups per CU for M <= 128: one wave per SIMD (the flat-address version's 418 registers) left the tile's two load
+// latencies, its 128 MFMAs and its 64 stores strictly in sequence (67 us per launch on config 4's rows, 53 now).
 template <int NB>
-__global__ __launch_bounds__(256, NB == 4 ? 3 : 1) void proj_layernorm_rows_kernel(ProjLnArgs a) {
+__global__ __launch_bounds__(256, NB == 4 ? 2 : 1) void proj_layernorm_rows_kernel(ProjLnArgs a) {
   constexpr int MB = NB * 32, LDW = MB + 32;
   extern __shared__ __attribute__((aligned(16))) float pl_smem[];
   float* wl = pl_smem;                 // [Kp][LDW]
   float* gl = wl + (size_t)a.Kp * LDW;  // gamma[MB] | beta[MB] | bias[MB]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the buffer resources below depend on it)
   const int lr = lane & 31, lh = lane >> 5;
   // the projection matrix goes to LDS ONCE per (persistent) workgroup: 16-byte loads, eight in flight per thread (a
   // dword-at-a-time loop of dependent load / store pairs cost 20 us per workgroup -- more than its tiles)
@@ -382,15 +383,28 @@ __global__ __launch_bounds__(256, NB == 4 ? 3 : 1) void proj_layernorm_rows_kern
   for (int j = 0; j < NB; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  // addressing: every row address is a wave-uniform pointer (utterance, compile-time channel -> scalar registers) plus
-  // ONE per-lane 32-bit offset, so the 64 + 64 + 32 loads / stores of a tile share a single address register (as
-  // 64-bit per-access offsets they took the kernel to 418 registers and one wave per SIMD)
-  const unsigned ldt = (unsigned)a.ldt;
-  const unsigned lo_x = (unsigned)lh * ldt + (unsigned)t;      // activation row k0 + 2u + lh
-  const unsigned lo_y = 4u * (unsigned)lh * ldt + (unsigned)t;  // channel 32 j + (r & 3) + 8 (r >> 2) + 4 lh
-  const float* xn = a.x + (size_t)n * a.K * ldt;  // (frames beyond T inside the row are padding: computed, not stored)
-  const float* rn = a.res ? a.res + (size_t)n * a.M * ldt : nullptr;
-  float* yn = a.y + (size_t)n * a.M * ldt;
+  // addressing: buffer instructions -- one resource per utterance, the row as a scalar offset (compile-time channel x ldt),
+  // ONE per-lane offset, masked lanes switched off by an out-of-range offset.  (Flat addresses cost this kernel 64-bit
+  // vector arithmetic per access, an exec-mask branch around every guarded one and ~250 scalar registers spilled into
+  // vector lanes: 2300 vector instructions per tile against 128 MFMAs.)
+  constexpr unsigned OOB = 0x7ffffff0u;
+  const int ldt = a.ldt;
+  const unsigned vo_x = t < ldt ? (unsigned)(lh * ldt + t) * 4u : OOB;   // activation row k0 + 2u + lh
+  const unsigned vo_y = live ? (unsigned)(4 * lh * ldt + t) * 4u : OOB;  // channel 32 j + (r & 3) + 8 (r >> 2) + 4 lh
+  // M % 4 == 0 (the launcher's condition): the four channels 32 j + 8 rq + {0..3} + 4 lh of a lane lie on one side of M,
+  // so 4 NB lane offsets (valid or out of range) serve all 16 NB residual loads and stores
+  const int mlim = a.M - 4 * lh, klim = a.K - lh;
+  unsigned vq[NB][4];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) vq[j][rq] = 32 * j + 8 * rq < mlim ? vo_y : OOB;
+  const __amdgpu_buffer_rsrc_t xr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)n * a.K * ldt, 0, a.K * ldt * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.res ? a.res : a.y) + (size_t)n * a.M * ldt, 0, a.res ? a.M * ldt * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr =
+      __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)n * a.M * ldt, 0, a.M * ldt * 4, 0x00020000);
   // the residual values of the tile are requested up front, next to the activations: behind the MFMAs they would be 16 NB
   // dependent loads per lane with nothing left to hide them (the first version: 40 us per tile)
   float rv[NB][16];
@@ -399,7 +413,8 @@ __global__ __launch_bounds__(256, NB == 4 ? 3 : 1) void proj_layernorm_rows_kern
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cu = 32 * j + (r & 3) + 8 * (r >> 2);
-      rv[j][r] = (rn && live && cu + 4 * lh < a.M) ? (rn + (size_t)cu * ldt)[lo_y] : 0.f;
+      rv[j][r] = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(rr, vq[j][r >> 2], cu * ldt * 4, 0));
     }
   constexpr int KU = 16;                                // k-pairs whose activation loads are in flight together
   for (int k0 = 0; k0 < a.Kp; k0 += 2 * KU) {
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(256, NB == 4 ? 3 : 1) void proj_layernorm_rows_kern
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       const int ku = k0 + 2 * u;
-      bv[u] = (ku + lh < a.K && t < a.ldt) ? (xn + (size_t)ku * ldt)[lo_x] : 0.f;
+      bv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ku < klim ? vo_x : OOB, ku * ldt * 4, 0));
     }
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
@@ -429,10 +444,9 @@ __global__ __launch_bounds__(256, NB == 4 ? 3 : 1) void proj_layernorm_rows_kern
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(gl + 2 * MB + c0);
 #pragma unroll
       for (int r3 = 0; r3 < 4; ++r3) {
-        const int c = c0 + r3;
+        // (channels >= M: zero weight rows, zero bias, residual read out of range -- v is 0 without a mask)
         float v = acc[j][rq * 4 + r3] + b4[r3];
         if (a.res_inside) v += rv[j][rq * 4 + r3];
-        v = c < a.M ? v : 0.f;
         acc[j][rq * 4 + r3] = v;
         s += v;
       }
@@ -444,8 +458,7 @@ __global__ __launch_bounds__(256, NB == 4 ? 3 : 1) void proj_layernorm_rows_kern
   for (int j = 0; j < NB; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int c = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float dv = c < a.M ? acc[j][r] - mean : 0.f;
+      const float dv = vq[j][r >> 2] != OOB ? acc[j][r] - mean : 0.f;
       q += dv * dv;
     }
   q += __shfl_xor(q, 32, 64);
@@ -459,13 +472,11 @@ __global__ __launch_bounds__(256, NB == 4 ? 3 : 1) void proj_layernorm_rows_kern
       const f32x4 g4 = *reinterpret_cast<const f32x4*>(gl + c0), be4 = *reinterpret_cast<const f32x4*>(gl + MB + c0);
 #pragma unroll
       for (int r3 = 0; r3 < 4; ++r3) {
-        const int c = c0 + r3;
-        if (live && c < a.M) {
-          float v = (acc[j][rq * 4 + r3] - mean) * rstd * g4[r3] + be4[r3];
-          if (!a.res_inside) v += rv[j][rq * 4 + r3];
-          (yn + (size_t)(c0 - 4 * lh + r3) * ldt)[lo_y] = v;
-          amx = fmaxf(amx, fabsf(v));
-        }
+        float v = (acc[j][rq * 4 + r3] - mean) * rstd * g4[r3] + be4[r3];
+        if (!a.res_inside) v += rv[j][rq * 4 + r3];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, vq[j][rq],
+                                              (32 * j + 8 * rq + r3) * ldt * 4, 0);
+        amx = fmaxf(amx, vq[j][rq] != OOB ? fabsf(v) : 0.f);
       }
     }
   if (a.y_amax) {
@@ -763,16 +774,17 @@ extern "C" int ps_proj_layernorm_amax_f32(const float* x, const float* wt, const
   const int kp = (K + 15) / 16 * 16;
   const int nb = M <= 128 ? 4 : 8;
   const size_t lds = ((size_t)kp * (nb * 32 + 32) + 3 * nb * 32) * sizeof(float);
-  if (!y2 && !x_copy && T >= 128 && lds <= 128 * 1024 && !(g_debug_flags & 16)) {
+  if (!y2 && !x_copy && T >= 128 && M % 4 == 0 && lds <= 128 * 1024 && (long long)(M > K ? M : K) * ldt * 4 < (1ll << 31) &&
+      !(g_debug_flags & 16)) {
     LaunchTimer timer("proj_layernorm", (hipStream_t)stream);
     const long long tiles = (long long)((T + 127) / 128) * N;
     // one persistent workgroup per CU (the kernel holds a tile's accumulators AND its residual values: 256 registers, one
     // wave per SIMD): the projection matrix is staged once, not once per tile
-    // persistent: as many workgroups as are resident (three per CU by registers for M <= 128, fewer by LDS for wide K)
-    const long long per_cu = nb == 4 ? (lds <= 48 * 1024 ? 3 : lds <= 76 * 1024 ? 2 : 1) : 1;
+    // persistent: as many workgroups as are resident (two per CU by registers for M <= 128, one by LDS for wide K)
+    const long long per_cu = nb == 4 ? (lds <= 76 * 1024 ? 2 : 1) : 1;
     const long long slots = (long long)device_cus() * per_cu;
     dim3 grid((unsigned)(tiles < slots ? tiles : slots));
-    if (K == 64 && M == 128 && (long long)M * ldt * 4 < (1ll << 31) && !(g_debug_flags & 512)) {  // (debug bit 9: the unpipelined kernel, for the tests)
+    if (K == 64 && M == 128 && !(g_debug_flags & (1 << 21))) {  // (debug bit 21: the unpipelined kernel, for the tests)
       const long long slots2 = (long long)device_cus() * 2;
       const size_t lds64 = ((size_t)64 * (4 * 32 + 32) + 3 * 4 * 32) * sizeof(float);
       hipLaunchKernelGGL(proj_layernorm_rows64_kernel, dim3((unsigned)(tiles < slots2 ? tiles : slots2)), dim3(256), lds64,

@@ -916,7 +916,7 @@ static int lstm_launch(const ps_lstm_args* args, void* stream, bool f16x2) {
     if (wide) {
       dim3 mgrid((unsigned)((seqs + 15) / 16), 1, a.D);
       // whole segments of 20 consecutive frames (DPRNN's intra pass at K = 20): all steps fetched up front
-      const bool seg = a.H == 64 && contig && a.steps == 20 && !(g_debug_flags & 256);
+      const bool seg = a.H == 64 && contig && a.steps == 20 && !(g_debug_flags & (1 << 20));
       if (seg && f16x2 && a.D == 1)
         hipLaunchKernelGGL((lstm_seg_f16x2_kernel<64, 20, false>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
       else if (seg && f16x2)

@@ -590,8 +590,7 @@ def test_lstm_kernel(H, dev, hid, bi, mode):
 @pytest.mark.parametrize("bi,wscale", [(False, 1.0), (True, 1.0), (False, 1.5), (False, 1e-3)])
 def test_lstm_whole_segment_kernel(H, dev, bi, wscale):
     """Intra pass at K = 20 (BASELINE config 4's shape): the whole-segment kernel (all 20 steps of 16 sequences held in
-    registers, h' staged in LDS) against the oracle and against the 4-step-group kernel it replaces (debug bit 8 of the
-    second byte); 18 sequences = one full and one ragged workgroup, both directions, initial and final states."""
+    registers, h' staged in LDS) against the oracle and against the 4-step-group kernel it replaces (debug bit 20); 18 sequences = one full and one ragged workgroup, both directions, initial and final states."""
     from puresound_amd.nnet._plans import lstm_plan
     from puresound_amd import _abi
     hid, n, c, k, s = 64, 2, 12, 20, 9
@@ -613,7 +612,7 @@ def test_lstm_whole_segment_kernel(H, dev, bi, wscale):
     outs = []
     tol = 2e-5
     # (flags, f16x2): whole-segment fp32, the 4-step-group kernel, whole-segment with the fp16x2 recurrent product
-    for flags, f16x2 in ((4, False), (4 | 256, False), (4, True)):
+    for flags, f16x2 in ((4, False), (4 | 1 << 20, False), (4, True)):
         old = _abi.lib().ps_debug_flags(flags)
         try:
             hout, (hl, cl) = H.lstm(gx, p["whh_t"], hid, d, s, k, k, 1, to_state(h0), to_state(c0), want_state=True,
@@ -850,8 +849,8 @@ def test_proj_layernorm_on_long_rows(H, dev, n, k, m, t, res_inside):
     if not res_inside:
         ref = ref + res.double()
     outs = []
-    # 0: by shape (K <= 64, M <= 128: the pipelined row kernel), 512: the unpipelined row kernel, 16: the 16-frame kernel
-    for flags in (0, 512, 16):
+    # 0: by shape (K = 64, M = 128: the pipelined row kernel), bit 21: the unpipelined row kernel, 16: the 16-frame kernel
+    for flags in (0, 1 << 21, 16):
         old = _abi.lib().ps_debug_flags(flags)
         try:
             y, _ = H.proj_layernorm(H.pad_rows(hx.to(dev)), t, H.pack_wt(wp.to(dev)), bp.to(dev), m, g1.to(dev), b1.to(dev),

@@ -23,7 +23,7 @@ for wscale in (1.0, 1e-1, 1e-2, 1e-3, 0.0):
     ref = ref.reshape(n, hid, s * k)
     gxp = H.pad_rows(gx.to(dev))
     out = {}
-    for name, flags, f in (("seg32", 4, False), ("grp32", 4 | 256, False), ("seg16x2", 4, True)):
+    for name, flags, f in (("seg32", 4, False), ("grp32", 4 | 1 << 20, False), ("seg16x2", 4, True)):
         old = _abi.lib().ps_debug_flags(flags)
         ho, _ = H.lstm(gxp, whh.to(dev).contiguous(), hid, 1, s, k, k, 1, H.pad_rows(h0.to(dev)), H.pad_rows(c0.to(dev)), f16x2=f)
         torch.cuda.synchronize()
