@@ -343,7 +343,11 @@ __global__ __launch_bounds__(H * 4, 1) void lstm_seg_kernel(LstmK k) {
   const int d = blockIdx.z;
   const int b = blockIdx.x * 16 + col;
   const bool valid = b < a.N * a.Q;
-  const int n = valid ? b / a.Q : 0, q = valid ? b % a.Q : 0;
+  // sequences past the end (the last workgroup) replay the last real one: every load below is unconditional -- a guarded
+  // load is an exec-mask branch each, and one of them made the compiler wait for ALL outstanding loads -- and nothing of
+  // theirs is stored (seq_off < 0, `valid` around the final states)
+  const int bb = valid ? b : a.N * a.Q - 1;
+  const int n = bb / a.Q, q = bb % a.Q;
   const int G = 4 * H;
   const int unit0 = 16 * w + 4 * quad;
   const bool rev = BIDIR && d == 1;  // (one direction: the loads land in their final registers, no selects)
@@ -351,24 +355,7 @@ __global__ __launch_bounds__(H * 4, 1) void lstm_seg_kernel(LstmK k) {
 
   if (threadIdx.x < 16) seq_off[threadIdx.x] = valid ? (long long)((size_t)(n * a.D + d) * H * ldt + (size_t)q * a.q_stride) : -1;
 
-  // every step's pre-activations: pre[s][g][r], s in processing order (frame STEPS-1-s for the reverse direction)
-  float pre[STEPS][4][4];
-  {
-    const float* gp = a.gx + ((size_t)(n * a.D + d) * G + unit0) * ldt + (size_t)q * a.q_stride;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < NG; ++j) {
-          const int jj = rev ? NG - 1 - j : j;
-          const f32x4 v = valid ? *reinterpret_cast<const f32x4*>(gp + (size_t)(g * H + r) * ldt + 4 * jj)
-                                : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pre[4 * j + e][g][r] = rev ? v[3 - e] : v[e];
-        }
-  }
-
+  // recurrent weights and initial states first: loads return in order, and these are needed before step 0
   float wf[4][KB];
   {
     const float* wt = a.whh_t + (size_t)d * H * G;
@@ -394,6 +381,26 @@ __global__ __launch_bounds__(H * 4, 1) void lstm_seg_kernel(LstmK k) {
       }
     }
   }
+
+  // every step's pre-activations: pre[s][g][r], s in processing order (frame STEPS-1-s for the reverse direction)
+  float pre[STEPS][4][4];
+  {
+    const float* gp = a.gx + ((size_t)(n * a.D + d) * G + unit0) * ldt + (size_t)q * a.q_stride;
+    // (the five 16-byte groups of a row back to back: they share a 128-byte line and merge on the way to the L2; with the
+    //  step groups outermost -- first steps startable earlier -- the kernel took 72 us instead of 61)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+          const int jj = rev ? NG - 1 - j : j;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(gp + (size_t)(g * H + r) * ldt + 4 * jj);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pre[4 * j + e][g][r] = rev ? v[3 - e] : v[e];
+        }
+  }
+
 #pragma unroll
   for (int r = 0; r < 4; ++r) hbuf[0][((w * 4 + r) * 4 + quad) * 16 + col] = h[r];
   __syncthreads();
@@ -473,7 +480,11 @@ __global__ __launch_bounds__(H * 4, 1) void lstm_seg_f16x2_kernel(LstmK k) {
   const int d = blockIdx.z;
   const int b = blockIdx.x * 16 + col;
   const bool valid = b < a.N * a.Q;
-  const int n = valid ? b / a.Q : 0, q = valid ? b % a.Q : 0;
+  // sequences past the end (the last workgroup) replay the last real one: every load below is unconditional -- a guarded
+  // load is an exec-mask branch each, and one of them made the compiler wait for ALL outstanding loads -- and nothing of
+  // theirs is stored (seq_off < 0, `valid` around the final states)
+  const int bb = valid ? b : a.N * a.Q - 1;
+  const int n = bb / a.Q, q = bb % a.Q;
   const int G = 4 * H;
   const int unit0 = 16 * w + 4 * quad;
   const bool rev = BIDIR && d == 1;  // (one direction: the loads land in their final registers, no selects)
@@ -482,28 +493,69 @@ __global__ __launch_bounds__(H * 4, 1) void lstm_seg_f16x2_kernel(LstmK k) {
   if (threadIdx.x < 16) seq_off[threadIdx.x] = valid ? (long long)((size_t)(n * a.D + d) * H * ldt + (size_t)q * a.q_stride) : -1;
 
   // A fragments: gate g, k-step ks: lane (row = lane & 15 -> unit 16 w + row, k-group = lane >> 4) holds k = 32 ks + 8 kgroup + e
+  // Issue order: the 64 recurrent weights of this lane, then all STEPS x 16 pre-activations, THEN the weights' maximum,
+  // scale and split -- the weights return first (loads return in order) and are processed under the pre-activations'
+  // flight instead of in front of it.
+  const float* wt = a.whh_t + (size_t)d * H * G;
+  float wv[4][2][8];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wv[g][ks][e] = wt[(size_t)(32 * ks + 8 * quad + e) * G + g * H + 16 * w + col];
+
+  // (initial states next: loads return in order, and these are waited for before step 0)
+  float c[4] = {0.f, 0.f, 0.f, 0.f}, h[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid && (a.h0 || a.c0)) {
+    const int bs = b - a.state_shift;
+    if (bs >= 0) {
+      const int nn = bs / a.Q, qq = bs % a.Q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t off = ((size_t)(nn * a.D + d) * H + unit0 + r) * a.ldq + qq;
+        if (a.h0) h[r] = a.h0[off];
+        if (a.c0) c[r] = a.c0[off];
+      }
+    }
+  }
+
+  float pre[STEPS][4][4];
+  {
+    const float* gp = a.gx + ((size_t)(n * a.D + d) * G + unit0) * ldt + (size_t)q * a.q_stride;
+    // (the five 16-byte groups of a row back to back: they share a 128-byte line and merge on the way to the L2; with the
+    //  step groups outermost -- first steps startable earlier -- the kernel took 72 us instead of 61)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+          const int jj = rev ? NG - 1 - j : j;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(gp + (size_t)(g * H + r) * ldt + 4 * jj);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pre[4 * j + e][g][r] = rev ? v[3 - e] : v[e];
+        }
+  }
+
+
   f16x8 whi[4][2], wlo[4][2];
   float inv;
   {
-    const float* wt = a.whh_t + (size_t)d * H * G;
-    float wv[4][2][8];
     float m = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          wv[g][ks][e] = wt[(size_t)(32 * ks + 8 * quad + e) * G + g * H + 16 * w + col];
-          m = fmaxf(m, fabsf(wv[g][ks][e]));
-        }
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(wv[g][ks][e]));
     m = wave_max(m);
     if (lane == 0) wmax[w] = m;
     __syncthreads();
     m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
     int ex = 0;
     if (m > 0.f) frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
-    ex = ex < -27 ? -27 : ex;     // (tiny matrices: keep the scaled pre-activations far from overflow)
+    ex = ex < -27 ? -27 : ex;     // (tiny matrices: keep the scaled products far from overflow)
     const float S = ldexpf(1.f, 13 - ex);
     inv = 1.f / (S * 1024.f);
 #pragma unroll
@@ -518,38 +570,7 @@ __global__ __launch_bounds__(H * 4, 1) void lstm_seg_f16x2_kernel(LstmK k) {
           wlo[g][ks][e] = (_Float16)(ws - (float)hi);
         }
   }
-  asm volatile("" ::: "memory");  // (the 320 pre-activation loads stay behind the 64 fp32 weights they would crowd out)
 
-  float pre[STEPS][4][4];
-  {
-    const float* gp = a.gx + ((size_t)(n * a.D + d) * G + unit0) * ldt + (size_t)q * a.q_stride;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < NG; ++j) {
-          const int jj = rev ? NG - 1 - j : j;
-          const f32x4 v = valid ? *reinterpret_cast<const f32x4*>(gp + (size_t)(g * H + r) * ldt + 4 * jj)
-                                : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pre[4 * j + e][g][r] = rev ? v[3 - e] : v[e];
-        }
-  }
-
-  float c[4] = {0.f, 0.f, 0.f, 0.f}, h[4] = {0.f, 0.f, 0.f, 0.f};
-  if (valid && (a.h0 || a.c0)) {
-    const int bs = b - a.state_shift;
-    if (bs >= 0) {
-      const int nn = bs / a.Q, qq = bs % a.Q;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const size_t off = ((size_t)(nn * a.D + d) * H + unit0 + r) * a.ldq + qq;
-        if (a.h0) h[r] = a.h0[off];
-        if (a.c0) c[r] = a.c0[off];
-      }
-    }
-  }
   auto put_h = [&](int buf) {  // this lane's 4 units of sequence `col`: two 8-byte writes
     f16x4 hi4, lo4;
 #pragma unroll
