@@ -666,7 +666,10 @@ __global__ __launch_bounds__(H * 4) void lstm_m4_kernel(LstmK k) {
   const int grp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   const int b = grp * 4 + j;
   const bool valid = b < a.N * a.Q;
-  const int n = valid ? b / a.Q : 0, q = valid ? b % a.Q : 0;
+  // sequences past the end replay the last real one: the gate loads of the step loop are unconditional (a guarded load is
+  // an exec-mask branch in the dependent chain of every step); nothing of theirs is stored
+  const int bb = valid ? b : a.N * a.Q - 1;
+  const int n = bb / a.Q, q = bb % a.Q;
   const int G = 4 * H;
 
   // A operand: lane (unit, i = lane&3) holds W_hh[gate i][unit][k]
@@ -709,10 +712,10 @@ __global__ __launch_bounds__(H * 4) void lstm_m4_kernel(LstmK k) {
   } else {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int ts = rev ? steps - 1 - u : u;
+      const int uc = u < steps ? u : steps - 1;
+      const int ts = rev ? steps - 1 - uc : uc;
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        pre[u][g] = (valid && u < steps) ? gp[g * gstride + (size_t)ts * a.step_stride] : 0.f;
+      for (int g = 0; g < 4; ++g) pre[u][g] = gp[g * gstride + (size_t)ts * a.step_stride];
     }
   }
   __syncthreads();
@@ -734,36 +737,44 @@ __global__ __launch_bounds__(H * 4) void lstm_m4_kernel(LstmK k) {
         f32x4 acc[4];
         acc[0] = f32x4{pre[u][0], pre[u][1], pre[u][2], pre[u][3]};
         acc[1] = acc[2] = acc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (!CONTIG) {
-          const int sn = s + PF;
-          const int ts = rev ? steps - 1 - sn : sn;
-          if (sn < steps) {
+#ifndef PS_M4_ABL
+#define PS_M4_ABL 0
+#endif
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[u][g] = valid ? gp[g * gstride + (size_t)ts * a.step_stride] : 0.f;
-          }
-        }
-#pragma unroll
-        for (int kk = 0; kk < H / 4; ++kk) {
+        for (int kk = 0; kk < ((PS_M4_ABL & 1) ? 1 : H / 4); ++kk) {
           const f32x4 hv = *reinterpret_cast<const f32x4*>(hb + 4 * kk);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             acc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[4 * kk + e], hv[e], acc[e], 0, 0, 0);
         }
+        if constexpr (!CONTIG) {
+          // refill the ring slot with step s + PF -- behind the MFMAs (in front of them the four loads and their
+          // address arithmetic sat between the barrier and the first LDS read of the step's dependent chain); steps past
+          // the end re-read the last one
+          const int sn = s + PF < steps ? s + PF : steps - 1;
+          const int ts = rev ? steps - 1 - sn : sn;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) pre[u][g] = gp[g * gstride + (size_t)ts * a.step_stride];
+          // ... and the PREVIOUS step's h' leaves here too (same reason; the last one after the loop)
+          if (s > 0 && valid) hp[(size_t)(rev ? steps - s : s - 1) * a.step_stride] = h;
+        }
         const f32x4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#if PS_M4_ABL & 2
+        c = t[1] * c + t[0] * t[2];
+        h = t[3] * c;
+#else
         const float gi = fast_sigmoid(t[0]);
         const float gf = fast_sigmoid(t[1]);
         const float gg = fast_tanh(t[2]);
         const float go = fast_sigmoid(t[3]);
         c = gf * c + gi * gg;
         h = go * fast_tanh(c);
+#endif
         hbuf[(s + 1) & 1][j * HS + unit] = h;
+        __syncthreads();
         if constexpr (CONTIG) {
           hst[rev ? 3 - u : u] = h;
-        } else {
-          const int ts = rev ? steps - 1 - s : s;
-          if (valid) hp[(size_t)ts * a.step_stride] = h;
         }
-        __syncthreads();
       }
     }
     if constexpr (CONTIG) {
@@ -772,6 +783,9 @@ __global__ __launch_bounds__(H * 4) void lstm_m4_kernel(LstmK k) {
         *reinterpret_cast<f32x4*>(hp + f0) = f32x4{hst[0], hst[1], hst[2], hst[3]};
       }
     }
+  }
+  if constexpr (!CONTIG) {
+    if (valid) hp[(size_t)(rev ? 0 : steps - 1) * a.step_stride] = h;
   }
   if (valid) {
     const size_t off = ((size_t)(n * a.D + d) * H + unit) * a.ldq + q;
