@@ -88,12 +88,14 @@ def cfg4(dev, steps=10, warmup=3, batch=32, gemm="fp32", graph=True):
         out["hipgraph_ms"] = msg
         out["hipgraph_us_per_serial_step"] = msg * 1e3 / (6 * (20 + 200))
     if gemm == "fp32":
-        # the same forward with the LSTM input projections in the fp16x2 arithmetic (fp32-class: l2_rel against the run above)
+        # the same forward with the masker in the fp16x2 arithmetic (fp32-class: l2_rel against the run above)
         ref = model.inference(noisy)
         model.masker.set_gemm_precision("fp16x2")
         ms2, y = _timed(lambda: model.inference(noisy), steps, warmup)
         out["fp16x2_projections"] = {"ms": ms2, "samples_s": batch * L / ms2 * 1e3,
-                                     "l2_rel_vs_fp32": float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref))}
+                                     "l2_rel_vs_fp32": float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref)),
+                                     "arithmetic": "masker.set_gemm_precision('fp16x2'): LSTM input projections and the "
+                                                   "intra-pass recurrent product W_hh h in two fp16 terms per operand"}
         model.masker.set_gemm_precision("fp32")
     return out
 
