@@ -631,6 +631,22 @@ def test_lstm_whole_segment_kernel(H, dev, bi, wscale):
     assert e02 < tol / 2, e02         # fp16x2 product: fp32-class
 
 
+def test_lstm_f16x2_entry_is_the_fp32_kernel_off_its_shape(H, dev):
+    """ps_lstm_f16x2_f32 documents: the two-term recurrent product only where a kernel for it exists (H = 64, 20 consecutive
+    steps), exactly ps_lstm_f32 elsewhere -- here 8-step segments, a 7-step inter pass and H = 128: bit for bit."""
+    from puresound_amd.nnet._plans import lstm_plan
+    for hid, k, s, mode in ((64, 8, 9, "intra"), (64, 5, 7, "inter"), (128, 20, 4, "intra")):
+        n, c = 2, 12
+        m, _ = _lstm_sd(c, hid, False, 170)
+        x = _rand((n, c, s * k), 171)
+        p = lstm_plan(m.to(dev), torch.device(dev))
+        gx, _ = H.conv1x1(H.pad_rows(x.to(dev)), s * k, p["wih"], p["rows"], None, p["bias"])
+        q, qs, steps, ss = (s, k, k, 1) if mode == "intra" else (k, 1, s, k)
+        a, _ = H.lstm(gx, p["whh_t"], hid, 1, q, qs, steps, ss)
+        b, _ = H.lstm(gx, p["whh_t"], hid, 1, q, qs, steps, ss, f16x2=True)
+        assert torch.equal(a[..., :s * k], b[..., :s * k]), (hid, k, s, mode)
+
+
 @pytest.mark.parametrize("n,c,t", [(2, 16, 77), (1, 128, 300), (2, 512, 65)])
 def test_chan_layernorm_kernel(H, dev, n, c, t):
     x, res, mul = _rand((n, c, t), 71, -2, 2), _rand((n, c, t), 72), _rand((n, c, t), 73)
