@@ -39,6 +39,7 @@ class DPRNN(PlanCache, nn.Module):
         self.embed_norm = embed_norm
         self.block_with_embed = block_with_embed
         self.embedding_free_tse = embedding_free_tse
+        self._last_amax = None
 
         self.input_film = nn.ModuleList()
         self.intra_rnn = nn.ModuleList()
@@ -74,8 +75,14 @@ class DPRNN(PlanCache, nn.Module):
                        layernorm_plan(self.inter_norm[i], device))))
         if self.output_fc[0].weight.numel() != 1:
             raise NotImplementedError("PReLU with per-channel slopes is not on the HIP path")
-        return dict(blocks=blocks, out=linear_plan(self.output_fc[1], device),
+        plan = dict(blocks=blocks, out=linear_plan(self.output_fc[1], device),
                     out_slope=_f32(self.output_fc[0].weight, device))
+        if self.gemm_precision == "fp16x2" and self.output_fc[1].in_channels >= 64:
+            # output conv in the fp16x2 arithmetic too (its input range comes from the last row kernel); |slope| <= 1 keeps
+            # PReLU(x) inside the range measured for x (read once, at plan time)
+            if abs(float(self.output_fc[0].weight.detach().reshape(-1)[0])) <= 1.0:
+                plan["out_f16x2"] = hip.pack_wt_f16x2(_f32(self.output_fc[1].weight[:, :, 0], device))
+        return plan
 
     # -- segment geometry -------------------------------------------------------------------------------
     def padded_frames_needed(self, t: int) -> int:
@@ -98,6 +105,7 @@ class DPRNN(PlanCache, nn.Module):
             x, st = lstm_path(x, tp, *blk["inter"], q=k, q_stride=1, steps=s, step_stride=k, h0=h0, c0=c0,
                               want_state=want_states, amax=amax)
             states.append(st)
+        self._last_amax = amax[0]   # (partial maxima of the block stack's output, or None; read by forward_padded only)
         return x, states
 
     def hidden_states_padded(self, e_pad: torch.Tensor, te: int):
@@ -129,10 +137,19 @@ class DPRNN(PlanCache, nn.Module):
             init = self.hidden_states_padded(embed, embed_frames)
             embed = None
         x, _ = self._run_blocks(x_pad, tp, embed, init, False)
+        x_amax = self._last_amax
+        self._last_amax = None
         if self.seg_overlap:
             x = hip.segment_merge(x, tp, t, self.seg_size)              # SplitMerge.merge (dprnn.py:182-185)
+            x_amax = None
         p = self._plan
         pro = hip.make_prologue(0, True, None, 0.0, 0.0, None, None, p["out_slope"])
+        if "out_f16x2" in p:
+            wf, we = p["out_f16x2"]
+            # (the maxima cover the tp >= t frames the blocks ran on: a bound for the first t)
+            y, _, _ = hip.conv1x1_f16x2(x, t, wf, we, p["out"]["M"], pro, p["out"]["bias"],
+                                        x_amax=x_amax if x_amax is not None else hip.absmax(x, t))
+            return y
         y, _ = hip.conv1x1(x, t, p["out"]["wt"], p["out"]["M"], pro, p["out"]["bias"])
         return y
 
