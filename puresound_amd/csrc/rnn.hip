@@ -893,6 +893,150 @@ static int launch_status(const char* who) {
   return 0;
 }
 
+// ---- the 4-sequence recurrence with the product W_hh h in two fp16 terms (ps_lstm_f16x2_f32, inter-segment pass) --------
+// The step of lstm_m4_kernel is a dependent chain: 64 v_mfma_f32_4x4x1_f32 (512 cycles of issue), the cell, one LDS
+// exchange.  v_mfma_f32_4x4x4_f16 takes four k per issue: with W_hh 2^e = hi + lo once per workgroup and h 2^10 = hi +
+// lo every step (the scheme of lstm_seg_f16x2_kernel, same error class) the chain is 3 x 16 issues, 384 cycles.  Layout
+// as the fp32 kernel: lane (unit, j): A = W_hh[gate j][unit][4 k], B = h[4 k][sequence j], the four result registers
+// the four gates of (unit, sequence j).  h' crosses LDS as halves, [plane][sequence][k], read 16 bytes (8 k) at a time.
+typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void lstm_m4_f16x2_kernel(LstmK k) {
+  constexpr int H = 64, PF = 8;
+  constexpr int LDK = H + 8;  // halves per (plane, sequence) row
+  __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][4][LDK];
+  __shared__ float wmax[4];
+  const ps_lstm_args& a = k.a;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = lane & 3, ub = lane >> 2;
+  const int unit = 16 * w + ub;
+  const int d = blockIdx.z;
+  const int per = gridDim.x >> 3;  // XCD-aware group order, as lstm_m4_kernel
+  const int grp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int b = grp * 4 + j;
+  const bool valid = b < a.N * a.Q;
+  const int bb = valid ? b : a.N * a.Q - 1;  // (sequences past the end replay the last one; nothing of theirs is stored)
+  const int n = bb / a.Q, q = bb % a.Q;
+  const int G = 4 * H;
+
+  // A operand: lane (unit, i = lane & 3) holds W_hh[gate i][unit][k], k-step kk: k = 4 kk .. 4 kk + 3
+  f16x4v whi[H / 4], wlo[H / 4];
+  float inv;
+  {
+    const float* wt = a.whh_t + (size_t)d * H * G + j * H + unit;
+    float wv[H];
+    float m = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < H; ++kk) {
+      wv[kk] = wt[(size_t)kk * G];
+      m = fmaxf(m, fabsf(wv[kk]));
+    }
+    m = wave_max(m);
+    if (lane == 0) wmax[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    int ex = 0;
+    if (m > 0.f) frexpf(m, &ex);
+    ex = ex < -27 ? -27 : ex;
+    const float S = ldexpf(1.f, 13 - ex);
+    inv = 1.f / (S * 1024.f);
+#pragma unroll
+    for (int kk = 0; kk < H / 4; ++kk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ws = wv[4 * kk + e] * S;
+        const _Float16 hi = (_Float16)ws;
+        whi[kk][e] = hi;
+        wlo[kk][e] = (_Float16)(ws - (float)hi);
+      }
+  }
+
+  float c = 0.f, h = 0.f;
+  if (valid && (a.h0 || a.c0)) {
+    const int bs = b - a.state_shift;
+    if (bs >= 0) {
+      const int nn = bs / a.Q, qq = bs % a.Q;
+      const size_t off = ((size_t)(nn * a.D + d) * H + unit) * a.ldq + qq;
+      if (a.h0) h = a.h0[off];
+      if (a.c0) c = a.c0[off];
+    }
+  }
+  auto put_h = [&](int buf) {
+    const float hs = h * 1024.f;
+    const _Float16 hi = (_Float16)hs;
+    hb[buf][0][j][unit] = hi;
+    hb[buf][1][j][unit] = (_Float16)(hs - (float)hi);
+  };
+  put_h(0);
+
+  const float* gp = a.gx + ((size_t)(n * a.D + d) * G + unit) * a.ldt + (size_t)q * a.q_stride;
+  float* hp = a.hout + ((size_t)(n * a.D + d) * H + unit) * a.ldt + (size_t)q * a.q_stride;
+  const int steps = a.steps;
+  const bool rev = d == 1;
+  const size_t gstride = (size_t)H * a.ldt;
+
+  float pre[PF][4];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int uc = u < steps ? u : steps - 1;
+    const int ts = rev ? steps - 1 - uc : uc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[u][g] = gp[g * gstride + (size_t)ts * a.step_stride];
+  }
+  __syncthreads();
+
+  for (int s0 = 0; s0 < steps; s0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int s = s0 + u;
+      if (s < steps) {  // uniform
+        const _Float16* hh = &hb[s & 1][0][j][0];
+        const _Float16* hl = &hb[s & 1][1][j][0];
+        f32x4 acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 p4 = f32x4{pre[u][0], pre[u][1], pre[u][2], pre[u][3]};
+#pragma unroll
+        for (int k8 = 0; k8 < H / 8; ++k8) {
+          const f16x8 vh = *reinterpret_cast<const f16x8*>(hh + 8 * k8);
+          const f16x8 vl = *reinterpret_cast<const f16x8*>(hl + 8 * k8);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int kk = 2 * k8 + e;
+            const f16x4v bh = f16x4v{vh[4 * e], vh[4 * e + 1], vh[4 * e + 2], vh[4 * e + 3]};
+            const f16x4v bl = f16x4v{vl[4 * e], vl[4 * e + 1], vl[4 * e + 2], vl[4 * e + 3]};
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x4f16(whi[kk], bh, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_4x4x4f16(whi[kk], bl, acc[1], 0, 0, 0);
+            acc[2 + (kk & 1)] = __builtin_amdgcn_mfma_f32_4x4x4f16(wlo[kk], bh, acc[2 + (kk & 1)], 0, 0, 0);
+          }
+        }
+        {  // refill the ring slot (step s + PF) and let the previous step's h' leave: in the shadow of the MFMAs
+          const int sn = s + PF < steps ? s + PF : steps - 1;
+          const int ts = rev ? steps - 1 - sn : sn;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) pre[u][g] = gp[g * gstride + (size_t)ts * a.step_stride];
+          if (s > 0 && valid) hp[(size_t)(rev ? steps - s : s - 1) * a.step_stride] = h;
+        }
+        const f32x4 t = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * inv + p4;
+        const float gi = fast_sigmoid(t[0]);
+        const float gf = fast_sigmoid(t[1]);
+        const float gg = fast_tanh(t[2]);
+        const float go = fast_sigmoid(t[3]);
+        c = gf * c + gi * gg;
+        h = go * fast_tanh(c);
+        put_h((s + 1) & 1);
+        __syncthreads();
+      }
+    }
+  }
+  if (valid) {
+    hp[(size_t)(rev ? 0 : steps - 1) * a.step_stride] = h;
+    const size_t off = ((size_t)(n * a.D + d) * H + unit) * a.ldq + q;
+    if (a.h_last) a.h_last[off] = h;
+    if (a.c_last) a.c_last[off] = c;
+  }
+}
+
 }  // namespace ps
 
 using namespace ps;
@@ -970,6 +1114,8 @@ static int lstm_launch(const ps_lstm_args* args, void* stream, bool f16x2) {
       dim3 mgrid((unsigned)(((seqs + 3) / 4 + 7) / 8 * 8), 1, a.D);  // multiple of 8: see the XCD-aware group order
       if (a.H == 64 && contig)
         hipLaunchKernelGGL((lstm_m4_kernel<64, true>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
+      else if (a.H == 64 && f16x2 && !(g_debug_flags & (1 << 20)))
+        hipLaunchKernelGGL(lstm_m4_f16x2_kernel, mgrid, dim3(256), 0, (hipStream_t)stream, k);
       else if (a.H == 64)
         hipLaunchKernelGGL((lstm_m4_kernel<64, false>), mgrid, dim3(256), 0, (hipStream_t)stream, k);
       else if (contig)

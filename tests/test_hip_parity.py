@@ -631,11 +631,45 @@ def test_lstm_whole_segment_kernel(H, dev, bi, wscale):
     assert e02 < tol / 2, e02         # fp16x2 product: fp32-class
 
 
+@pytest.mark.parametrize("bi,wscale,s", [(False, 1.0, 50), (True, 1.0, 13), (False, 1e-3, 9), (False, 1.5, 9)])
+def test_lstm_inter_pass_f16x2_kernel(H, dev, bi, wscale, s):
+    """Inter-segment pass (strided steps, 4 sequences per workgroup): the fp16x2 recurrent product (v_mfma_f32_4x4x4_f16,
+    three products) against the oracle and the fp32 4x4x1 kernel; ragged last workgroup (2 * 5 = 10 sequences), both
+    directions, initial and final states, more steps than the pre-activation ring holds."""
+    from puresound_amd.nnet._plans import lstm_plan
+    hid, n, c, k = 64, 2, 12, 5
+    m, sd = _lstm_sd(c, hid, bi, 180)
+    if wscale != 1.0:
+        sd = {kk: (v * wscale if "weight_hh" in kk else v) for kk, v in sd.items()}
+        m.load_state_dict(sd)
+    x = _rand((n, c, s * k), 181)
+    d = 2 if bi else 1
+    seqs = x.transpose(1, 2).reshape(n, s, k, c).permute(0, 2, 1, 3).reshape(n * k, s, c)
+    h0 = _rand((d, n * k, hid), 182, -0.5, 0.5)
+    c0 = _rand((d, n * k, hid), 183, -0.5, 0.5)
+    ref, (hn, cn) = DP.lstm(seqs, sd, "", bi, (h0, c0))
+    p = lstm_plan(m.to(dev), torch.device(dev))
+    t = s * k
+    gx, _ = H.conv1x1(H.pad_rows(x.to(dev)), t, p["wih"], p["rows"], None, p["bias"])
+    to_state = lambda v: H.pad_rows(v.reshape(d, n, k, hid).permute(1, 0, 3, 2).reshape(n, d * hid, k).to(dev))  # noqa: E731
+    back = lambda v: v[..., :k].cpu().reshape(n, d, hid, k).permute(1, 0, 3, 2).reshape(d, n * k, hid)  # noqa: E731
+    outs = []
+    tol = 2e-5 if s < 20 else 5e-5   # (50 dependent steps)
+    for f16x2 in (False, True):
+        hout, (hl, cl) = H.lstm(gx, p["whh_t"], hid, d, k, 1, s, k, to_state(h0), to_state(c0), want_state=True, f16x2=f16x2)
+        torch.cuda.synchronize()
+        got = hout[..., :t].cpu().transpose(1, 2).reshape(n, s, k, d * hid).permute(0, 2, 1, 3).reshape(n * k, s, -1)
+        e = (rel_max(got.numpy(), ref.numpy()), rel_max(back(hl).numpy(), hn.numpy()), rel_max(back(cl).numpy(), cn.numpy()))
+        assert max(e) < tol, (f16x2, e)
+        outs.append(hout[..., :t].clone())
+    assert rel_max(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < tol / 2
+
+
 def test_lstm_f16x2_entry_is_the_fp32_kernel_off_its_shape(H, dev):
     """ps_lstm_f16x2_f32 documents: the two-term recurrent product only where a kernel for it exists (H = 64, 20 consecutive
-    steps), exactly ps_lstm_f32 elsewhere -- here 8-step segments, a 7-step inter pass and H = 128: bit for bit."""
+    steps, or strided steps), exactly ps_lstm_f32 elsewhere -- here 8-step segments and H = 128 both ways: bit for bit."""
     from puresound_amd.nnet._plans import lstm_plan
-    for hid, k, s, mode in ((64, 8, 9, "intra"), (64, 5, 7, "inter"), (128, 20, 4, "intra")):
+    for hid, k, s, mode in ((64, 8, 9, "intra"), (128, 5, 7, "inter"), (128, 20, 4, "intra")):
         n, c = 2, 12
         m, _ = _lstm_sd(c, hid, False, 170)
         x = _rand((n, c, s * k), 171)
