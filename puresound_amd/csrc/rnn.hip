@@ -952,8 +952,8 @@ __global__ __launch_bounds__(256) void lstm_m4_f16x2_kernel(LstmK k) {
   }
 
   float c = 0.f, h = 0.f;
-  if (valid && (a.h0 || a.c0)) {
-    const int bs = b - a.state_shift;
+  if (a.h0 || a.c0) {  // (replayed sequences take the replayed state: they must store the very same h')
+    const int bs = bb - a.state_shift;
     if (bs >= 0) {
       const int nn = bs / a.Q, qq = bs % a.Q;
       const size_t off = ((size_t)(nn * a.D + d) * H + unit) * a.ldq + qq;
@@ -992,9 +992,10 @@ __global__ __launch_bounds__(256) void lstm_m4_f16x2_kernel(LstmK k) {
       if (s < steps) {  // uniform
         const _Float16* hh = &hb[s & 1][0][j][0];
         const _Float16* hl = &hb[s & 1][1][j][0];
-        f32x4 acc[4];
+        constexpr int NC = 2;  // accumulator chains: 105 us with two, 108 with four, 110 with one, 115 with six
+        f32x4 acc[NC];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < NC; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 p4 = f32x4{pre[u][0], pre[u][1], pre[u][2], pre[u][3]};
 #pragma unroll
         for (int k8 = 0; k8 < H / 8; ++k8) {
@@ -1005,9 +1006,10 @@ __global__ __launch_bounds__(256) void lstm_m4_f16x2_kernel(LstmK k) {
             const int kk = 2 * k8 + e;
             const f16x4v bh = f16x4v{vh[4 * e], vh[4 * e + 1], vh[4 * e + 2], vh[4 * e + 3]};
             const f16x4v bl = f16x4v{vl[4 * e], vl[4 * e + 1], vl[4 * e + 2], vl[4 * e + 3]};
-            acc[0] = __builtin_amdgcn_mfma_f32_4x4x4f16(whi[kk], bh, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_4x4x4f16(whi[kk], bl, acc[1], 0, 0, 0);
-            acc[2 + (kk & 1)] = __builtin_amdgcn_mfma_f32_4x4x4f16(wlo[kk], bh, acc[2 + (kk & 1)], 0, 0, 0);
+            const int c0 = (3 * kk) % NC, c1 = (3 * kk + 1) % NC, c2 = (3 * kk + 2) % NC;
+            acc[c0] = __builtin_amdgcn_mfma_f32_4x4x4f16(whi[kk], bh, acc[c0], 0, 0, 0);
+            acc[c1] = __builtin_amdgcn_mfma_f32_4x4x4f16(whi[kk], bl, acc[c1], 0, 0, 0);
+            acc[c2] = __builtin_amdgcn_mfma_f32_4x4x4f16(wlo[kk], bh, acc[c2], 0, 0, 0);
           }
         }
         {  // refill the ring slot (step s + PF) and let the previous step's h' leave: in the shadow of the MFMAs
@@ -1015,9 +1017,13 @@ __global__ __launch_bounds__(256) void lstm_m4_f16x2_kernel(LstmK k) {
           const int ts = rev ? steps - 1 - sn : sn;
 #pragma unroll
           for (int g = 0; g < 4; ++g) pre[u][g] = gp[g * gstride + (size_t)ts * a.step_stride];
+          // (guarded: made unconditional -- replayed sequences storing the same values -- the kernel took 134 us, not 107)
           if (s > 0 && valid) hp[(size_t)(rev ? steps - s : s - 1) * a.step_stride] = h;
         }
-        const f32x4 t = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * inv + p4;
+        f32x4 sum = acc[0];
+#pragma unroll
+        for (int e = 1; e < NC; ++e) sum += acc[e];
+        const f32x4 t = sum * inv + p4;
         const float gi = fast_sigmoid(t[0]);
         const float gf = fast_sigmoid(t[1]);
         const float gg = fast_tanh(t[2]);
