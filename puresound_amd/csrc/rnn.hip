@@ -734,9 +734,9 @@ __global__ __launch_bounds__(H * 4) void lstm_m4_kernel(LstmK k) {
       const int s = s0 + u;
       if (s < steps) {  // uniform
         const float* hb = hbuf[s & 1] + j * HS;
-        f32x4 acc[4];
+        f32x4 acc[2];
         acc[0] = f32x4{pre[u][0], pre[u][1], pre[u][2], pre[u][3]};
-        acc[1] = acc[2] = acc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifndef PS_M4_ABL
 #define PS_M4_ABL 0
 #endif
@@ -744,8 +744,8 @@ __global__ __launch_bounds__(H * 4) void lstm_m4_kernel(LstmK k) {
         for (int kk = 0; kk < ((PS_M4_ABL & 1) ? 1 : H / 4); ++kk) {
           const f32x4 hv = *reinterpret_cast<const f32x4*>(hb + 4 * kk);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[4 * kk + e], hv[e], acc[e], 0, 0, 0);
+          for (int e = 0; e < 4; ++e)  // two accumulator chains (116 us per inter pass; four: 119, one: 130)
+            acc[e & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[4 * kk + e], hv[e], acc[e & 1], 0, 0, 0);
         }
         if constexpr (!CONTIG) {
           // refill the ring slot with step s + PF -- behind the MFMAs (in front of them the four loads and their
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(H * 4) void lstm_m4_kernel(LstmK k) {
           // ... and the PREVIOUS step's h' leaves here too (same reason; the last one after the loop)
           if (s > 0 && valid) hp[(size_t)(rev ? steps - s : s - 1) * a.step_stride] = h;
         }
-        const f32x4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        const f32x4 t = acc[0] + acc[1];
 #if PS_M4_ABL & 2
         c = t[1] * c + t[0] * t[2];
         h = t[3] * c;
