@@ -75,6 +75,74 @@ __global__ __launch_bounds__(256) void attn_stats_pool_kernel(const float* __res
   }
 }
 
+// Rows of up to 4096 frames (the 4 s utterances of the benchmarks: 3999): the row of logits and the row of x are read
+// ONCE, as four 16-byte loads each per thread, and the three passes above run on registers -- the same sums in the same
+// per-thread order, so the results are those of the kernel above bit for bit.
+__global__ __launch_bounds__(256) void attn_stats_pool_reg_kernel(const float* __restrict__ logits,
+                                                                  const float* __restrict__ x,
+                                                                  const float* __restrict__ lens, float* __restrict__ out,
+                                                                  int C, int T_all, int ldt, float eps) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, n = blockIdx.y;
+  int T = T_all;
+  if (lens) {
+    const float lim = lens[n] * (float)T_all;
+    int lo = 0, hi = T_all;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((float)mid < lim) lo = mid + 1; else hi = mid;
+    }
+    T = lo;
+  }
+  const float* lr = logits + ((size_t)n * C + c) * ldt;
+  const float* xr = x + ((size_t)n * C + c) * ldt;
+  // element (i, e) of this thread: frame t = 1024 i + 4 threadIdx.x + e  (the looping kernel walks t = threadIdx.x + 256 k:
+  // other frames per thread, but every block-wide sum is the same set of terms; fp32 sums differ in the last bits only)
+  f32x4 lv[4], xv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t0 = 1024 * i + 4 * threadIdx.x;
+    const bool in = t0 < ldt;  // (rows are padded to a multiple of 4 frames: a 16-byte piece is inside or outside)
+    lv[i] = in ? *reinterpret_cast<const f32x4*>(lr + t0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    xv[i] = in ? *reinterpret_cast<const f32x4*>(xr + t0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (1024 * i + 4 * (int)threadIdx.x + e < T) m = fmaxf(m, lv[i][e]);
+  m = block_max(m, red);
+  float s = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool on = 1024 * i + 4 * (int)threadIdx.x + e < T;
+      const float w = on ? expf(lv[i][e] - m) : 0.f;
+      lv[i][e] = w;  // (the weight replaces the logit: the third pass needs only it)
+      s += w;
+      s1 += on ? w * xv[i][e] : 0.f;
+    }
+  s = block_sum(s, red);
+  s1 = block_sum(s1, red);
+  const float mean = s1 / s;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool on = 1024 * i + 4 * (int)threadIdx.x + e < T;
+      const float d = xv[i][e] - mean;
+      s2 += on ? lv[i][e] * d * d : 0.f;
+    }
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    out[(size_t)n * 2 * C + c] = mean;
+    out[(size_t)n * 2 * C + C + c] = sqrtf((s2 / s) < eps ? eps : (s2 / s));
+  }
+}
+
 // The attention map itself (forward(..., return_weight=True), lobe/pooling.py:109-113): softmax over the valid frames of
 // each (utterance, channel) row, 0 on masked frames; the frames beyond T_all of the padded output row are cleared.
 __global__ __launch_bounds__(256) void attn_weights_kernel(const float* __restrict__ logits,
@@ -135,8 +203,13 @@ extern "C" int ps_attn_stats_pool_len_f32(const float* logits, const float* x, c
   }
   {
     LaunchTimer timer("attn_stats_pool", (hipStream_t)stream);
-    hipLaunchKernelGGL(attn_stats_pool_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, logits, x, lengths, out,
-                       C, T, ldt, eps);
+    // rows that fit 16 values per thread: one pass over memory (ps_debug_flags bit 0 keeps the three-pass kernel: tests)
+    if (T <= 4096 && ldt % 4 == 0 && !(((uintptr_t)logits | (uintptr_t)x) & 15) && !(g_debug_flags & 1))
+      hipLaunchKernelGGL(attn_stats_pool_reg_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, logits, x, lengths,
+                         out, C, T, ldt, eps);
+    else
+      hipLaunchKernelGGL(attn_stats_pool_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, logits, x, lengths, out,
+                         C, T, ldt, eps);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -296,17 +296,25 @@ def test_wrapper_inference_matches_reference_golden(PA, dev, golden_dir, name):
 # ------------------------------------------------------------------------------------------------
 # speaker branch (BASELINE config 3): TCN x5 -> attentive statistics pooling -> 1x1 projection -> dvec
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,c,t", [(2, 24, 77), (3, 512, 249), (1, 40, 1500)])
+@pytest.mark.parametrize("n,c,t", [(2, 24, 77), (3, 512, 249), (1, 40, 1500), (2, 16, 3999), (1, 8, 4096), (1, 8, 5000)])
 def test_attn_stats_pool_kernel(H, dev, n, c, t):
+    """rows of <= 4096 frames: the one-pass kernel (rows in registers); debug bit 0 / longer rows: the three-pass kernel."""
+    from puresound_amd import _abi
     logits = _rand((n, c, t), 31, -3.0, 3.0)
     x = _rand((n, c, t), 32)
     a = torch.softmax(logits.double(), 2)
     mean = (a * x.double()).sum(2)
     std = torch.sqrt((a * (x.double() - mean.unsqueeze(2)) ** 2).sum(2).clamp(1e-12))
     ref = torch.cat((mean, std), 1).float().numpy()
-    out = H.attn_stats_pool(H.pad_rows(logits.to(dev)), H.pad_rows(x.to(dev)), t)
-    assert out.shape == (n, 2 * c)
-    assert rel_max(out.cpu().numpy(), ref) < 2e-5
+    for flags in (0, 1):
+        old = _abi.lib().ps_debug_flags(flags)
+        try:
+            out = H.attn_stats_pool(H.pad_rows(logits.to(dev)), H.pad_rows(x.to(dev)), t)
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
+        assert out.shape == (n, 2 * c)
+        assert rel_max(out.cpu().numpy(), ref) < 2e-5, flags
 
 
 @pytest.mark.parametrize("n,k,m,t", [(2, 24, 12, 77), (2, 128, 512, 249)])
