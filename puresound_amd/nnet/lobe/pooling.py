@@ -19,6 +19,10 @@ def _pool_shape(ctor, x, aux, params):
 
 @op_module("attn_stats_pool_fwd", _pool_shape, method="_pool")
 class AttentiveStatisticsPooling(nn.Module):
+    # arithmetic of the two 1x1 convs: "fp16x2" (two fp16 terms per operand, three MFMA products, fp32 accumulation -- the
+    # TCN blocks' default; the first conv measures its input's range, the second one's input is a tanh) or "fp32"
+    gemm_precision = "fp16x2"
+
     def __init__(self, channels, attention_channels=128):
         super().__init__()
         self.eps = 1e-12
@@ -37,7 +41,7 @@ class AttentiveStatisticsPooling(nn.Module):
 
     def _get_plan(self, device):
         sig = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers())) + \
-            (self.training, str(device))
+            (self.training, str(device), self.gemm_precision)
         if self._plan is None or self._plan["sig"] != sig:
             bn = self.tdnn[2]
             if bn.training:
@@ -50,18 +54,27 @@ class AttentiveStatisticsPooling(nn.Module):
                               b1=self.tdnn[0].bias.detach().to(**f32).contiguous(),
                               w2=hip.pack_wt(self.conv.weight.detach().to(**f32)),
                               b2=self.conv.bias.detach().to(**f32).contiguous(), scale=scale, shift=shift)
+            if self.gemm_precision == "fp16x2" and min(self.channels, self.attention_channels) >= 64:
+                self._plan["w1_f16x2"] = hip.pack_wt_f16x2(self.tdnn[0].weight.detach().to(**f32))
+                self._plan["w2_f16x2"] = hip.pack_wt_f16x2(self.conv.weight.detach().to(**f32))
         return self._plan
 
     def forward_padded(self, x_pad: torch.Tensor, t: int, lengths=None, return_weight: bool = False) -> torch.Tensor:
         """padded [N,C,ldt] (+ relative lengths [N]) -> [N,2C] (mean ; std), or the padded attention map [N,C,ldt]."""
         p = self._get_plan(x_pad.device)
         n, _, ldt = x_pad.shape
-        h, _ = hip.conv1x1(x_pad, t, p["w1"], self.attention_channels, None, p["b1"],
-                           out=torch.empty(n, self.attention_channels, ldt, device=x_pad.device))
         pro = hip.make_prologue(PS_NORM_AFFINE, False, None, 0.0, 0.0, p["scale"], p["shift"], None,
                                 pre_relu=True, post_tanh=True)
-        logits, _ = hip.conv1x1(h, t, p["w2"], self.channels, pro, p["b2"],
-                                out=torch.empty(n, self.channels, ldt, device=x_pad.device))
+        h = torch.empty(n, self.attention_channels, ldt, device=x_pad.device)
+        logits = torch.empty(n, self.channels, ldt, device=x_pad.device)
+        if "w1_f16x2" in p:
+            (w1, e1), (w2, e2) = p["w1_f16x2"], p["w2_f16x2"]
+            hip.conv1x1_f16x2(x_pad, t, w1, e1, self.attention_channels, None, p["b1"], out=h,
+                              x_amax=hip.absmax(x_pad, t))
+            hip.conv1x1_f16x2(h, t, w2, e2, self.channels, pro, p["b2"], out=logits, x_bound=1.0)  # |tanh| <= 1
+        else:
+            hip.conv1x1(x_pad, t, p["w1"], self.attention_channels, None, p["b1"], out=h)
+            hip.conv1x1(h, t, p["w2"], self.channels, pro, p["b2"], out=logits)
         if return_weight:
             return hip.attn_weights(logits, t, lengths)
         return hip.attn_stats_pool(logits, x_pad, t, self.eps, lengths)
