@@ -333,7 +333,8 @@ int ps_lstm_f32(const ps_lstm_args* args, void* stream);
  * operand, three MFMA products, fp32 accumulation on top of the fp32 pre-activations; error <= 2^-21 of sum |W||h| per
  * gate and step) where a kernel for it exists -- H = 64 with 20 consecutive 16-byte-aligned steps per sequence (the
  * intra-segment pass of DPRNN(seg_size=20), dprnn.py:154-160) or with strided steps and fewer than 4096 sequences (its
- * inter-segment pass, dprnn.py:162-171) -- and exactly ps_lstm_f32 for every other shape. */
+ * inter-segment pass, dprnn.py:162-171) -- and exactly ps_lstm_f32 for every other shape.  h0 is taken as an LSTM
+ * output (|h0| <= 1; the two-term form holds up to |h0| < 32). */
 int ps_lstm_f16x2_f32(const ps_lstm_args* args, void* stream);
 
 /* 50 % overlapped segmentation of the dual-path maskers (SplitMerge.split / merge, lobe/trivial.py:178-241; SkiM.split /
