@@ -57,6 +57,8 @@ class PlanCache:
         state = dict(self.__dict__)
         state["_plan"] = None
         state["_plan_sig"] = None
+        if "_last_amax" in state:   # (DPRNN: a device tensor handed from the block stack to the output conv within one call)
+            state["_last_amax"] = None
         return state
 
     def _plan_get(self, device, builder):
