@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="multi-GPU: uneven shards (rank r owns 32 - r utterances) through "
                          "puresound_amd.batch_shard.sharded_inference's ragged gather instead of equal shards")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="multi-GPU: issue each step's all-gather synchronously (the next step waits for it) instead of "
+                         "overlapping it with the next step's kernels")
     ap.add_argument("--gemm", default="fp16x2", choices=["fp32", "bf16x3", "fp16x2", "bf16"],
                     help="arithmetic of the 1x1-conv GEMMs; tensors and accumulation are fp32 in every case.  fp16x2 "
                          "(default): every fp32 operand as two fp16 terms, three products on the fp16 MFMA pipe, "
@@ -163,7 +166,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from puresound_amd import _abi
-    from puresound_amd.batch_shard import gather_utterances, sharded_inference
+    from puresound_amd.batch_shard import OverlappedGather, gather_utterances, sharded_inference
     lib = _abi.lib()  # no HIP extension, no benchmark
     model = build_model(dev)
     model.masker.set_gemm_precision(args.gemm)
@@ -184,15 +187,23 @@ def main():
         g = torch.Generator().manual_seed(1234 + rank)
         noisy = ((torch.rand(B_PER_GPU, L, generator=g) * 2 - 1) * 0.5).to(dev)  # synthetic 16 kHz waveforms
 
+    # equal shards, N > 1: the all-gather of step i is issued asynchronously and runs (on RCCL's stream) under the
+    # kernels of step i+1; fence() waits for every outstanding one, so all K gathers complete inside the timed region
+    overlap = OverlappedGather(total_b) if (world > 1 and not ragged and not args.sync_gather) else None
+
     def step():
         if ragged:
             return sharded_inference(model.inference, full)
         out = model.inference(noisy)
+        if overlap is not None:
+            return overlap.submit(out)   # (the previous step's gathered batch)
         if world > 1:
             out = gather_utterances(out, total_b)
         return out
 
     def fence():
+        if overlap is not None:
+            overlap.flush()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -237,7 +248,11 @@ def main():
         # what the collective layer actually saw (the driver's scaling run checks it against --gpus)
         "distributed": {"world_size": dist.get_world_size() if world > 1 else 1,
                         "backend": dist.get_backend() if world > 1 else None,
-                        "collective": "all_gather_into_tensor of [B/N, L] fp32 inside the timed step" if world > 1 else None,
+                        "collective": (None if world == 1 else
+                                       "all_gather_into_tensor of [B/N, L] fp32 per step, asynchronous and double-buffered: "
+                                       "step i's gather runs under step i+1's kernels; all complete inside the timed region"
+                                       if overlap is not None else
+                                       "all_gather_into_tensor of [B/N, L] fp32 inside the timed step"),
                         "ms_per_step_by_rank": rank_ms},
     }
 

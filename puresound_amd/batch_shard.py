@@ -48,3 +48,56 @@ def sharded_inference(infer: Callable[[torch.Tensor], torch.Tensor], noisy: torc
     rank = dist.get_rank(group)
     lo, hi = shard_bounds(noisy.shape[0], world, rank)
     return gather_utterances(infer(noisy[lo:hi]), noisy.shape[0], group)
+
+
+class OverlappedGather:
+    """gather_utterances for a STREAM of steps with equal shards: the all-gather of step i is issued asynchronously (RCCL
+    runs it on its own stream, behind the kernels of step i) and is only waited for after step i+1's kernels have been
+    queued, so the collective runs under the next step's compute instead of between two steps.  Two result buffers
+    alternate; a buffer is reused only after the gather that filled it two steps ago has been waited for.
+
+        og = OverlappedGather(batch)
+        for x in stream:
+            prev = og.submit(infer(x))   # full [batch, L] of the PREVIOUS step (None on the first call)
+        last = og.flush()                # the final step's result; every collective has completed
+    """
+
+    def __init__(self, batch: int, group=None):
+        self.batch, self.group = batch, group
+        self.world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        counts = [hi - lo for lo, hi in (shard_bounds(batch, self.world, r) for r in range(self.world))]
+        if min(counts) != max(counts):
+            raise ValueError("OverlappedGather needs equal shards (use gather_utterances for ragged batches)")
+        self.rows = counts[rank]
+        self._buf = [None, None]
+        self._work = [None, None]
+        self._n = 0
+
+    def submit(self, local: torch.Tensor):
+        if local.shape[0] != self.rows:
+            raise ValueError(f"expected a shard of {self.rows} utterances, got {local.shape[0]}")
+        i = self._n & 1
+        if self._work[i] is not None:      # the gather that filled this buffer two steps ago
+            self._work[i].wait()
+            self._work[i] = None
+        shape = (self.batch,) + tuple(local.shape[1:])
+        if self._buf[i] is None or self._buf[i].shape != shape or self._buf[i].dtype != local.dtype:
+            self._buf[i] = torch.empty(shape, dtype=local.dtype, device=local.device)
+        self._work[i] = dist.all_gather_into_tensor(self._buf[i], local.contiguous(), group=self.group, async_op=True)
+        self._n += 1
+        j = i ^ 1
+        if self._n < 2:
+            return None
+        if self._work[j] is not None:      # the previous step's gather: it ran under this step's compute
+            self._work[j].wait()
+            self._work[j] = None
+        return self._buf[j]
+
+    def flush(self):
+        """Wait for every outstanding gather; returns the last submitted step's result (None if nothing was submitted)."""
+        for k in (0, 1):
+            if self._work[k] is not None:
+                self._work[k].wait()
+                self._work[k] = None
+        return None if self._n == 0 else self._buf[(self._n - 1) & 1]

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 import cases
 from detweights import det_state_dict, det_wave
 from oracle import separator_oracle as O
-from puresound_amd.batch_shard import gather_utterances, shard_bounds, sharded_inference
+from puresound_amd.batch_shard import OverlappedGather, gather_utterances, shard_bounds, sharded_inference
 import puresound_amd.nnet as PA
 
 
@@ -86,3 +86,41 @@ def test_config4_dprnn_sharded_two_ranks_gloo(batch):
     for r in range(world):
         same_as_unsharded, deterministic, shape = results[r]
         assert same_as_unsharded and deterministic and shape[0] == batch
+
+
+def _overlap_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batch, width, steps = 6, 50, 5
+        og = OverlappedGather(batch)
+        lo, hi = shard_bounds(batch, world, rank)
+        fulls = [torch.arange(batch * width, dtype=torch.float32).reshape(batch, width) * (s + 1) + s for s in range(steps)]
+        ok = True
+        for s in range(steps):
+            prev = og.submit(fulls[s][lo:hi].clone())
+            ok = ok and ((prev is None) if s == 0 else bool(torch.equal(prev, fulls[s - 1])))
+        last = og.flush()
+        ok = ok and bool(torch.equal(last, fulls[-1])) and og.flush() is last
+        try:
+            OverlappedGather(batch + 1)
+            ragged_refused = False
+        except ValueError:
+            ragged_refused = True
+        results[rank] = (ok, ragged_refused)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gather_two_ranks_gloo():
+    """The asynchronous, double-buffered all-gather bench.py --gpus N uses: step i's result is handed out at step i+1,
+    buffers alternate, flush() completes everything; ragged batches are refused (they take gather_utterances)."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, port, results), nprocs=world, join=True)
+    assert len(results) == world
+    for r in range(world):
+        assert results[r] == (True, True)
