@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void free_encode_mfma_kernel(const float* __re
                                                                int relu) {
   __shared__ float xs[34 * 17];
   __shared__ float ws[128 * 33];  // the workgroup's 128 filter rows, row stride 33 floats (conflict-free fragment reads)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the store resource depends on it)
   const int lr = lane & 31, lh = lane >> 5;
   const int n = blockIdx.z;
   const int c_base = (blockIdx.y * 4 + wave) * 32;
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256) void free_encode_mfma_kernel(const float* __re
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[kp], b, acc, 0, 0, 0);
     }
     const int t = t0 + lr;
+#ifdef PS_ENC_FLAT_STORES
     if (t < T) {
       float* o = feats + ((size_t)n * C + c_base + 4 * lh) * ldt + t;
 #pragma unroll
@@ -224,6 +226,19 @@ __global__ __launch_bounds__(256) void free_encode_mfma_kernel(const float* __re
         o[(size_t)((r & 3) + 8 * (r >> 2)) * ldt] = v;
       }
     }
+#else
+    {  // buffer stores: the wave's 32-channel block as the resource, the row as a scalar offset, frames past T out of range
+      const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+          feats + ((size_t)n * C + c_base) * ldt, 0, 32 * ldt * 4, 0x00020000);
+      const unsigned vo = t < T ? (unsigned)(4 * lh * ldt + t) * 4u : 0x7ffffff0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[r];
+        if (relu) v = relu_keep_nan(v);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, vo, ((r & 3) + 8 * (r >> 2)) * ldt * 4, 0);
+      }
+    }
+#endif
   }
 }
 
