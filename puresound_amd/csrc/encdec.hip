@@ -258,15 +258,23 @@ __global__ __launch_bounds__(256) void free_decode_mfma_kernel(const float* __re
                                                                int mask_mode, const float* __restrict__ w,
                                                                float* __restrict__ out, float* __restrict__ tails, int C,
                                                                int T, int ldt, int ntiles, int out_mode) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int n = blockIdx.y, tile = blockIdx.x * 4 + wave;
   if (tile >= ntiles) return;
   const int t = tile * 32 + lr;
   const bool live = t < T;
   const int Lout = (T - 1) * 16 + 32;
-  const float* f = feats + (size_t)n * C * ldt + (live ? t : 0);
-  const float* m = mask ? mask + (size_t)n * C * ldt + (live ? t : 0) : nullptr;
+  // feature / mask rows through buffer loads: the utterance as the resource, the channel pair as a scalar offset, one lane
+  // offset (frames past T out of range: they read 0); C is a multiple of 2 DM_UC (launcher), so no channel masks
+  const int slab = C * ldt * 4;
+  const __amdgpu_buffer_rsrc_t fr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feats) + (size_t)n * C * ldt, 0, slab, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(mask ? mask : feats) + (size_t)n * C * ldt, 0, mask ? slab : 0, 0x00020000);
+  const unsigned vo = live ? (unsigned)(lh * ldt + t) * 4u : 0x7ffffff0u;
+  const float* wl = w + lh * 32 + lr;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -274,15 +282,14 @@ __global__ __launch_bounds__(256) void free_decode_mfma_kernel(const float* __re
     float e[DM_UC], mv[DM_UC], wv[DM_UC];
 #pragma unroll
     for (int u = 0; u < DM_UC; ++u) {
-      const int c = c0 + 2 * u + lh;
-      const bool in = c < C;
-      e[u] = (in && live) ? f[(size_t)c * ldt] : 0.f;
-      mv[u] = (m && in && live) ? m[(size_t)c * ldt] : 1.f;
-      wv[u] = in ? w[(size_t)c * 32 + lr] : 0.f;
+      const int so = (c0 + 2 * u) * ldt * 4;
+      e[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fr, vo, so, 0));
+      if (mask) mv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mr, vo, so, 0));
+      wv[u] = wl[(c0 + 2 * u) * 32];
     }
 #pragma unroll
     for (int u = 0; u < DM_UC; ++u) {
-      const float ev = m ? e[u] * mask_act(mv[u], mask_mode) : e[u];
+      const float ev = mask ? e[u] * mask_act(mv[u], mask_mode) : e[u];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u], ev, acc, 0, 0, 0);
     }
   }
@@ -603,7 +610,7 @@ extern "C" int ps_free_decode_ws_f32(const float* feats, const float* mask, int 
   // the matrix-pipe kernel: the benchmark's filterbank on long rows, with the side buffer it needs (ps_debug_flags
   // bit 0 keeps the VALU kernel; so does a missing or short workspace)
   if (need == 0 || !workspace || workspace_bytes < need || T < 64 || N > 65535 || ((uintptr_t)out & 15) ||
-      ((uintptr_t)workspace & 15) || (g_debug_flags & 1))
+      ((uintptr_t)workspace & 15) || C % (2 * ps::DM_UC) || (long long)C * ldt * 4 >= (1ll << 31) || (g_debug_flags & 1))
     return ps_free_decode_f32(feats, mask, mask_act, w, out, N, C, T, ldt, win, hop, out_mode, stream);
   if (!feats || !w || !out || C <= 0 || ldt < T) {
     set_error("ps_free_decode_ws_f32: bad argument (N=%d C=%d T=%d)", N, C, T);
