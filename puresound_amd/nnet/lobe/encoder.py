@@ -53,7 +53,7 @@ class FreeEncDec(nn.Module):
         return hip.free_encode(x, self.encoder.weight.detach(), self.hop_length, self.output_active, min_frames)
 
     def feature_bound(self, x: torch.Tensor) -> torch.Tensor:
-        """[N,L] -> [N,parts]: partial upper bounds (their maximum bounds |forward(x)[n]|): max |x[n]| times the largest row sum of |w| (the ReLU only
+        """[N,L] -> [N,1]: an upper bound on |forward(x)[n]|: max |x[n]| times the largest row sum of |w| (the ReLU only
         shrinks).  Consumers that scale their input into a narrow exponent range (the fp16x2 GEMMs) take it instead of
         measuring the features.  (The row sum is read back to the host once per weight version.)"""
         w = self.encoder.weight
@@ -61,12 +61,7 @@ class FreeEncDec(nn.Module):
         if getattr(self, "_l1_key", None) != key:
             self._l1 = float(w.detach().abs().sum(dim=(1, 2)).max())
             self._l1_key = key
-        x = x.detach()
-        if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] % 128 == 0 and x.data_ptr() % 16 == 0:
-            # the library's own reduction ([N, parts] partial maxima: what the consumers take) instead of torch's (26 us at
-            # 32 x 64000, one of the few ATen launches of a step)
-            return hip.absmax(x.view(x.shape[0], 1, x.shape[1]), x.shape[1]) * self._l1
-        return torch.linalg.vector_norm(x.float(), ord=float("inf"), dim=1, keepdim=True) * self._l1
+        return torch.linalg.vector_norm(x.detach().float(), ord=float("inf"), dim=1, keepdim=True) * self._l1
 
     def decode_padded(self, feats_pad: torch.Tensor, t: int, mask_pad: Optional[torch.Tensor] = None,
                       mask_act: str = "linear", out_mode: str = "none",
