@@ -46,6 +46,25 @@ class MemLSTM(PlanCache, nn.Module):
                     c=(lstm_plan(self.c_net, device, self.gemm_precision), linear_plan(self.c_proj, device),
                        layernorm_plan(self.c_norm, device)))
 
+    def step_plans(self, device) -> dict:
+        """Streaming update (one LSTM step per stream, states carried): for each of the two nets, [W_ih | W_hh] as ONE weight
+        over K = [x; h] with rows reordered unit-major (4u + g) for ps_lstm_gates_cell_f32, plus its projection and norm
+        plans.  Unidirectional nets only (the causal SkiM)."""
+        p = self._plan_get(device, self._build)
+        if "units" not in p:
+            units = {}
+            for key, net in (("h", self.h_net), ("c", self.c_net)):
+                if net.bidirectional:
+                    raise NotImplementedError("merged-gate streaming update: causal MemLSTM only")
+                w = torch.cat([_f32(net.weight_ih_l0, device), _f32(net.weight_hh_l0, device)], dim=1)
+                hid = net.hidden_size
+                order = (torch.arange(4, device=device).reshape(1, 4) * hid + torch.arange(hid, device=device).reshape(hid, 1)
+                         ).reshape(-1)
+                units[key] = dict(w_units=hip.pack_wt(w[order].contiguous()), bias_units=p[key][0]["bias"][order].contiguous(),
+                                  proj=p[key][1], norm=p[key][2], H=hid, I=net.input_size)
+            p["units"] = units
+        return p["units"]
+
     def forward_state(self, h: torch.Tensor, c: torch.Tensor, s: int, h_states=None, c_states=None,
                       want_states: bool = False, per_frame_sequences: bool = False):
         """h, c: state layout [N, D*H, ldS] with S frames.  Offline: every utterance is one sequence over its S

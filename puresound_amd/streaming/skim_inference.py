@@ -116,8 +116,18 @@ class StreamingSkiM(SkiM):
             self._seg_h = [z(rows) for _ in range(self.n_blocks)]
         self._seg_c = [z(rows) for _ in range(self.n_blocks)]
         self._h_new = [z(rows) for _ in range(self.n_blocks)]
-        self._mem_h = [(z(rows), z(rows)) for _ in range(self.n_blocks - 1)]
-        self._mem_c = [(z(rows), z(rows)) for _ in range(self.n_blocks - 1)]
+        if self.causal:
+            # each Mem-LSTM net keeps [x; h] in one row block too (x = the segment state it reads, h = its own LSTM state,
+            # the lower part): its one-step update is the fused gates + cell kernel of the frame step, not an input GEMM and
+            # a generic recurrence launch (64 us each at H = 256)
+            self._mem_xh = [{k: z(2 * rows) for k in ("h", "c")} for _ in range(self.n_blocks - 1)]
+            self._mem_h = [(xh["h"][:, rows:, :], z(rows)) for xh in self._mem_xh]
+            self._mem_c = [(xh["c"][:, rows:, :], z(rows)) for xh in self._mem_xh]
+            self._mem_hnew = z(rows)
+        else:
+            self._mem_xh = None
+            self._mem_h = [(z(rows), z(rows)) for _ in range(self.n_blocks - 1)]
+            self._mem_c = [(z(rows), z(rows)) for _ in range(self.n_blocks - 1)]
         self._x_in = z(self.input_size)
         self._embed_key = None
         self._embed_static = None
@@ -363,6 +373,23 @@ class StreamingSkiM(SkiM):
     def update_mem_lstm(self):
         """skim_inference.py:220-252: block i's segment-end state -> MemLSTM i -> block i+1's initial state."""
         b = self.streams
+        if self._mem_xh is not None and self.hidden_size == self.mem_lstm[0].h_net.input_size:
+            # Blocks from the last to the first: Mem-LSTM i reads segment state i and writes segment state i+1, which Mem-LSTM
+            # i+1 has read by then -- the reference's "compute all, then assign" without temporaries.  Per net: x rows <- the
+            # segment state, gates + cell in one launch (cell state in place), projection + LayerNorm + residual straight into
+            # the next block's state, h' handed back into the [x; h] block by the same launch.
+            hid = self.hidden_size
+            for i in range(self.n_blocks - 2, -1, -1):
+                plans = self.mem_lstm[i].step_plans(self._seg_c[i].device)
+                for key, src, dst, cell in (("h", self._seg_h[i], self._seg_h[i + 1], self._mem_h[i][1]),
+                                            ("c", self._seg_c[i], self._seg_c[i + 1], self._mem_c[i][1])):
+                    u, xh = plans[key], self._mem_xh[i][key]
+                    xh[:, :hid, :].copy_(src)
+                    hip.lstm_gates_cell(xh, b, u["w_units"], u["bias_units"], cell, self._mem_hnew, hid)
+                    pr, nm = u["proj"], u["norm"]
+                    hip.proj_layernorm(self._mem_hnew, b, pr["wt"], pr["bias"], pr["M"], nm["gamma"], nm["beta"], nm["eps"],
+                                       xh[:, :hid, :], x_copy=xh[:, hid:, :], out=dst)
+            return
         new = []
         for i in range(self.n_blocks - 1):
             new.append(self.mem_lstm[i].forward_state(self._seg_h[i], self._seg_c[i], b, self._mem_h[i],
