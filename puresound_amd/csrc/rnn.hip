@@ -324,7 +324,7 @@ __global__ __launch_bounds__(H * 4) void lstm_mfma_kernel(LstmK k) {
 // The 16-sequence kernel above fetches the gate pre-activations in 16-byte groups of 4 steps, one group ahead: with
 // q_stride = K frames (K = 20: 80 bytes) each 128-byte line of a gate row holds 1.6 whole sequences and is visited
 // by all five groups, ~6 us apart; 64 resident workgroups per XCD keep 21 MB of such lines in flight against a 4 MB
-// L2, so every visit misses: 645 MB fetched for 131 MB of pre-activations (profiles/r03_pmc_cfg4_traffic.txt) and the
+// L2, so every visit misses: 645 MB fetched for 131 MB of pre-activations (profiles/r03_pmc_cfg4_traffic_group_kernel.txt) and the
 // pass runs at the fabric's rate, not the recurrence's.  Here a workgroup fetches ALL the steps of its 16 sequences
 // before the first one (the five groups of a line leave back to back and merge in the vector L1 / L2), keeps them
 // in registers -- STEPS x 16 values per lane, the reason for one wave per SIMD (__launch_bounds__(256, 1): 512
