@@ -1434,6 +1434,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_bf16_solo_kernel(BfArgs a) {
 
 #include "conv1x1_bf16_il.inc"
 #include "conv1x1_f16x2_w1.inc"
+#include "conv1x1_f16x2_rb.inc"
 
 static int bf16_cus() { return device_cus(); }
 
@@ -1514,6 +1515,23 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
         else PS_W1(false, false, false);
       }
 #undef PS_W1
+      return;
+    }
+    // fp16x2 on fp32 rows: the register-B kernel (conv1x1_f16x2_rb.inc) -- activations go from HBM to the MFMA operand
+    // registers without touching LDS.  ps_debug_flags bit 22 selects it (round 4, while it is being measured).
+    if constexpr (PLANES == 2 && !XB && !YB) if (g_debug_flags & (1 << 22)) {
+#define PS_RB(TRV, STV, RSV) \
+  hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)
+      if (tr) {
+        if (stats) PS_RB(true, true, false);
+        else if (res) PS_RB(true, false, true);
+        else PS_RB(true, false, false);
+      } else {
+        if (stats) PS_RB(false, true, false);
+        else if (res) PS_RB(false, false, true);
+        else PS_RB(false, false, false);
+      }
+#undef PS_RB
       return;
     }
 #define PS_IL(TRV, STV, RSV) \
