@@ -43,6 +43,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 
 // operand element type and MFMA of an arithmetic (PLANES = 1 / 3: bf16 terms, PLANES = 2: fp16 terms)
 template <int PLANES>
@@ -1519,7 +1520,7 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
     }
     // fp16x2 on fp32 rows: the register-B kernel (conv1x1_f16x2_rb.inc) -- activations go from HBM to the MFMA operand
     // registers without touching LDS.  ps_debug_flags bit 22 selects it (round 4, while it is being measured).
-    if constexpr (PLANES == 2 && !XB && !YB) if (g_debug_flags & (1 << 22)) {
+    if constexpr (PLANES == 2 && !XB && !YB) if ((g_debug_flags & (1 << 22)) && a.ksteps % 2 == 0) {
 #define PS_RB(TRV, STV, RSV) \
   hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)
       if (tr) {
