@@ -1518,22 +1518,44 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
 #undef PS_W1
       return;
     }
-    // fp16x2 on fp32 rows: the register-B kernel (conv1x1_f16x2_rb.inc) -- activations go from HBM to the MFMA operand
-    // registers without touching LDS.  ps_debug_flags bit 22 selects it (round 4, while it is being measured).
-    if constexpr (PLANES == 2 && !XB && !YB) if ((g_debug_flags & (1 << 22)) && a.ksteps % 2 == 0) {
+    // fp16x2 on fp32 rows, K a multiple of 32, M a multiple of 256: the register-B kernel (conv1x1_f16x2_rb.inc) --
+    // activations go from HBM to the MFMA operand registers without touching LDS, v_mfma_f32_16x16x32_f16, two workgroups
+    // per CU.  Same-box comparison in the benchmark's step (profiles/r04_gemm_kernels_same_box.txt), out / in / pointwise:
+    // 176.0 / 108.0 / 70.7 us against 179.0 / 111.7 / 76.6 for the interleaved kernel.  ps_debug_flags bit 22 keeps the
+    // interleaved kernel (tests run both).
+    if constexpr (PLANES == 2 && !XB && !YB) if (!(g_debug_flags & ((1 << 22) | 128)) && a.K % 32 == 0 && a.M % 256 == 0) {
+      // two 256-thread workgroups per CU, each on tiles of 256 x 128 (the m-tiles of a frame tile back to back)
+      const long long ntiles = (long long)a.tiles_t * a.tiles_m * N;
+      const int Gr = (int)(ntiles < 2 * cus ? ntiles : 2 * cus);
+      const long long pw = (ntiles + Gr - 1) / Gr, pu = (long long)a.tiles_t * a.tiles_m;
+      if ((pw + pu - 2) / pu + 1 <= PP_MAXU) {
+        BfArgs& b = const_cast<BfArgs&>(a);
+        b.groups = Gr / 2;                  // workgroups from here on start late ...
+#ifndef RB_DELAY_RES
+#define RB_DELAY_RES 0
+#endif
+#ifndef RB_DELAY_ST
+#define RB_DELAY_ST 0
+#endif
+        b.delay = (a.ksteps / 2) * (res ? RB_DELAY_RES : RB_DELAY_ST);  // ... by about half a K loop (cycles per K-step)
+        b.pair_r = 0;
+#ifdef PS_TUNE
+        if (const char* v = getenv("PS_RB_DELAY")) b.delay = atoi(v) * (a.ksteps / 2);
+#endif
 #define PS_RB(TRV, STV, RSV) \
-  hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<TRV, STV, RSV>), dim3(G, 1), dim3(512), 0, stream, a)
-      if (tr) {
-        if (stats) PS_RB(true, true, false);
-        else if (res) PS_RB(true, false, true);
-        else PS_RB(true, false, false);
-      } else {
-        if (stats) PS_RB(false, true, false);
-        else if (res) PS_RB(false, false, true);
-        else PS_RB(false, false, false);
-      }
+  hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<TRV, STV, RSV>), dim3(Gr, 1), dim3(256), 0, stream, a)
+        if (tr) {
+          if (stats) PS_RB(true, true, false);
+          else if (res) PS_RB(true, false, true);
+          else PS_RB(true, false, false);
+        } else {
+          if (stats) PS_RB(false, true, false);
+          else if (res) PS_RB(false, false, true);
+          else PS_RB(false, false, false);
+        }
 #undef PS_RB
-      return;
+        return;
+      }
     }
 #define PS_IL(TRV, STV, RSV) \
   hipLaunchKernelGGL((conv1x1_bf16_il_kernel<PLANES, TRV, STV, RSV, XB, (YB && !RSV)>), dim3(G, 1), dim3(512), 0, stream, a)

@@ -103,7 +103,8 @@ def test_fp16x2_gemm_is_as_close_to_fp64_as_the_fp32_kernel(dev, n, k, m, t, mod
     # kernel (256 x 32 tiles for small grids), bits 27 | 29 = its 256 x 128 tile
     # bit 7 = the one-wave-per-SIMD persistent kernel (conv1x1_f16x2_w1.inc) instead of the interleaved one, bit 28 = a
     # persistent kernel at any launch size (where the shape allows one)
-    for flags in (0, 1 << 27, (1 << 27) | (1 << 29), 128, 1 << 28, 128 | (1 << 28)):
+    # bit 22 = the interleaved kernel where the default is the register-B kernel (conv1x1_f16x2_rb.inc: K % 32 == 0, M % 256 == 0)
+    for flags in (0, 1 << 27, (1 << 27) | (1 << 29), 128, 1 << 28, 128 | (1 << 28), 1 << 22, (1 << 22) | (1 << 28)):
         old = _abi.lib().ps_debug_flags(flags)
         try:
             y, st, am = H.conv1x1_f16x2(xd, t, wf, we, m, pro, b.to(dev), None, resd, want_stats=want, want_amax=True,

@@ -8,10 +8,12 @@ import bench
 dev = torch.device("cuda:0")
 model = bench.build_model(dev)
 model.hip_streams = 1
+from puresound_amd import _abi
+_abi.lib().ps_debug_flags(int(os.environ.get("PS_FLAGS", "0"), 0))
 x = ((torch.rand(32, 64000) * 2 - 1) * 0.5).to(dev)
-for gemm in ("fp16x2", "bf16x3"):
+for gemm in ("fp16x2",):
     model.masker.set_gemm_precision(gemm)
-    for b in (32, 16, 8, 4, 2):
+    for b in (32, 16, 8):
         chunks = list(x.split(b))
         for _ in range(2):
             for c in chunks:
