@@ -4,6 +4,7 @@ per GPU (BASELINE.json configs[1]), whole-job aggregate over N GPUs (weak scalin
 32 utterances, one RCCL all-gather reassembles the output waveforms inside the timed step).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks: puresound_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -152,6 +153,14 @@ def main():
                          "the other two as well and reports them in the same line.  bf16 (rounded operands) is not an "
                          "fp32 result and is labelled an experiment.")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` on its own: start the N ranks as child processes (before anything here touches a GPU),
+    # relay their output and leave with their status.  Under torch.distributed.run this is a no-op.
+    from puresound_amd import launch
+    if launch.needs_self_launch(args.gpus):
+        raise SystemExit(launch.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    if launch.launch_probe("bench.py"):
+        return
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))

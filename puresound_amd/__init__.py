@@ -3,7 +3,8 @@
 The package mirrors the part of `puresound.nnet` that lies on the inference path
 (encoder -> Conv-TasNet masker -> mask -> decoder -> clamp): same class names, constructor and call
 signatures, state_dict keys and error types, with the arithmetic done by hand-written HIP kernels in
-libpuresound_hip.so (C ABI: include/puresound_hip.h).  There is no CPU fallback.
+libpuresound_hip.so (C ABI: include/puresound_hip.h).  ROCm tensors never fall back to anything else; CPU tensors are
+served by stock-ATen registrations of the filterbank / STFT / Conv-TasNet operators (nnet/cpu_path.py), nothing more.
 """
 __version__ = "0.1.0"
 

@@ -204,6 +204,9 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
     @torch.no_grad()
     def inference(self, noisy: torch.Tensor, enroll: Optional[torch.Tensor] = None) -> torch.Tensor:
         """noisy [N,L] (+ enroll [N,L']) -> enhanced waveform [N,L_out] (base_nn.py:690-722)."""
+        if noisy.device.type == "cpu":  # BASELINE configs[0] / the recipes' --backend cpu: stock ATen (nnet/cpu_path.py)
+            from . import cpu_path
+            return cpu_path.wrapper_inference(self, noisy, enroll)
         hip.require_device(noisy, "SoTaskWrapModule.inference")
         mask_act = self.check_mask_constraint(self.mask_constraint)
         pairing = self.check_mask_pairing(self.mask_type, self.f_type)

@@ -48,7 +48,7 @@ def _param_signature(module: nn.Module):
     return tuple(sig)
 
 
-@op_module("tcn_block_fwd", same_shape)
+@op_module("tcn_block_fwd", same_shape, cpu="tcn_block")
 class TCN(_PlanCache, nn.Module):
     """Input 1x1 conv -> norm -> PReLU -> depthwise-separable conv -> output 1x1 conv -> + residual
     (conv_tasnet.py:11-90)."""
@@ -216,7 +216,7 @@ class TCN(_PlanCache, nn.Module):
         return hip.unpad_rows(out, t)
 
 
-@op_module("gated_tcn_fwd", same_shape)
+@op_module("gated_tcn_fwd", same_shape, cpu="gated_tcn_block")
 class GatedTCN(_PlanCache, nn.Module):
     """Gated TCN block (conv_tasnet.py:93-215): 1x1 in_conv; left = PReLU(norm(dense dilated conv)); right =
     sigmoid(PReLU(norm(dense dilated conv of [h; e] or of FiLM(h)))); out_conv(left * right); + residual.
@@ -352,7 +352,7 @@ class GatedTCN(_PlanCache, nn.Module):
         return hip.unpad_rows(self.forward_padded(hip.pad_rows(x), t, embed), t)
 
 
-@op_module("conv_tasnet_fwd", same_shape)
+@op_module("conv_tasnet_fwd", same_shape, cpu="conv_tasnet")
 class ConvTasNet(_PlanCache, nn.Module):
     """R repeats of X dilated TCN blocks with optional speaker-embedding injection
     (conv_tasnet.py:218-377).  Encoder/decoder live outside, as in the reference."""

@@ -106,8 +106,8 @@ def _stft_rebuild(a):
     return dict(a, window_mask=torch.hann_window(a.get("win_length") or a["n_fft"]))
 
 
-@op_module("istft_decode", _istft_shape, method="_istft", rebuild=_stft_rebuild)
-@op_module("stft_encode", _stft_shape, rebuild=_stft_rebuild)
+@op_module("istft_decode", _istft_shape, method="_istft", rebuild=_stft_rebuild, cpu="istft_decode")
+@op_module("stft_encode", _stft_shape, rebuild=_stft_rebuild, cpu="stft_encode")
 class ConvSTFT(nn.Module):
     """Conv-STFT with trainable analysis kernels (encoder.py:275-456).  Parameter / buffer holder."""
 

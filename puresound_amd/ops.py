@@ -9,7 +9,9 @@ so every reference-API `forward` / `inverse` of the mirror modules goes through 
     modules' padded-layout code),
   * a Meta implementation that only computes the output shape (FakeTensor / meta-device tracing, shape checks on a
     box without a GPU),
-  * a CPU registration that raises: there is no CPU fallback.
+  * a CPU registration: a stock-ATen composition (nnet/cpu_path.py) for the filterbanks, the STFT pair and the TCN family
+    -- what BASELINE's "PyTorch CPU forward" configuration and the recipes' `--backend cpu` need -- and an error for the
+    rest.  (On a ROCm device nothing falls back to it: a missing HIP library still fails at first use.)
 
 Two kinds of operators:
 
@@ -42,20 +44,24 @@ _KINDS: Dict[str, dict] = {}                       # kind -> {cls, method, shape
 _LIVE: "weakref.WeakValueDictionary" = weakref.WeakValueDictionary()   # (kind, cfg, ptrs) -> module that called
 _REBUILT: Dict[tuple, torch.nn.Module] = {}        # modules rebuilt from (cfg, params) of a loaded trace
 OP_NAMES: List[str] = []
+CPU_OPS: List[str] = []   # operators whose CPU registration computes (stock ATen compositions, nnet/cpu_path.py)
 
 
 def _no_cpu(name: str) -> Callable:
     def impl(*args, **kwargs):
-        raise RuntimeError(f"{NAMESPACE}::{name}: inputs must be HIP (cuda) tensors -- there is no CPU fallback")
+        raise RuntimeError(f"{NAMESPACE}::{name}: inputs must be HIP (cuda) tensors -- this operator has no CPU path "
+                           f"(those that have one: {', '.join(CPU_OPS)})")
     return impl
 
 
-def _define(name: str, schema: str, hip_impl: Callable, meta_impl: Callable) -> None:
+def _define(name: str, schema: str, hip_impl: Callable, meta_impl: Callable, cpu_impl: Optional[Callable] = None) -> None:
     _LIB.define(f"{name}{schema}")
     _LIB.impl(name, hip_impl, "CUDA")
     _LIB.impl(name, meta_impl, "Meta")
-    _LIB.impl(name, _no_cpu(name), "CPU")
+    _LIB.impl(name, cpu_impl if cpu_impl is not None else _no_cpu(name), "CPU")
     OP_NAMES.append(name)
+    if cpu_impl is not None:
+        CPU_OPS.append(name)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -85,8 +91,20 @@ def _free_decode_meta(feats, weight, hop):
     return feats.new_empty((n, (t - 1) * hop + weight.shape[-1]))
 
 
-_define("free_encode", "(Tensor wav, Tensor weight, int hop, bool relu) -> Tensor", _free_encode_hip, _free_encode_meta)
-_define("free_decode", "(Tensor feats, Tensor weight, int hop) -> Tensor", _free_decode_hip, _free_decode_meta)
+def _free_encode_cpu(wav, weight, hop, relu):
+    from .nnet import cpu_path
+    return cpu_path.free_encode(wav, weight.detach(), hop, relu)
+
+
+def _free_decode_cpu(feats, weight, hop):
+    from .nnet import cpu_path
+    return cpu_path.free_decode(feats, weight.detach(), hop)
+
+
+_define("free_encode", "(Tensor wav, Tensor weight, int hop, bool relu) -> Tensor", _free_encode_hip, _free_encode_meta,
+        _free_encode_cpu)
+_define("free_decode", "(Tensor feats, Tensor weight, int hop) -> Tensor", _free_decode_hip, _free_decode_meta,
+        _free_decode_cpu)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -137,7 +155,7 @@ def _call_cache(m: torch.nn.Module, kind: str):
         cfg = json.dumps({"ctor": getattr(m, "_ctor_args", None)}, sort_keys=True)
         object.__setattr__(m, "_op_cfg_json", cfg)
     params = module_tensors(m)
-    if params and params[0].device.type == "cuda":
+    if params:
         _LIVE[(kind, cfg, tuple(p.data_ptr() for p in params))] = m
     return params, cfg
 
@@ -173,11 +191,13 @@ def _resolve(kind: str, cfg: str, params: Sequence[torch.Tensor]) -> torch.nn.Mo
     return m
 
 
-def op_module(kind: str, shape: Callable, method: str = "forward", rebuild: Optional[Callable] = None):
+def op_module(kind: str, shape: Callable, method: str = "forward", rebuild: Optional[Callable] = None,
+              cpu: Optional[str] = None):
     """Class decorator: the reference-API `method(x, aux=None)` of the class goes through
     torch.ops.puresound_amd.<kind>; the original body stays reachable as `_hip_<method>`.
 
-    shape(ctor_args, x_shape, aux_shape) -> output shape (the Meta implementation)."""
+    shape(ctor_args, x_shape, aux_shape) -> output shape (the Meta implementation).
+    cpu: name of the function in nnet/cpu_path.py that serves CPU tensors, `fn(module, x[, aux])` (None: CPU tensors raise)."""
 
     def deco(cls):
         body = getattr(cls, method)
@@ -216,7 +236,15 @@ def op_module(kind: str, shape: Callable, method: str = "forward", rebuild: Opti
                         [tuple(p.shape) for p in params])
             return x.new_empty(out)
 
-        _define(kind, "(Tensor x, Tensor? aux, Tensor[] params, str cfg) -> Tensor", hip_impl, meta_impl)
+        cpu_impl = None
+        if cpu is not None:
+            def cpu_impl(x, aux, params, cfg):
+                from .nnet import cpu_path
+                m = _resolve(kind, cfg, params)
+                fn = getattr(cpu_path, cpu)
+                return fn(m, x) if n_in == 1 else fn(m, x, aux)
+
+        _define(kind, "(Tensor x, Tensor? aux, Tensor[] params, str cfg) -> Tensor", hip_impl, meta_impl, cpu_impl)
         _KINDS[kind] = dict(cls=cls, method=method, shape=shape, rebuild=rebuild or (lambda a: a))
         op = getattr(getattr(torch.ops, NAMESPACE), kind)
 

@@ -40,12 +40,13 @@ def test_every_operator_has_hip_meta_and_cpu_registrations():
             assert torch._C._dispatch_has_kernel_for_dispatch_key(f"puresound_amd::{name}", key), (name, key)
 
 
-def test_cpu_tensors_raise_instead_of_falling_back():
+def test_cpu_dispatch_computes_where_registered_and_raises_elsewhere():
     enc = PA.FreeEncDec(32, 64, 16)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        enc(torch.zeros(2, 4000))
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        torch.ops.puresound_amd.free_decode(torch.zeros(2, 64, 10), enc.decoder.weight, 16)
+    feats = enc(torch.zeros(2, 4000))                      # CPU registration: a stock ATen composition
+    assert feats.shape == (2, 64, (4000 - 32) // 16 + 1) and not feats.requires_grad
+    assert torch.ops.puresound_amd.free_decode(torch.zeros(2, 64, 10), enc.decoder.weight, 16).shape == (2, 9 * 16 + 32)
+    with pytest.raises(RuntimeError, match="no CPU path"):  # an operator without one
+        torch.ops.puresound_amd.lstm_seq_fwd(torch.zeros(1, 2, 8), torch.zeros(8, 2), None, None)
 
 
 @pytest.mark.parametrize("name", ["cfg3_short", "cfg2_short", "cfg1_short", "cfg4_short"])
@@ -92,7 +93,7 @@ def test_sequence_and_streaming_operators_propagate_shapes_on_the_meta_device():
     params, cfg = ops.call_args(m, "skim_step")
     yf = torch.ops.puresound_amd.skim_step(torch.empty(2, 16, device="meta"), e, state, 0, params, cfg)
     assert yf.shape == (2, 24, 1)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
+    with pytest.raises(RuntimeError, match="no CPU path"):
         torch.ops.puresound_amd.lstm_seq_fwd(torch.zeros(1, 2, 8), torch.zeros(8, 2), None, None)
 
 

@@ -132,18 +132,21 @@ def test_task_labels():
 
 
 # ---------------------------------------------------------------------------------------------------
-# no CPU fallback
+# CPU tensors: the operators that have a CPU registration compute (stock ATen, tests/test_cpu_path.py); the HIP entry
+# points themselves never fall back, and the operators without a CPU registration say so
 # ---------------------------------------------------------------------------------------------------
-def test_product_path_refuses_cpu_tensors():
+def test_hip_entry_points_refuse_cpu_tensors_and_uncovered_operators_say_so():
+    from puresound_amd import hip
     m = _wrapper().eval()
+    assert m.inference(torch.zeros(1, 400)).shape == (1, 400)      # FreeEncDec + ConvTasNet: CPU registrations
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # the kernels' launchers: ROCm tensors only
+        hip.free_encode(torch.zeros(1, 400), m.encoder.encoder.weight.detach(), m.encoder.hop_length, False)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
-        m.inference(torch.zeros(1, 400))
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        m.masker(torch.zeros(1, 8, 20))
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        m.encoder(torch.zeros(1, 400))
+        m.encoder.encode_padded(torch.zeros(1, 400))
     with pytest.raises(RuntimeError, match="ROCm device only"):
         _abi.require_device(torch.zeros(2), "x")
+    with pytest.raises(RuntimeError, match="no CPU path"):          # a recurrent masker has no CPU registration
+        PA.DPRNN(8, 4, 8, n_blocks=1, seg_size=4).eval()(torch.zeros(1, 8, 20))
 
 
 def test_product_code_never_imports_the_oracle():

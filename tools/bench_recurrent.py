@@ -153,7 +153,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default="cfg4,cfg5")
     ap.add_argument("--gpus", type=int, default=1,
-                    help="cfg4: data-parallel over N GPUs (launch with torch.distributed.run --nproc-per-node N): 32 utterances "
+                    help="cfg4: data-parallel over N GPUs (starts its own N ranks, or runs under torch.distributed.run): 32 utterances "
                          "per rank, one all-gather of the outputs per step")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=10)
@@ -165,6 +165,12 @@ if __name__ == "__main__":
     ap.add_argument("--gemm", default="fp32", choices=["fp32", "fp16x2", "bf16x3", "bf16"],
                     help="arithmetic of the LSTM input projections (per module: masker.set_gemm_precision)")
     a = ap.parse_args()
+    # `--gpus N` on its own: start the N ranks as child processes before anything here touches a GPU (as bench.py does)
+    from puresound_amd import launch
+    if launch.needs_self_launch(a.gpus):
+        raise SystemExit(launch.self_launch(os.path.abspath(__file__), sys.argv[1:], a.gpus))
+    if launch.launch_probe("bench_recurrent.py"):
+        raise SystemExit(0)
     if a.flags:
         _abi.lib().ps_debug_flags(a.flags)
     if "cfg4" in a.which:
