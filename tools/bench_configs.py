@@ -57,11 +57,15 @@ def cfg3(dev, steps=5, warmup=2, modes=("fp16x2", "bf16"), batch=32):
     set_mode("fp32")
     ref = model.inference(noisy, enroll)
     out = {"workload": f"td_tse_conv_tasnet_v0, {batch} x (4 s mixture + 4 s enrolment), 1 GPU", "steps": steps}
+    # 0.745 GB per utterance pair in bf16 storage (mixture 24 blocks + enrolment 5 blocks + features), twice
+    # that with fp32 rows; roofline_frac = those bytes / time / 8 TB/s
+    alg = {"bf16": 23.86e9 * batch / 32, "fp16x2": 47.72e9 * batch / 32, "bf16x3": 47.72e9 * batch / 32, "fp32": 47.72e9 * batch / 32}
     for prec in modes:
         set_mode(prec)
         ms, y = _timed(lambda: model.inference(noisy, enroll), steps, warmup)
         out[prec] = {"ms": ms, "samples_s": batch * L / ms * 1e3,
-                     "l2_rel_vs_fp32": float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref))}
+                     "l2_rel_vs_fp32": float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref)),
+                     "algorithmic_bytes": alg[prec], "roofline_frac": alg[prec] / (ms * 1e-3) / 8e12}
     return out
 
 
@@ -81,6 +85,11 @@ def cfg4(dev, steps=10, warmup=3, batch=32, gemm="fp32", graph=True):
     out = {"workload": f"DPRNN(128,64,128,6 blocks,K=20,causal), {batch} x 4 s, 1 GPU, fp32 rows, input projections {gemm}",
            "steps": steps, "ms": ms, "samples_s": batch * L / ms * 1e3, "serial_steps": 6 * (20 + 200),
            "us_per_serial_step": ms * 1e3 / (6 * (20 + 200))}
+    # (6 * 4C + 4C) elements per frame, T' = 4000 frames, fp32 rows here (bf16 storage: half); the config is
+    # bounded by its 1320 dependent LSTM steps, so the HBM fraction rides along with the microseconds per step
+    alg = (6 * 4 * 128 + 4 * 128) * 4000 * 4.0 * batch
+    out["algorithmic_bytes"] = alg
+    out["roofline_frac"] = alg / (ms * 1e-3) / 8e12
     if graph:
         from puresound_amd.graphs import GraphedInference
         fast = GraphedInference(model)
@@ -92,7 +101,7 @@ def cfg4(dev, steps=10, warmup=3, batch=32, gemm="fp32", graph=True):
         ref = model.inference(noisy)
         model.masker.set_gemm_precision("fp16x2")
         ms2, y = _timed(lambda: model.inference(noisy), steps, warmup)
-        out["fp16x2_projections"] = {"ms": ms2, "samples_s": batch * L / ms2 * 1e3,
+        out["fp16x2_projections"] = {"ms": ms2, "samples_s": batch * L / ms2 * 1e3, "roofline_frac": alg / (ms2 * 1e-3) / 8e12,
                                      "l2_rel_vs_fp32": float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref)),
                                      "arithmetic": "masker.set_gemm_precision('fp16x2'): LSTM input projections and the "
                                                    "intra-pass recurrent product W_hh h in two fp16 terms per operand"}
@@ -100,7 +109,7 @@ def cfg4(dev, steps=10, warmup=3, batch=32, gemm="fp32", graph=True):
     return out
 
 
-def cfg5(dev, chunks=300, streams=64, warmup=10):
+def cfg5(dev, chunks=500, streams=64, warmup=10):
     """Demo preset (egs/tse/demo/utils.py:51-72), `streams` concurrent streams, 320-sample chunks, one hipGraph per chunk."""
     from detweights import det_state_dict
     from puresound_amd.streaming.demo import DemoTseNet
@@ -125,4 +134,6 @@ def cfg5(dev, chunks=300, streams=64, warmup=10):
     return {"workload": f"demo StreamingSkiM(128,256,128,4 blocks,K=150), {streams} streams x 320-sample chunks, one hipGraph "
                         f"per chunk", "chunks": int(len(lat)), "p50_ms": float(np.percentile(lat, 50)),
             "p90_ms": float(np.percentile(lat, 90)), "max_ms": float(lat.max()), "budget_ms": 20.0,
-            "mem_lstm_updates_seen": int(len(lat) * 20 // 150)}
+            "mem_lstm_updates_seen": int(len(lat) * 20 // 150),
+            "roofline_frac": None, "roofline_note": "latency-bound (SURVEY 8d): 80 dependent LSTM steps per chunk against "
+                                                    "a 20 ms budget; no bandwidth roofline applies"}
