@@ -32,8 +32,8 @@ HBM_PEAK_GBPS = 8000.0  # same guide: HBM3E, ~8 TB/s
 # need their own rocprofv3 passes -- so it is READ from the summary of those passes committed under profiles/
 # (tools/pmc_summary.py; same command line as this benchmark, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
 # gfx950) and labelled with the file it came from.  It never enters `frac`.
-PMC_FILES = {"fp16x2": "profiles/r03_pmc_hbm_traffic_fp16x2.json", "bf16x3": "profiles/r03_pmc_hbm_traffic_bf16x3.json",
-             "fp32": "profiles/r03_pmc_hbm_traffic_fp32.json"}
+PMC_FILES = {"fp16x2": "profiles/r04_pmc_hbm_traffic_fp16x2.json", "bf16x3": "profiles/r04_pmc_hbm_traffic_bf16x3.json",
+             "fp32": "profiles/r04_pmc_hbm_traffic_fp32.json"}
 
 
 def pmc_traffic(gemm, prefix):
@@ -41,7 +41,8 @@ def pmc_traffic(gemm, prefix):
     path = os.path.join(ROOT, PMC_FILES.get(gemm, ""))
     if not os.path.isfile(path):
         return None, None
-    ks = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(prefix)}
+    prefixes = (prefix,) if isinstance(prefix, str) else tuple(prefix)
+    ks = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(prefixes)}
     n = sum(v["launches"] for v in ks.values())
     if not n:
         return None, None
@@ -330,7 +331,7 @@ def main():
         else:
             planes_products = SPLIT_PRODUCTS[args.gemm]
             peak = BF16_MFMA_PEAK_TFLOPS / planes_products
-            traffic, src = pmc_traffic(args.gemm, "ps::conv1x1_bf16_")
+            traffic, src = pmc_traffic(args.gemm, ("ps::conv1x1_bf16_", "ps::conv1x1_f16x2_"))
             # SURVEY 8(d), per TCN block and frame: in_conv reads C and writes H, the pointwise conv reads H and writes H,
             # out_conv reads H and the residual (C) and writes C: (3C + 4H) elements over three launches.  (out_conv's
             # two m-tiles each stream the same input rows; that second read is traffic, not algorithmic work.)
@@ -346,7 +347,8 @@ def main():
                         "floor_ms": alg_bytes / (HBM_PEAK_GBPS * 1e9) * 1e3}
             tnote = (f"HBM bytes per launch read from {src} (separate rocprofv3 --pmc passes of this command), not "
                      f"measured in this run" if src else "no PMC summary committed for this arithmetic")
-            kern = "ps::conv1x1_bf16_il_kernel (%s)" % ("ps_conv1x1_f16x2_f32" if args.gemm == "fp16x2" else "ps_conv1x1_bf16_f32")
+            kern = ("ps::conv1x1_f16x2_rb_kernel (ps_conv1x1_f16x2_f32)" if args.gemm == "fp16x2" else
+                    "ps::conv1x1_bf16_il_kernel (ps_conv1x1_bf16_f32)")
             # the binding roofline is the one with the larger floor for the average launch: the six-product split is
             # matrix-pipe bound (67 us against 60), the three-product split HBM bound (34 us against 60)
             if hbm_side["floor_ms"] > mfma_side["floor_ms"]:

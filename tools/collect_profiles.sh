@@ -3,7 +3,7 @@
 #   kernel trace + stats of the default bench.py command, PMC HBM-traffic passes (FETCH_SIZE / WRITE_SIZE separately)
 # usage: tools/collect_profiles.sh r03
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 out=gpurun_out/prof_$tag

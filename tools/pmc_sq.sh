@@ -23,7 +23,7 @@ tot, cnt = defaultdict(float), defaultdict(int)
 for f in glob.glob("gpurun_out/pmc_sq/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "")
-        if "il_kernel" not in k and "w1_kernel" not in k: continue
+        if "il_kernel" not in k and "w1_kernel" not in k and "rb_kernel" not in k: continue
         tot[(k, row["Counter_Name"])] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
 for k in sorted({k for k, _ in tot}):
     print(k)
