@@ -1538,7 +1538,13 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
 #define RB_DELAY_ST 0
 #endif
         b.delay = (a.ksteps / 2) * (res ? RB_DELAY_RES : RB_DELAY_ST);  // ... by about half a K loop (cycles per K-step)
-        b.pair_r = 0;
+        // two m-tiles: workgroups 8 apart share a run of frame tiles, one m-tile each (see the kernel); needs an even grid
+        // whose halves get whole, equal runs
+        b.pair_r = (a.tiles_m == 2 && Gr % 16 == 0 && !(g_debug_flags & 64)) ? 1 : 0;
+        if (b.pair_r) {  // (a pair's run of frame tiles must stay within PP_MAXU utterances too)
+          const long long fr = (long long)a.tiles_t * N, pw2 = (fr + Gr / 2 - 1) / (Gr / 2);
+          if ((pw2 + a.tiles_t - 2) / a.tiles_t + 1 > PP_MAXU) b.pair_r = 0;
+        }
 #ifdef PS_TUNE
         if (const char* v = getenv("PS_RB_DELAY")) b.delay = atoi(v) * (a.ksteps / 2);
 #endif
