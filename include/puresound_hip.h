@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 10
+#define PS_ABI_VERSION 11
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -441,16 +441,22 @@ typedef struct ps_tcn_block {
    * the residual stream's range travels from out_conv to the next in_conv as partial maxima inside the workspace */
   int w_exp[3];
   float dw_gmax, dw_bmax, pw_gmax, pw_bmax;
+  /* gemm_planes = 1 with hidden_bf16, inside ps_conv_tasnet_bf16_rows: optional two-plane fp16 images of the three
+   * weights (as for gemm_planes = 2, with w_exp / dw_* / pw_* above filled in the same way).  Launches large enough for
+   * the register-B kernel then run ps_conv1x1_f16_rows (bf16 rows, one fp16 product per multiply-add) instead of the
+   * planes = 1 kernels; NULL keeps the latter. */
+  const void *in_wf, *pw_wf, *out_wf;
 } ps_tcn_block;
 
 /* ps_conv1x1_bf16_f32 / ps_dwconv_f32 with bf16 activation rows (x_bf16 / y_bf16 != 0: the buffer holds
- * [N][channels][ldt] bf16 instead of fp32; planes must be 1, the residual stays fp32 and excludes y_bf16; the depthwise
+ * [N][channels][ldt] bf16 instead of fp32; planes must be 1; with y_bf16 a residual is bf16 rows as well; the depthwise
  * form is built for P = 3).  Used inside ps_conv_tasnet_f32 for the hidden maps of a block with hidden_bf16. */
 int ps_conv1x1_bf16_io(const void* x, int x_bf16, const void* wt_planes, void* y, int y_bf16, int N, int K, int M, int T,
                        int ldt, int planes, const ps_prologue* pro, const float* bias, const float* bias_n,
                        const float* res, double* ostats, void* stream);
 int ps_dwconv_io(const void* x, int x_bf16, const float* w, const float* b, void* y, int y_bf16, int N, int H, int T,
                  int ldt, int P, int dilation, int left, const ps_prologue* pro, double* ostats, void* stream);
+
 
 /* ps_conv1x1_f32's contract in the "fp16x2" arithmetic: every operand as two fp16 terms (22 significant bits), three
  * products W0x0 + W0x1 + W1x0 on v_mfma_f32_32x32x16_f16, fp32 accumulation: half the matrix-pipe work of the
@@ -477,6 +483,19 @@ typedef struct ps_f16x2_range {
 int ps_conv1x1_f16x2_f32(const float* x, const void* wt_planes, const ps_f16x2_range* rng, float* y, int N, int K, int M,
                          int T, int ldt, const ps_prologue* pro, const float* bias, const float* bias_n,
                          const float* res, double* ostats, void* stream);
+
+/* The 1x1 convolution with every activation row (x, y, the residual) stored as bf16 and ONE fp16 product per
+ * multiply-add: x is rounded to fp16 behind its prologue (a bf16-stored value has 8 significant bits, fp16 keeps 11),
+ * the weights enter as the first plane of their fp16x2 image (11 bits against bf16's 8), accumulation, bias, statistics
+ * and the range handling are those of ps_conv1x1_f16x2_f32 (rng as there; a range is mandatory).  Runs on the
+ * register-B kernel only: ps_conv1x1_f16_rows_ok(N, K, M, T) says whether a launch qualifies (K % 32 == 0,
+ * M % 256 == 0, enough tiles for the chip); otherwise PS_E_UNSUPPORTED and the caller takes ps_conv1x1_bf16_io.
+ * Replaces the same reference op as ps_conv1x1_f32 (/root/reference/puresound/nnet/conv_tasnet.py:43-90) in the
+ * "bf16 storage / fp32 accumulate" arithmetic BASELINE.json names for config 3. */
+int ps_conv1x1_f16_rows_ok(int N, int K, int M, int T);
+int ps_conv1x1_f16_rows(const void* x, const void* wt_planes, const ps_f16x2_range* rng, void* y, int N, int K, int M,
+                        int T, int ldt, const ps_prologue* pro, const float* bias, const float* bias_n, const void* res,
+                        double* ostats, void* stream);
 /* partial maxima of |x| over the valid frames: amax [N][ps_absmax_parts()] */
 int ps_absmax_parts(void);
 int ps_absmax_f32(const float* x, float* amax, int N, int C, int T, int ldt, void* stream);
@@ -495,6 +514,13 @@ int ps_conv_tasnet_f32(const ps_tcn_block* blocks_host, int n_blocks, const floa
 int ps_conv_tasnet_ranged_f32(const ps_tcn_block* blocks, int n_blocks, const float* x_in, float* x_out,
                               const float* dvec, int embed_norm, int N, int T, int ldt, void* workspace,
                               size_t workspace_bytes, const float* x_amax, int x_amax_parts, void* stream);
+
+/* The same masker with the residual stream stored as bf16 rows too: x_in / x_out are [N][C][ldt] bf16.  Every block must
+ * be in the bf16 arithmetic (gemm_planes = 1, hidden_bf16 = 1): bf16 products and rows, fp32 accumulation, statistics,
+ * bias and norm parameters -- what BASELINE.json names for its config 3 ("bf16 storage / fp32 accumulate";
+ * /root/reference/egs/tse/model.py:95-140 builds the model).  Not an fp32-class result: acceptance l2-rel <= 3e-2. */
+int ps_conv_tasnet_bf16_rows(const ps_tcn_block* blocks, int n_blocks, const void* x_in, void* x_out, const float* dvec,
+                             int embed_norm, int N, int T, int ldt, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Five moments of an (estimate, reference) waveform pair per row -- sum a, sum b, sum a^2, sum b^2, sum ab over L
  * samples, fp64 -- as per-workgroup partials [N][ps_wave_moments_chunks(L)][5] (the caller adds them up).  Every

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PURESOUND_HIP_LIB: an experimental build of the same library (tools/build_variant.sh); kernel experiments only
 LIB_PATH = os.environ.get("PURESOUND_HIP_LIB") or os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -50,7 +50,7 @@ class TcnBlock(C.Structure):
                 ("out_wt", _vp), ("out_b", _vp),
                 ("gemm_planes", C.c_int), ("in_wb", _vp), ("pw_wb", _vp), ("out_wb", _vp), ("hidden_bf16", C.c_int),
                 ("w_exp", C.c_int * 3), ("dw_gmax", C.c_float), ("dw_bmax", C.c_float), ("pw_gmax", C.c_float),
-                ("pw_bmax", C.c_float)]
+                ("pw_bmax", C.c_float), ("in_wf", _vp), ("pw_wf", _vp), ("out_wf", _vp)]
 
 
 # name -> (restype, argtypes); every symbol include/puresound_hip.h declares
@@ -127,6 +127,10 @@ SIGNATURES = {
                                      C.c_int, _vp, C.c_size_t, _vp]),
     "ps_conv_tasnet_ranged_f32": (C.c_int, [C.POINTER(TcnBlock), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                             C.c_int, _vp, C.c_size_t, _vp, C.c_int, _vp]),
+    "ps_conv1x1_f16_rows_ok": (C.c_int, [C.c_int] * 4),
+    "ps_conv1x1_f16_rows": (C.c_int, [_vp, _vp, C.POINTER(F16x2Range), _vp] + [C.c_int] * 5 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
+    "ps_conv_tasnet_bf16_rows": (C.c_int, [C.POINTER(TcnBlock), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, _vp, C.c_size_t, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -184,9 +184,10 @@ extern "C" size_t ps_conv_tasnet_workspace_bytes(int N, int C, int H, int T) {
 }
 
 // x_amax / x_amax_parts: partial maxima of |x_in| (gemm_planes = 2); y_amax: where out_conv leaves those of x_out
+// sb: the residual stream (x_in, x_out) is bf16 rows too (ps_conv_tasnet_bf16_rows; needs gemm_planes = 1 with hidden_bf16)
 static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, const float* dvec, int embed_norm,
                      int N, int T, int ldt, const TasnetWs& w, const float* x_amax, int x_amax_parts, float* y_amax,
-                     void* stream) {
+                     void* stream, int sb = 0) {
   int rc;
   const float eps = 1e-8f;  // GlobLN.eps and gGN's eps (lobe/norm.py:10,96); folded BN carries its own
   const double count = (double)b.H * (double)T;
@@ -227,6 +228,26 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
       if (which == 2) rng.y_amax = y_amax;
       return ps_conv1x1_f16x2_f32(x, wb, &rng, y, N, K, M, T, ldt, pro, bias, bn, res, st, stream);
     }
+    // bf16 residual stream: launches the register-B kernel takes run with bf16 rows and ONE fp16 product per multiply-add
+    // (ps_conv1x1_f16_rows) whenever the block carries the fp16 weight images and the input's range is known
+    const void* wf = which == 0 ? b.in_wf : which == 1 ? b.pw_wf : b.out_wf;
+    if (sb && wf && xb && yb && ps_conv1x1_f16_rows_ok(N, K, M, T)) {
+      ps_f16x2_range rng{};
+      rng.w_exp = b.w_exp[which];
+      bool have = true;
+      if (which == 0) {
+        rng.x_amax = x_amax;
+        rng.x_amax_parts = x_amax_parts;
+        have = x_amax != nullptr;
+      } else {
+        const float gmax = which == 1 ? b.dw_gmax : b.pw_gmax, bmax = which == 1 ? b.dw_bmax : b.pw_bmax;
+        rng.x_bound = gmax * (float)sqrt(count) + bmax;
+        if (!(rng.x_bound > 0.f)) rng.x_bound = 1.f;
+        have = (which == 1 ? b.dw_norm : b.pw_norm) == PS_NORM_GLOBAL;
+      }
+      if (which == 2) rng.y_amax = y_amax;
+      if (have) return ps_conv1x1_f16_rows(x, wf, &rng, y, N, K, M, T, ldt, pro, bias, bn, res, st, stream);
+    }
     return ps_conv1x1_bf16_io(x, xb, wb, y, yb, N, K, M, T, ldt, b.gemm_planes, pro, bias, bn, res, st, stream);
   };
   if (b.gemm_planes == 2 && (b.dw_norm != PS_NORM_GLOBAL || b.pw_norm != PS_NORM_GLOBAL || !x_amax)) {
@@ -238,7 +259,12 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
     set_error("ps_conv_tasnet_f32: gemm_planes=%d needs the plane-packed weights in_wb / pw_wb / out_wb", b.gemm_planes);
     return PS_E_INVALID;
   }
-  rc = gemm(0, x_in, 0, b.in_wt, b.in_wb, w.y1, hb, b.C, b.H, nullptr, nullptr, bias_n, nullptr,
+  if (sb && !hb) {
+    set_error("ps_conv_tasnet_bf16_rows: block needs gemm_planes = 1 with hidden_bf16 (got planes=%d hidden_bf16=%d)",
+              b.gemm_planes, b.hidden_bf16);
+    return PS_E_UNSUPPORTED;
+  }
+  rc = gemm(0, x_in, sb, b.in_wt, b.in_wb, w.y1, hb, b.C, b.H, nullptr, nullptr, bias_n, nullptr,
             b.in_norm == PS_NORM_GLOBAL ? w.s1 : nullptr);
   if (rc) return rc;
 
@@ -284,7 +310,7 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
   p3.gamma = b.pw_gamma;
   p3.beta = b.pw_beta;
   p3.slope = b.pw_slope;
-  return gemm(2, w.y3, hb, b.out_wt, b.out_wb, x_out, 0, b.H, b.C, &p3, b.out_b, nullptr, x_in, nullptr);
+  return gemm(2, w.y3, hb, b.out_wt, b.out_wb, x_out, sb, b.H, b.C, &p3, b.out_b, nullptr, x_in, nullptr);
 }
 
 extern "C" int ps_conv_tasnet_f32(const ps_tcn_block* blocks, int n_blocks, const float* x_in, float* x_out,
@@ -294,9 +320,28 @@ extern "C" int ps_conv_tasnet_f32(const ps_tcn_block* blocks, int n_blocks, cons
                                    nullptr, 0, stream);
 }
 
+static int conv_tasnet_rows(const ps_tcn_block* blocks, int n_blocks, const float* x_in, float* x_out, const float* dvec,
+                            int embed_norm, int N, int T, int ldt, void* workspace, size_t workspace_bytes,
+                            const float* x_amax, int x_amax_parts, void* stream, int sb);
+
 extern "C" int ps_conv_tasnet_ranged_f32(const ps_tcn_block* blocks, int n_blocks, const float* x_in, float* x_out,
                                          const float* dvec, int embed_norm, int N, int T, int ldt, void* workspace,
                                          size_t workspace_bytes, const float* x_amax, int x_amax_parts, void* stream) {
+  return conv_tasnet_rows(blocks, n_blocks, x_in, x_out, dvec, embed_norm, N, T, ldt, workspace, workspace_bytes, x_amax,
+                          x_amax_parts, stream, 0);
+}
+
+// BASELINE config 3's arithmetic ("bf16 storage / fp32 accumulate"): the residual stream is bf16 rows as well
+extern "C" int ps_conv_tasnet_bf16_rows(const ps_tcn_block* blocks, int n_blocks, const void* x_in, void* x_out,
+                                        const float* dvec, int embed_norm, int N, int T, int ldt, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  return conv_tasnet_rows(blocks, n_blocks, (const float*)x_in, (float*)x_out, dvec, embed_norm, N, T, ldt, workspace,
+                          workspace_bytes, nullptr, 0, stream, 1);
+}
+
+static int conv_tasnet_rows(const ps_tcn_block* blocks, int n_blocks, const float* x_in, float* x_out, const float* dvec,
+                            int embed_norm, int N, int T, int ldt, void* workspace, size_t workspace_bytes,
+                            const float* x_amax, int x_amax_parts, void* stream, int sb) {
   if (x_amax && x_amax_parts <= 0) {
     set_error("ps_conv_tasnet_ranged_f32: x_amax needs x_amax_parts > 0");
     return PS_E_INVALID;
@@ -343,18 +388,27 @@ extern "C" int ps_conv_tasnet_ranged_f32(const ps_tcn_block* blocks, int n_block
   const int out_parts = ps_conv1x1_stats_parts(C, T);
   for (int i = 0; i < n_blocks; ++i) {
     const float* xi = i == 0 ? x_in : x_out;
-    const bool f16 = blocks[i].gemm_planes == 2;
+    // (bf16 rows: out_conv leaves the maxima of the stream for the next in_conv when it runs on the register-B kernel)
+    const bool rows16 = sb && blocks[i].out_wf && blocks[i].in_wf && ps_conv1x1_f16_rows_ok(N, H, C, T) &&
+                        blocks[i].pw_norm == PS_NORM_GLOBAL;
+    const bool f16 = blocks[i].gemm_planes == 2 || rows16;
     const float* range = w.amax[i & 1];
     if (f16 && i == 0 && x_amax) {  // the caller knows the range of x_in (maxima, or any upper bound per utterance)
       range = x_amax;
       have_parts = x_amax_parts;
+    } else if (f16 && !have_parts && sb) {
+      range = nullptr;  // (no pass over bf16 rows: this block's in_conv takes the planes = 1 kernel)
     } else if (f16 && !have_parts) {  // first fp16x2 block (or one behind another arithmetic): one pass over its input
       const int rc = ps_absmax_f32(xi, w.amax[i & 1], N, C, T, ldt, stream);
       if (rc) return rc;
       have_parts = ps_absmax_parts();
     }
-    const int rc = run_block(blocks[i], xi, x_out, dvec, embed_norm, N, T, ldt, w, f16 ? range : nullptr,
-                             have_parts, f16 ? w.amax[(i + 1) & 1] : nullptr, stream);
+    if (sb && (blocks[i].gemm_planes != 1 || !blocks[i].hidden_bf16)) {
+      set_error("ps_conv_tasnet_bf16_rows: block %d is not in the bf16 arithmetic (gemm_planes = 1, hidden_bf16)", i);
+      return PS_E_UNSUPPORTED;
+    }
+    const int rc = run_block(blocks[i], xi, x_out, dvec, embed_norm, N, T, ldt, w, (f16 && have_parts) ? range : nullptr,
+                             have_parts, f16 ? w.amax[(i + 1) & 1] : nullptr, stream, sb);
     if (rc) return rc;
     have_parts = f16 ? out_parts : 0;
   }

@@ -341,11 +341,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
   if (a.ablate & 2) return;
   float fsum = 0.f, fsq = 0.f;
   [[maybe_unused]] float amx2[TI] = {};  // per column block; the pad-frame mask is applied once at the end
-  const int slab = a.M * a.ldt * 4;
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<unsigned char*>(a.y) + (size_t)n * a.M * a.ldt * YE, 0, a.M * a.ldt * YE, 0x00020000);
+  // (bf16 output rows with a residual: the residual stream is bf16 too -- the "bf16 stream" arithmetic of BASELINE config 3)
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(RES ? a.res : a.x) + (size_t)n * a.M * a.ldt, 0, RES ? slab : 0, 0x00020000);
+      reinterpret_cast<unsigned char*>(const_cast<float*>(RES ? a.res : a.x)) + (size_t)n * a.M * a.ldt * YE, 0,
+      RES ? a.M * a.ldt * YE : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.bias ? a.bias : a.x), 0, a.bias ? a.M * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t bnr = __builtin_amdgcn_make_buffer_rsrc(
@@ -366,9 +367,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16_kernel(BfArgs a) {
                 __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bnr, moff, 0, 0));
       if constexpr (RES) {
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti)
-          rv[ti][r] = __builtin_bit_cast(
-              float, __builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, tile_off + rc * a.ldt * 4 + ti * 128, 0));
+        for (int ti = 0; ti < TI; ++ti) {
+          if constexpr (YB)
+            rv[ti][r] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(
+                                                      rr, lane_off >> 1, (tile_off + rc * a.ldt * 4 + ti * 128) >> 1, 0) << 16);
+          else
+            rv[ti][r] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rr, lane_off, tile_off + rc * a.ldt * 4 + ti * 128, 0));
+        }
       }
     }
 #pragma unroll
@@ -1439,6 +1445,49 @@ __global__ __launch_bounds__(256, 1) void conv1x1_bf16_solo_kernel(BfArgs a) {
 
 static int bf16_cus() { return device_cus(); }
 
+// Can this launch run on the register-B kernel (conv1x1_f16x2_rb.inc)?  K a multiple of 32, M a multiple of 256, a
+// scale / shift + PReLU prologue at most, enough tiles for the chip and a workgroup's run inside PP_MAXU utterances.
+// Gr receives the grid.
+static bool rb_ok(const BfArgs& a, int N, int* Gr_out) {
+  if (a.K % 32 != 0 || a.M % 256 != 0 || a.ksteps < 4 || a.pro.pre_relu || a.pro.post_tanh) return false;
+  const int cus = bf16_cus();
+  const long long ntiles = (long long)a.tiles_t * a.tiles_m * N;
+  const long long st_per = (a.tiles_t + 1) / 2, nsuper = st_per * a.tiles_m * N;
+  if (!(2 * nsuper >= cus || (g_debug_flags & (1 << 28)))) return false;
+  const int Gr = (int)(ntiles < 2 * cus ? ntiles : 2 * cus);
+  const long long pw = (ntiles + Gr - 1) / Gr, pu = (long long)a.tiles_t * a.tiles_m;
+  if ((pw + pu - 2) / pu + 1 > PP_MAXU) return false;
+  if (Gr_out) *Gr_out = Gr;
+  return true;
+}
+
+template <bool R16>
+static void rb_launch(const BfArgs& a, int N, bool tr, int Gr, hipStream_t stream) {
+  const bool stats = a.ostats != nullptr, res = a.res != nullptr;
+  BfArgs& b = const_cast<BfArgs&>(a);
+  b.groups = Gr / 2;
+  b.delay = 0;
+  // two m-tiles: workgroups 8 apart share a run of frame tiles, one m-tile each (see the kernel); needs an even grid
+  // whose halves get whole, equal runs
+  b.pair_r = (a.tiles_m == 2 && Gr % 16 == 0 && !(g_debug_flags & 64)) ? 1 : 0;
+  if (b.pair_r) {  // (a pair's run of frame tiles must stay within PP_MAXU utterances too)
+    const long long fr = (long long)a.tiles_t * N, pw2 = (fr + Gr / 2 - 1) / (Gr / 2);
+    if ((pw2 + a.tiles_t - 2) / a.tiles_t + 1 > PP_MAXU) b.pair_r = 0;
+  }
+#define PS_RB(TRV, STV, RSV) \
+  hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<TRV, STV, RSV, R16>), dim3(Gr, 1), dim3(256), 0, stream, a)
+  if (tr) {
+    if (stats) PS_RB(true, true, false);
+    else if (res) PS_RB(true, false, true);
+    else PS_RB(true, false, false);
+  } else {
+    if (stats) PS_RB(false, true, false);
+    else if (res) PS_RB(false, false, true);
+    else PS_RB(false, false, false);
+  }
+#undef PS_RB
+}
+
 template <int PLANES, bool XB = false, bool YB = false>
 static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
   const bool stats = a.ostats != nullptr, res = a.res != nullptr;
@@ -1523,48 +1572,15 @@ static void bf16_launch(const BfArgs& a, int N, bool tr, hipStream_t stream) {
     // per CU.  Same-box comparison in the benchmark's step (profiles/r04_gemm_kernels_same_box.txt), out / in / pointwise:
     // 176.0 / 108.0 / 70.7 us against 179.0 / 111.7 / 76.6 for the interleaved kernel.  ps_debug_flags bit 22 keeps the
     // interleaved kernel (tests run both).
-    if constexpr (PLANES == 2 && !XB && !YB) if (!(g_debug_flags & ((1 << 22) | 128)) && a.K % 32 == 0 && a.M % 256 == 0) {
-      // two 256-thread workgroups per CU, each on tiles of 256 x 128 (the m-tiles of a frame tile back to back)
-      const long long ntiles = (long long)a.tiles_t * a.tiles_m * N;
-      const int Gr = (int)(ntiles < 2 * cus ? ntiles : 2 * cus);
-      const long long pw = (ntiles + Gr - 1) / Gr, pu = (long long)a.tiles_t * a.tiles_m;
-      if ((pw + pu - 2) / pu + 1 <= PP_MAXU) {
-        BfArgs& b = const_cast<BfArgs&>(a);
-        b.groups = Gr / 2;                  // workgroups from here on start late ...
-#ifndef RB_DELAY_RES
-#define RB_DELAY_RES 0
-#endif
-#ifndef RB_DELAY_ST
-#define RB_DELAY_ST 0
-#endif
-        b.delay = (a.ksteps / 2) * (res ? RB_DELAY_RES : RB_DELAY_ST);  // ... by about half a K loop (cycles per K-step)
-        // two m-tiles: workgroups 8 apart share a run of frame tiles, one m-tile each (see the kernel); needs an even grid
-        // whose halves get whole, equal runs
-        b.pair_r = (a.tiles_m == 2 && Gr % 16 == 0 && !(g_debug_flags & 64)) ? 1 : 0;
-        if (b.pair_r) {  // (a pair's run of frame tiles must stay within PP_MAXU utterances too)
-          const long long fr = (long long)a.tiles_t * N, pw2 = (fr + Gr / 2 - 1) / (Gr / 2);
-          if ((pw2 + a.tiles_t - 2) / a.tiles_t + 1 > PP_MAXU) b.pair_r = 0;
-        }
-#ifdef PS_TUNE
-        if (const char* v = getenv("PS_RB_DELAY")) b.delay = atoi(v) * (a.ksteps / 2);
-#endif
-#define PS_RB(TRV, STV, RSV) \
-  hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<TRV, STV, RSV>), dim3(Gr, 1), dim3(256), 0, stream, a)
-        if (tr) {
-          if (stats) PS_RB(true, true, false);
-          else if (res) PS_RB(true, false, true);
-          else PS_RB(true, false, false);
-        } else {
-          if (stats) PS_RB(false, true, false);
-          else if (res) PS_RB(false, false, true);
-          else PS_RB(false, false, false);
-        }
-#undef PS_RB
+    if constexpr (PLANES == 2 && !XB && !YB) if (!(g_debug_flags & ((1 << 22) | 128))) {
+      int Gr = 0;
+      if (rb_ok(a, N, &Gr)) {
+        rb_launch<false>(a, N, tr, Gr, stream);
         return;
       }
     }
 #define PS_IL(TRV, STV, RSV) \
-  hipLaunchKernelGGL((conv1x1_bf16_il_kernel<PLANES, TRV, STV, RSV, XB, (YB && !RSV)>), dim3(G, 1), dim3(512), 0, stream, a)
+  hipLaunchKernelGGL((conv1x1_bf16_il_kernel<PLANES, TRV, STV, RSV, XB, YB>), dim3(G, 1), dim3(512), 0, stream, a)
     if (tr) {
       if (stats) PS_IL(true, true, false);
       else if (res) PS_IL(true, false, true);
@@ -1656,6 +1672,27 @@ extern "C" int ps_conv1x1_f16x2_f32(const float* x, const void* wt_planes, const
   return split_gemm(x, 0, wt_planes, rng, y, 0, N, K, M, T, ldt, 2, pro, bias, bias_n, res, ostats, stream);
 }
 
+extern "C" int ps_conv1x1_f16_rows_ok(int N, int K, int M, int T) {
+  if (N <= 0 || K <= 0 || M <= 0 || T <= 0) return 0;
+  BfArgs a{};
+  a.K = K, a.M = M, a.T = T;
+  a.ksteps = (K + XB_K - 1) / XB_K;
+  a.tiles_t = (T + XB_T - 1) / XB_T;
+  a.tiles_m = (M + XB_M - 1) / XB_M;
+  return rb_ok(a, N, nullptr) ? 1 : 0;
+}
+
+extern "C" int ps_conv1x1_f16_rows(const void* x, const void* wt_planes, const ps_f16x2_range* rng, void* y, int N, int K,
+                                   int M, int T, int ldt, const ps_prologue* pro, const float* bias, const float* bias_n,
+                                   const void* res, double* ostats, void* stream) {
+  if (!rng || rng->w_exp < -100 || rng->w_exp > 100 || rng->x_bound < 0.f || (rng->x_amax && rng->x_amax_parts <= 0) ||
+      (!(rng->x_bound > 0.f) && !rng->x_amax)) {
+    set_error("ps_conv1x1_f16_rows: range descriptor missing or incomplete (w_exp within +-100 and x_bound > 0 or x_amax)");
+    return PS_E_INVALID;
+  }
+  return split_gemm(x, 1, wt_planes, rng, y, 1, N, K, M, T, ldt, 2, pro, bias, bias_n, (const float*)res, ostats, stream);
+}
+
 // partial maxima of |x| per utterance for the fp16x2 GEMM's range: [N][PS_ABSMAX_PARTS]
 constexpr int kAbsmaxParts = 64;
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T,
@@ -1702,12 +1739,9 @@ static int split_gemm(const void* x_any, int x_bf16, const void* wt_planes, cons
                       const float* bias, const float* bias_n, const float* res, double* ostats, void* stream) {
   const float* x = (const float*)x_any;
   float* y = (float*)y_any;
-  if ((x_bf16 || y_bf16) && planes != 1) {
+  const bool rows16 = planes == 2 && x_bf16 && y_bf16;  // ps_conv1x1_f16_rows
+  if ((x_bf16 || y_bf16) && planes != 1 && !rows16) {
     set_error("ps_conv1x1_bf16_io: bf16 activation rows go with planes = 1 (got %d)", planes);
-    return PS_E_UNSUPPORTED;
-  }
-  if (y_bf16 && res) {
-    set_error("ps_conv1x1_bf16_io: a bf16 output cannot take the fp32 residual");
     return PS_E_UNSUPPORTED;
   }
   if (!x || !wt_planes || !y || N <= 0 || K <= 0 || M <= 0 || T <= 0 || N > 65535) {
@@ -1780,7 +1814,16 @@ static int split_gemm(const void* x_any, int x_bf16, const void* wt_planes, cons
       a.x_amax = rng->x_bound > 0.f ? nullptr : rng->x_amax;
       a.x_amax_parts = rng->x_amax_parts;
       a.y_amax = rng->y_amax;
-      bf16_launch<2>(a, N, tr, st);
+      if (rows16) {
+        int Gr = 0;
+        if (!rb_ok(a, N, &Gr)) {
+          set_error("ps_conv1x1_f16_rows: this launch cannot run on the register-B kernel (ps_conv1x1_f16_rows_ok)");
+          return PS_E_UNSUPPORTED;
+        }
+        rb_launch<true>(a, N, tr, Gr, st);
+      } else {
+        bf16_launch<2>(a, N, tr, st);
+      }
     } else if (planes == 3)
       bf16_launch<3>(a, N, tr, st);
     else if (a.x_bf16 && a.y_bf16)

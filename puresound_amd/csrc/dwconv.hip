@@ -234,7 +234,9 @@ constexpr int DWW_SEG = DW_FRAMES + 256;  // frames per LDS strip (64 * DWW_NV p
                                           // that EIGHT workgroups -- all 2048 of a 32 x 256 x 3999 launch at once -- fit a CU
 constexpr int DWW_NV = 5;                     // 16-byte pieces per lane: 4 + halo
 
-template <bool ALIGNED>
+// B16: the rows of x AND y are bf16 in HBM (round 4: the hidden maps of a block whose activation rows are all bf16); the
+// LDS strip and the arithmetic stay fp32, a piece is 8 bytes per lane instead of 16.
+template <bool ALIGNED, bool B16 = false>
 __global__ __launch_bounds__(256, 8) void dwconv_wave_kernel(DwArgs a) {
   __shared__ __attribute__((aligned(16))) float strip[4][DWW_SEG];
   double* const red = reinterpret_cast<double*>(&strip[0][0]);  // the two reductions run before / after the strips are in use
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256, 8) void dwconv_wave_kernel(DwArgs a) {
 #pragma unroll
     for (int k = 0; k < DWW_NV; ++k) {
       const int idx = k * 64 + lane, f = org + idx * 4;
-      v[q][k] = (idx < nvec && f >= 0 && f < a.T) ? *reinterpret_cast<const f32x4*>(a.x + row + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[q][k] = (idx < nvec && f >= 0 && f < a.T) ? dw_load4<B16>(a.x, row + f) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   using q0 = std::integral_constant<int, 0>;
@@ -338,7 +340,14 @@ __global__ __launch_bounds__(256, 8) void dwconv_wave_kernel(DwArgs a) {
                 fsq += out[e] * out[e];
               }
           }
-          *reinterpret_cast<f32x4*>(a.y + ((size_t)n * a.H + h) * a.ldt + t) = out;
+          if constexpr (B16) {
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __builtin_bit_cast(unsigned short, (__bf16)out[e]);
+            *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(a.y) + ((size_t)n * a.H + h) * a.ldt + t) = o;
+          } else {
+            *reinterpret_cast<f32x4*>(a.y + ((size_t)n * a.H + h) * a.ldt + t) = out;
+          }
         }
       }
     }
@@ -436,7 +445,12 @@ extern "C" int ps_dwconv_io(const void* x_any, int x_bf16, const float* w, const
     LaunchTimer timer("dwconv", (hipStream_t)stream);
     hipStream_t st = (hipStream_t)stream;
     const bool small = (P - 1) * dilation + 8 <= DW_SMALLHALO;
-    if (x_bf16 || y_bf16) {
+    const bool wave_ok = P == 3 && 2 * dilation <= 256 &&
+                         DW_FRAMES / 4 + ((left + 3) / 4 * 4 + 2 * dilation - left + 3) / 4 <= 64 * DWW_NV && !(g_debug_flags & 1);
+    if (x_bf16 && y_bf16 && wave_ok) {  // (bit 0 keeps the workgroup-synchronised kernel: tests run both)
+      if (aligned) hipLaunchKernelGGL((dwconv_wave_kernel<true, true>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dwconv_wave_kernel<false, true>), grid, dim3(256), 0, st, a);
+    } else if (x_bf16 || y_bf16) {
       if (P != 3 || !small) {
         set_error("ps_dwconv_io: bf16 rows are built for P = 3 with (P-1)*dilation <= %d", DW_SMALLHALO - 8);
         return PS_E_UNSUPPORTED;

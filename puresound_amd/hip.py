@@ -267,6 +267,8 @@ def conv1x1_bf16(x: torch.Tensor, t: int, wt_planes: torch.Tensor, m: int, pro: 
     n, k, ldt = x.shape
     planes = wt_planes.shape[2]
     y = out if out is not None else torch.empty(n, m, ldt, dtype=out_dtype, device=x.device)
+    if res is not None and res.dtype != y.dtype:
+        raise ValueError(f"conv1x1_bf16: the residual rows must have the output's dtype ({y.dtype}), got {res.dtype}")
     stats = None
     if want_stats:
         parts = lib().ps_conv1x1_stats_parts(m, t)
@@ -711,12 +713,26 @@ def l2_normalize(dvec: torch.Tensor) -> torch.Tensor:
 
 def conv_tasnet(blocks: "C.Array[TcnBlock]", n_blocks: int, x_pad: torch.Tensor, t: int, c: int, h: int,
                 dvec: Optional[torch.Tensor], embed_norm: bool,
-                workspace: Optional[torch.Tensor] = None, x_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+                workspace: Optional[torch.Tensor] = None, x_amax: Optional[torch.Tensor] = None,
+                bf16_rows: bool = False) -> torch.Tensor:
     """Run the whole masker on padded input [N,C,ldt]; returns padded mask logits [N,C,ldt] (the frames beyond T are
     not written).  x_amax [N, parts]: per utterance, values whose maximum bounds |x_pad[n]| -- the range blocks in the
     fp16x2 arithmetic scale their input by (without it they measure it with one pass over x_pad)."""
-    require_device(x_pad, "conv_tasnet")
+    require_device(x_pad, "conv_tasnet", allow_bf16=True)
     n, _, ldt = x_pad.shape
+    if bf16_rows and x_pad.dtype == torch.float32:
+        # fp32 rows in, fp32 rows out, the residual stream in between as bf16 rows (two dtype casts around the stack)
+        return conv_tasnet(blocks, n_blocks, x_pad.to(torch.bfloat16), t, c, h, dvec, embed_norm, workspace).float()
+    if x_pad.dtype == torch.bfloat16:
+        # the residual stream as bf16 rows (BASELINE config 3's arithmetic): every block in the bf16 arithmetic
+        need = lib().ps_conv_tasnet_workspace_bytes(n, c, h, t)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.zeros(need, dtype=torch.uint8, device=x_pad.device)
+        out = torch.empty_like(x_pad)
+        check(lib().ps_conv_tasnet_bf16_rows(blocks, n_blocks, ptr(x_pad), ptr(out), ptr(dvec), int(embed_norm), n, t, ldt,
+                                             ptr(workspace), workspace.numel(), stream_ptr(x_pad.device)),
+              "ps_conv_tasnet_bf16_rows")
+        return out
     need = lib().ps_conv_tasnet_workspace_bytes(n, c, h, t)
     if workspace is None or workspace.numel() < need:
         workspace = torch.zeros(need, dtype=torch.uint8, device=x_pad.device)

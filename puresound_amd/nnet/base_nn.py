@@ -364,7 +364,7 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
                         ws = torch.zeros(need, dtype=torch.uint8, device=x.device)
                         object.__setattr__(self, "_spk_workspace", ws)
                     x = hip.conv_tasnet(blocks, len(plans), x, t, run[0].in_channels, run[0].hid_channels, None, False,
-                                        workspace=ws, x_amax=x_amax)
+                                        workspace=ws, x_amax=x_amax, bf16_rows=all(p["rows_bf16"] for p in plans))
                 else:
                     for m in run:
                         x = m.forward_padded_staged(x, t, None)

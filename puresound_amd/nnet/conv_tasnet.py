@@ -85,6 +85,9 @@ class TCN(_PlanCache, nn.Module):
     #: with gemm_precision "bf16": keep the block's hidden maps (y1, y2, y3 inside the fused driver's workspace) as
     #: bf16 rows -- BASELINE's "bf16" configurations name bf16 storage with fp32 accumulation.  False: fp32 rows.
     hidden_bf16 = True
+    #: with gemm_precision "bf16" and hidden_bf16: the residual stream between the blocks of a fused stack is bf16 rows as
+    #: well (ps_conv_tasnet_bf16_rows) -- "bf16 storage / fp32 accumulate" for every activation row of the stack
+    stream_bf16 = True
 
     def gemm_planes_for_plan(self) -> int:
         """ps_tcn_block.gemm_planes this block runs with: its gemm_precision, unless the block cannot take it."""
@@ -104,7 +107,7 @@ class TCN(_PlanCache, nn.Module):
     def plan(self, device: torch.device) -> dict:
         planes = self.gemm_planes_for_plan()
         hb = bool(self.hidden_bf16) and planes == 1 and self.kernel == 3 and 2 * self.dilation + 8 <= 288
-        sig = (_param_signature(self), str(device), planes, hb)
+        sig = (_param_signature(self), str(device), planes, hb, bool(self.stream_bf16))
         if self._plan is not None and self._plan_sig == sig:
             return self._plan
         if self.training and self.dconv[1].p > 0:
@@ -146,6 +149,7 @@ class TCN(_PlanCache, nn.Module):
         b.E = self.emb_dim
         b.gemm_planes = planes
         b.hidden_bf16 = int(hb)
+        rows_bf16 = bool(hb and self.stream_bf16)
         if planes == 2:
             assert fused and kinds["dw"] == PS_NORM_GLOBAL and kinds["pw"] == PS_NORM_GLOBAL
             for i, (key, wsrc) in enumerate((("in_wb", w_in[:, :c, 0]),
@@ -162,11 +166,23 @@ class TCN(_PlanCache, nn.Module):
             t["in_wb"] = hip.pack_wt_bf16(w_in[:, :c, 0], planes)
             t["pw_wb"] = hip.pack_wt_bf16(dsc.pointwise[0].weight.detach().to(**f32), planes)
             t["out_wb"] = hip.pack_wt_bf16(self.out_conv.weight.detach().to(**f32), planes)
+            if rows_bf16 and fused and kinds["dw"] == PS_NORM_GLOBAL and kinds["pw"] == PS_NORM_GLOBAL:
+                # bf16 residual stream: large launches run ps_conv1x1_f16_rows (bf16 rows, one fp16 product) -- the fp16
+                # images of the weights and the bounds of the normalised activations, as for "fp16x2"
+                for i, (key, wsrc) in enumerate((("in_wf", w_in[:, :c, 0]),
+                                                 ("pw_wf", dsc.pointwise[0].weight.detach().to(**f32)),
+                                                 ("out_wf", self.out_conv.weight.detach().to(**f32)))):
+                    t[key], b.w_exp[i] = hip.pack_wt_f16x2(wsrc)
+                fd = max(1.0, abs(float(t["dw_slope"][0])))
+                fp = max(1.0, abs(float(t["pw_slope"][0])))
+                b.dw_gmax, b.dw_bmax = float(t["dw_gamma"].abs().max()) * fd, float(t["dw_beta"].abs().max()) * fd
+                b.pw_gmax, b.pw_bmax = float(t["pw_gamma"].abs().max()) * fp, float(t["pw_beta"].abs().max()) * fp
         for k, v in t.items():
             setattr(b, k, ptr(v))
         _PLAN_SERIAL[0] += 1
         # tensors kept alive alongside the raw pointers
-        self._plan = {"block": b, "tensors": t, "serial": _PLAN_SERIAL[0], "kinds": kinds, "fused": fused}
+        self._plan = {"block": b, "tensors": t, "serial": _PLAN_SERIAL[0], "kinds": kinds, "fused": fused,
+                      "rows_bf16": rows_bf16}
         self._plan_sig = sig
         return self._plan
 
@@ -446,9 +462,10 @@ class ConvTasNet(_PlanCache, nn.Module):
         ws = self._workspace.get(lane)
         if ws is None or ws.numel() < need or ws.device != x_pad.device:
             ws = self._workspace[lane] = torch.zeros(need, dtype=torch.uint8, device=x_pad.device)
+        rows_bf16 = all(m.plan(x_pad.device)["rows_bf16"] for stack in self.tcn_list for m in stack)
         return hip.conv_tasnet(blocks, n_blocks, x_pad, t, self.input_dim, self.tcn_dim,
                                None if dvec is None else dvec.contiguous().float(),
-                               bool(self.embed_norm), ws, x_amax)
+                               bool(self.embed_norm), ws, x_amax, bf16_rows=rows_bf16)
 
     def _forward_staged(self, x: torch.Tensor, t: int, dvec: Optional[torch.Tensor]) -> torch.Tensor:
         """Normal TCN blocks with a cLN somewhere: block by block, stage by stage."""

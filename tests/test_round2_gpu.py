@@ -337,9 +337,16 @@ def test_dwconv_bf16_rows(dev, dil, causal):
     left = 2 * dil if causal else dil
     xp = H.pad_rows(x.to(dev))
     y_ref, st_ref = H.dwconv(xp, t, w.to(dev), b.to(dev), dil, left, pro, True)
-    for xb, yb in ((True, True), (True, False), (False, True)):
-        y, st = H.dwconv(xp.bfloat16() if xb else xp, t, w.to(dev), b.to(dev), dil, left, pro, True,
-                         out_dtype=torch.bfloat16 if yb else torch.float32)
+    # (True, True) twice: the wave-private kernel (round 4: bf16 rows there too) and, with ps_debug_flags bit 0, the
+    # workgroup-synchronised one
+    for xb, yb, flags in ((True, True, 0), (True, True, 1), (True, False, 0), (False, True, 0)):
+        old = _abi.lib().ps_debug_flags(flags)
+        try:
+            y, st = H.dwconv(xp.bfloat16() if xb else xp, t, w.to(dev), b.to(dev), dil, left, pro, True,
+                             out_dtype=torch.bfloat16 if yb else torch.float32)
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
         # (the instantiations may contract their multiply-adds differently: equal to one fp32 rounding, i.e. the bf16
         #  results differ in at most the last bit of a few elements)
         if yb:
