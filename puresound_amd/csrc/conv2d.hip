@@ -11,6 +11,8 @@
 // needed by exactly one wave and goes from global memory to its lane without LDS.  The k -> (source row, time shift)
 // table of this fo lives in LDS.  Weights come from the packed transposed layout of ps_conv1x1_f32 (L2 resident).
 // Eval BatchNorm2d is folded into W / bias by the caller; the activation is the epilogue.
+#include <type_traits>
+
 #include "ps_common.h"
 
 namespace ps {
@@ -41,8 +43,10 @@ __device__ __forceinline__ float act_apply(float u, int kind, float s) {
 
 template <int MB>
 __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
-  __shared__ int tab_off[C2D_MAXK];    // element offset of the source row inside the utterance (bit 30: second source), -1 = zero row
-  __shared__ int tab_shift[C2D_MAXK];  // frame shift
+  // dynamic LDS, 2 * Kp ints (round 4: the static 32 KiB tables held a CU to five workgroups whatever K was)
+  extern __shared__ int c2d_tab[];
+  int* const tab_off = c2d_tab;            // element offset of the source row inside the utterance (bit 30: second source), -1 = zero row
+  int* const tab_shift = c2d_tab + a.Kp;  // frame shift
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 31, lk = lane >> 5;
   const int t0 = blockIdx.x * 128, fo = blockIdx.y;
@@ -81,9 +85,13 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
 
+  // Operands of C2D_UN k-pairs per batch; the loads of batch i + 1 are issued before the MFMAs of batch i (round 4: with
+  // load -> wait -> MFMA in sequence the kernel ran at a third of the fp32 MFMA rate, every wave waiting out an L2 round
+  // trip per batch).
   const int npairs = a.Kp / 2;
-  for (int p0 = 0; p0 < npairs; p0 += C2D_UN) {
-    float av[C2D_UN][MB], bv[C2D_UN];
+  float av[2][C2D_UN][MB], bv[2][C2D_UN];
+  auto fetch = [&](int p0, auto buf_c) {
+    constexpr int buf = decltype(buf_c)::value;
 #pragma unroll
     for (int u = 0; u < C2D_UN; ++u) {
       const int k = 2 * (p0 + u) + lk;  // Kp is a multiple of 16 = 2 * C2D_UN: always < Kp
@@ -93,17 +101,32 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
       const float* src = (off & (1 << 30)) ? x2n : x1n;
       const int idx = ok ? (off & ((1 << 30) - 1)) + ti : 0;
       const float v = src[idx];   // unconditional load of a valid address, masked afterwards
-      bv[u] = ok ? v : 0.f;
+      bv[buf][u] = ok ? v : 0.f;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const int m = m0 + 32 * mb + lr;  // the packed weight is zero padded to 256 rows per tile
-        av[u][mb] = a.wt[((size_t)(m >> 8) * a.Kp + k) * 256 + (m & 255)];
+        av[buf][u][mb] = a.wt[((size_t)(m >> 8) * a.Kp + k) * 256 + (m & 255)];
       }
     }
+  };
+  auto multiply = [&](auto buf_c) {
+    constexpr int buf = decltype(buf_c)::value;
 #pragma unroll
     for (int u = 0; u < C2D_UN; ++u)
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mb], bv[u], acc[mb], 0, 0, 0);
+      for (int mb = 0; mb < MB; ++mb)
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][mb], bv[buf][u], acc[mb], 0, 0, 0);
+  };
+  using b0 = std::integral_constant<int, 0>;
+  using b1 = std::integral_constant<int, 1>;
+  fetch(0, b0{});
+  for (int p0 = 0; p0 < npairs; p0 += 2 * C2D_UN) {
+    if (p0 + C2D_UN < npairs) fetch(p0 + C2D_UN, b1{});
+    multiply(b0{});
+    if (p0 + C2D_UN < npairs) {
+      if (p0 + 2 * C2D_UN < npairs) fetch(p0 + 2 * C2D_UN, b0{});
+      multiply(b1{});
+    }
   }
 
   const float s = a.slope ? a.slope[0] : 0.f;
@@ -158,12 +181,13 @@ extern "C" int ps_conv2d_f32(const float* x1, int C1, const float* x2, int C2, c
   dim3 grid(ld / 128, Fout, N * mtiles);
   {
     LaunchTimer timer("conv2d", (hipStream_t)stream);
+    const size_t lds = (size_t)2 * Kp * sizeof(int);
     if (mb == 1)
-      hipLaunchKernelGGL((conv2d_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      hipLaunchKernelGGL((conv2d_kernel<1>), grid, dim3(256), lds, (hipStream_t)stream, a);
     else if (mb == 2)
-      hipLaunchKernelGGL((conv2d_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      hipLaunchKernelGGL((conv2d_kernel<2>), grid, dim3(256), lds, (hipStream_t)stream, a);
     else
-      hipLaunchKernelGGL((conv2d_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      hipLaunchKernelGGL((conv2d_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

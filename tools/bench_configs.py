@@ -109,6 +109,22 @@ def cfg4(dev, steps=10, warmup=3, batch=32, gemm="fp32", graph=True):
     return out
 
 
+def ns_dpcrn(dev, steps=3, warmup=2, batch=32, gemm="fp16x2"):
+    """The real egs/ns model (ns_dpcrn_v0_causal, egs/ns/model.py:40-82: conv-STFT 512/128 + DPCRN(1,32,32,32,64,128; H=128)
+    + complex mask + iSTFT), batch x 4 s; `gemm` = arithmetic of the LSTM input projections and linear layers."""
+    model = _build("ns_dpcrn_short", dev)
+    noisy = _waves(batch, 1234, dev)
+    out = {"workload": f"ns_dpcrn_v0_causal, {batch} x 4 s, 1 GPU, fp32 rows", "steps": steps}
+    model.masker.set_gemm_precision("fp32")
+    ref = model.inference(noisy)
+    for prec in ("fp32", gemm):
+        model.masker.set_gemm_precision(prec)
+        ms, y = _timed(lambda: model.inference(noisy), steps, warmup)
+        out[prec] = {"ms": ms, "samples_s": batch * L / ms * 1e3,
+                     "l2_rel_vs_fp32": float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref))}
+    return out
+
+
 def cfg5(dev, chunks=500, streams=64, warmup=10):
     """Demo preset (egs/tse/demo/utils.py:51-72), `streams` concurrent streams, 320-sample chunks, one hipGraph per chunk."""
     from detweights import det_state_dict
