@@ -241,6 +241,10 @@ int ps_real_mask_f32(const float* feats, const float* mask, float* out, int64_t 
  * kind 3: power + 1e-8 -- ConvMelSpectrogram's "Magnitude" input to the mel projection, lobe/encoder.py:529-536);
  * y is [N][half-drop_first][ldt]. */
 int ps_magnitude_f32(const float* x, float* y, int N, int half, int drop_first, int kind, int T, int ldt, void* stream);
+/* SpecAugment's masked fill (/root/reference/puresound/nnet/lobe/trivial.py:306-335: the span itself comes from
+ * torchaudio.functional.mask_along_axis' two host-side random draws): y = x [N][rows][ld] with rows [lo, hi) of every
+ * utterance (axis = 1) or frames [lo, hi) of every row (axis = 2) replaced by `value`; ld % 4 == 0, x == y allowed. */
+int ps_fill_span_f32(const float* x, float* y, int N, int rows, int ld, int axis, int lo, int hi, float value, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 2-D convolutional maskers (Unet / UnetTcn / DPCRN: unet.py:13-557, dpcrn.py:11-213).  A 4-D activation

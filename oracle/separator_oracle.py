@@ -428,6 +428,25 @@ def magnitude(x: torch.Tensor, drop_first: bool = True, log1p: bool = False) -> 
     return torch.log1p(mag) if log1p else mag
 
 
+def spec_augment(x: torch.Tensor, freq_mask: int, time_mask: int, value: float) -> torch.Tensor:
+    """SpecAugment (lobe/trivial.py:306-335) = torchaudio.functional.mask_along_axis per masked axis (torchaudio >= 0.9,
+    unpinned in requirements.txt:4; absent from this image): two draws from the global generator per axis --
+    value = rand(1) * mask_param, min_value = rand(1) * (size - value) -- span [long(min_value), long(min_value) +
+    long(value)), the same span for every item of the batch, filled with `value`."""
+    x = x.clone()
+    for axis, param in ((1, freq_mask), (2, time_mask)):
+        if param == 0:
+            continue
+        v = torch.rand(1) * param
+        m = torch.rand(1) * (x.shape[axis] - v)
+        lo, hi = int(m.long()), int(m.long()) + int(v.long())
+        if axis == 1:
+            x[:, lo:hi, :] = value
+        else:
+            x[:, :, lo:hi] = value
+    return x
+
+
 def speaker_embedding(enroll_feats: torch.Tensor, sd: SD, spk: dict, p: str = "speaker_net.") -> torch.Tensor:
     """Speaker nets of the TSE presets (egs/tse/model.py:118-135, 228-238; base_nn.py:697-705): optional Magnitude,
     n_tcn TCN or GatedTCN blocks, attentive stats pooling, Conv1d(2C->E,1,bias=False), squeeze(-1)."""
@@ -436,6 +455,9 @@ def speaker_embedding(enroll_feats: torch.Tensor, sd: SD, spk: dict, p: str = "s
     if spk.get("magnitude", False):
         x = magnitude(x, drop_first=False)
         off = 1                                   # the parameter-free lobe still occupies ModuleList index 0
+    if spk.get("specaug"):
+        x = spec_augment(x, *spk["specaug"])
+        off = 1
     if spk.get("block") == "rnn":
         # tse_skim_v1_causal (egs/tse/model.py:487-502): SingleRNN (lobe/rnn.py:9-55) -> ASP -> Conv1d
         from . import dualpath_oracle as DP

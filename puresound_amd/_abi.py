@@ -112,6 +112,7 @@ SIGNATURES = {
     "ps_conv2d_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 16 + [_vp, _vp]),
     "ps_activation_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "ps_magnitude_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 6 + [_vp]),
+    "ps_fill_span_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 6 + [C.c_float, _vp]),
     "ps_real_mask_f32": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "ps_norm_activation_f32": (C.c_int, [_vp, C.POINTER(Prologue), C.c_double, C.c_double, C.c_int, C.c_int, _vp]
                                + [C.c_int] * 4 + [_vp]),

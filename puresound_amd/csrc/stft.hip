@@ -273,3 +273,41 @@ extern "C" int ps_magnitude_f32(const float* x, float* y, int N, int half, int d
   return 0;
 }
 
+// SpecAugment's masked fill (lobe/trivial.py:306-335 of the reference: torchaudio.functional.mask_along_axis picks the
+// span on the host, this writes it): rows [lo, hi) of every utterance (axis 1) or frames [lo, hi) of every row (axis 2) of
+// y [N][rows][ld] := x with that span replaced by `value`.
+namespace ps {
+__global__ __launch_bounds__(256) void fill_span_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int ld,
+                                                        int axis, int lo, int hi, float value, long long total) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= total) return;
+  const int t = (int)(i % ld), r = (int)((i / ld) % rows);
+  f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+  if (axis == 1) {
+    if (r >= lo && r < hi) v = f32x4{value, value, value, value};
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (t + e >= lo && t + e < hi) v[e] = value;
+  }
+  *reinterpret_cast<f32x4*>(y + i) = v;
+}
+}  // namespace ps
+
+extern "C" int ps_fill_span_f32(const float* x, float* y, int N, int rows, int ld, int axis, int lo, int hi, float value,
+                                void* stream) {
+  if (!x || !y || N <= 0 || rows <= 0 || ld <= 0 || ld % 4 || (axis != 1 && axis != 2) || lo < 0 || hi < lo) {
+    set_error("ps_fill_span_f32: bad argument (N=%d rows=%d ld=%d axis=%d span=[%d,%d))", N, rows, ld, axis, lo, hi);
+    return PS_E_INVALID;
+  }
+  const long long total = (long long)N * rows * ld;
+  LaunchTimer timer("fill_span", (hipStream_t)stream);
+  hipLaunchKernelGGL(ps::fill_span_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     rows, ld, axis, lo, hi, value, total);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("ps_fill_span_f32: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}

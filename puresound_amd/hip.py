@@ -596,6 +596,16 @@ def real_mask(feats: torch.Tensor, mask: torch.Tensor, mask_act: str = "linear")
     return out
 
 
+def fill_span(x: torch.Tensor, axis: int, lo: int, hi: int, value: float) -> torch.Tensor:
+    """[N, rows, ld] -> a copy with rows [lo, hi) (axis 1) or frames [lo, hi) (axis 2) set to `value` (SpecAugment)."""
+    require_device(x, "fill_span")
+    n, rows, ld = x.shape
+    y = torch.empty_like(x)
+    check(lib().ps_fill_span_f32(ptr(x), ptr(y), n, rows, ld, axis, int(lo), int(hi), float(value), stream_ptr(x.device)),
+          "ps_fill_span_f32")
+    return y
+
+
 def magnitude(x: torch.Tensor, t: int, drop_first: bool, log1p: bool, kind: Optional[str] = None) -> torch.Tensor:
     """[re rows; im rows] padded [N,2H,ldt] -> |.| (or log1p|.|, or the power with kind="power"/"power_eps")
     padded [N,H-drop,ldt]."""

@@ -7,7 +7,7 @@ from .conv_tasnet import TCN, ConvTasNet, GatedTCN
 from .dprnn import DPRNN
 from .lobe.encoder import ConvEncDec, FbankEnc, FreeEncDec
 from .lobe.pooling import AttentiveStatisticsPooling
-from .lobe.trivial import FiLM, Gate, Magnitude
+from .lobe.trivial import FiLM, Gate, Magnitude, SpecAugment
 from .skim import MemLSTM, SegLSTM, SkiM
 from .unet import Unet, UnetTcn
 from .dpcrn import DPCRN, DPRNNblock2D
@@ -29,4 +29,4 @@ NS = _Namespace(SoTaskWrapModule=SoTaskWrapModule, SiMoTaskWrapModule=SiMoTaskWr
                      ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                      AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM, MemLSTM=MemLSTM, Unet=Unet, UnetTcn=UnetTcn,
                 DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, DPARN=DPARN, DPARNblock2D=DPARNblock2D,
-                MhaSelfAttenLayer=MhaSelfAttenLayer, SingleRNN=SingleRNN, Magnitude=Magnitude, FbankEnc=FbankEnc, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate, DepthwiseSeparableConv1d=DepthwiseSeparableConv1d)
+                MhaSelfAttenLayer=MhaSelfAttenLayer, SingleRNN=SingleRNN, Magnitude=Magnitude, SpecAugment=SpecAugment, FbankEnc=FbankEnc, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate, DepthwiseSeparableConv1d=DepthwiseSeparableConv1d)

@@ -14,7 +14,7 @@ import torch.nn as nn
 from .. import hip
 from .._abi import TcnBlock
 from .conv_tasnet import TCN, ConvTasNet, GatedTCN
-from .lobe.trivial import Magnitude
+from .lobe.trivial import Magnitude, SpecAugment
 from .dprnn import DPRNN
 from .skim import SkiM
 from .unet import Unet
@@ -344,6 +344,9 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             elif isinstance(lay, Magnitude):
                 x = lay.forward_padded(x, t)
                 x_amax = None
+                i += 1
+            elif isinstance(lay, SpecAugment):   # tse_skim_v2_causal: masks even in eval mode, as the reference does
+                x = lay.forward_padded(x, t)
                 i += 1
             elif isinstance(lay, TCN):
                 run = []

@@ -49,6 +49,48 @@ class Magnitude(nn.Module):
         return hip.unpad_rows(self.forward_padded(hip.pad_rows(x), t), t)
 
 
+class SpecAugment(nn.Module):
+    """Random frequency / time masking of a spectrogram [N, F, T] (lobe/trivial.py:306-335).  The reference applies it
+    in eval mode too (its forward has no training switch), through torchaudio.functional.mask_along_axis; that function's
+    algorithm is restated here draw for draw -- per masked axis `value = torch.rand(1) * mask_param`,
+    `min_value = torch.rand(1) * (size - value)`, span [long(min_value), long(min_value) + long(value)), one span for the
+    whole batch, both draws from torch's global CPU generator -- so a seeded run masks what the reference masks.  The
+    fill itself is ps_fill_span_f32."""
+
+    def __init__(self, freq_mask_length: int, time_mask_length: int, fill_value: float) -> None:
+        super().__init__()
+        self.freq_mask = freq_mask_length
+        self.time_mask = time_mask_length
+        self.mask_value = fill_value
+
+    @staticmethod
+    def _span(size: int, mask_param: int):
+        value = torch.rand(1) * mask_param
+        min_value = torch.rand(1) * (size - value)
+        lo = int(min_value.long())
+        return lo, lo + int(value.long())
+
+    def forward_padded(self, x: torch.Tensor, t: int) -> torch.Tensor:
+        """[N, F, ld] rows with t valid frames."""
+        if self.freq_mask != 0:
+            lo, hi = self._span(x.shape[1], self.freq_mask)
+            x = hip.fill_span(x, 1, lo, hi, self.mask_value)
+        if self.time_mask != 0:
+            lo, hi = self._span(t, self.time_mask)
+            x = hip.fill_span(x, 2, lo, hi, self.mask_value)
+        return x
+
+    def apply_mask(self, x: torch.Tensor) -> torch.Tensor:
+        hip.require_device(x, "SpecAugment.forward")
+        if x.dim() != 3:
+            raise ValueError("SpecAugment: [N, F, T] input")
+        t = x.shape[-1]
+        return hip.unpad_rows(self.forward_padded(hip.pad_rows(x.float()), t), t)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.apply_mask(x)
+
+
 class _PerFrameCondition:
     """Streaming: the frames of the row are concurrent streams, each with its own embedding, so the embedding
     columns of the conditioning conv become a per-frame additive term [1, M, ldB] instead of a per-utterance bias.

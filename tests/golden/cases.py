@@ -139,6 +139,16 @@ CASES = {
                             block_with_embed=[1, 1, 1, 1], embed_fusion="FiLM")),
         speaker_net=dict(n_tcn=5, C=80, H=256, att=128, E=192),
         wrap=dict(mask_constraint="ReLU"), B=2, L=4000, L_enroll=3000, seed=1234),
+    # tse_skim_v2_causal verbatim (egs/tse/model.py:509-558): SpecAugment(10, 0, 0.0) in front of the speaker net.  The layer
+    # draws its mask from torch's global generator; generator and tests seed it with the case's seed before every pass.
+    "tse_skim_v2_short": dict(
+        kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
+        enc_spk=dict(kw=dict(trainable=False, output_format="Magnitude", n_banks=80)),
+        masker=dict(cls="SkiM", args=(128, 256, 128),
+                    kw=dict(n_blocks=4, seg_size=150, seg_overlap=False, causal=True, embed_dim=192, embed_norm=True,
+                            block_with_embed=[1, 1, 1, 1], embed_fusion="FiLM")),
+        speaker_net=dict(n_tcn=5, C=80, H=256, att=128, E=192, specaug=(10, 0, 0.0)),
+        wrap=dict(mask_constraint="ReLU"), B=2, L=4000, L_enroll=3000, seed=1234),
     "tse_skim_vad_short": dict(   # tse_skim_v0_causal_vad (egs/tse/model.py:560-606): sigmoid output, H = 64, 2 blocks
         kind="wrap", enc=dict(kind="free", win=32, hop=16, C=128, relu=True),
         masker=dict(cls="SkiM", args=(128, 64, 128),
@@ -390,8 +400,9 @@ def build_speaker_net(ns, s):
             + [ns.GatedTCN(s["C"], s["H"], 3, dilation=2 ** i, causal=False, tcn_norm="gLN") for i in range(s["n_tcn"])]
             + [ns.AttentiveStatisticsPooling(s["C"], s["att"]), nn.Conv1d(s["C"] * 2, s["E"], 1, bias=False)])
     return nn.ModuleList(
-        [ns.TCN(s["C"], s["H"], 3, dilation=2 ** i, causal=False, tcn_norm="gLN", dconv_norm="gGN")
-         for i in range(s["n_tcn"])]
+        ([ns.SpecAugment(*s["specaug"])] if s.get("specaug") else [])
+        + [ns.TCN(s["C"], s["H"], 3, dilation=2 ** i, causal=False, tcn_norm="gLN", dconv_norm="gGN")
+           for i in range(s["n_tcn"])]
         + [ns.AttentiveStatisticsPooling(s["C"], s["att"]), nn.Conv1d(s["C"] * 2, s["E"], 1, bias=False)])
 
 
@@ -484,7 +495,8 @@ def oracle_cfg(name):
         cfg["encoder_spk"] = dict(hop=c["enc_spk"]["kw"].get("hop_length", 128),
                                   trainable=c["enc_spk"]["kw"].get("trainable", True))
     if "speaker_net" in c:
-        cfg["speaker_net"] = {k: v for k, v in c["speaker_net"].items() if k in ("n_tcn", "block", "magnitude", "bidirectional")}
+        cfg["speaker_net"] = {k: v for k, v in c["speaker_net"].items()
+                              if k in ("n_tcn", "block", "magnitude", "bidirectional", "specaug")}
     return cfg
 
 

@@ -24,7 +24,23 @@ sys.dont_write_bytecode = True
 if "torchaudio" not in sys.modules:
     ta = types.ModuleType("torchaudio")
     taf = types.ModuleType("torchaudio.functional")
-    taf.mask_along_axis = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+
+    def _mask_along_axis(specgram, mask_param, mask_value, axis, p=1.0):
+        """torchaudio.functional.mask_along_axis as published (torchaudio 0.9 ... 2.x; requirements.txt:4 leaves the version
+        open): one span per call, drawn from the global generator, for the whole batch."""
+        if axis not in (1, 2):
+            raise ValueError("Only Frequency and Time masking are supported")
+        value = torch.rand(1) * mask_param
+        min_value = torch.rand(1) * (specgram.size(axis) - value)
+        mask_start = (min_value.long()).squeeze()
+        mask_end = (min_value.long() + value.long()).squeeze()
+        mask = torch.arange(0, specgram.shape[axis], device=specgram.device, dtype=specgram.dtype)
+        mask = (mask >= mask_start) & (mask < mask_end)
+        if axis == 1:
+            mask = mask.unsqueeze(-1)
+        return specgram.masked_fill(mask, mask_value)
+
+    taf.mask_along_axis = _mask_along_axis
     ta.functional = taf
     sys.modules["torchaudio"] = ta
     sys.modules["torchaudio.functional"] = taf
@@ -40,7 +56,7 @@ from puresound.streaming.skim_inference import StreamingSkiM  # noqa: E402
 from puresound.nnet.unet import Unet, UnetTcn  # noqa: E402
 from puresound.nnet.dpcrn import DPCRN  # noqa: E402
 from puresound.nnet.dparn import DPARN  # noqa: E402
-from puresound.nnet.lobe.trivial import Magnitude  # noqa: E402
+from puresound.nnet.lobe.trivial import Magnitude, SpecAugment  # noqa: E402
 from puresound.nnet.lobe.rnn import SingleRNN  # noqa: E402
 from puresound.nnet.lobe.cnn import DepthwiseSeparableConv1d  # noqa: E402
 
@@ -51,7 +67,7 @@ REF = cases.namespace(SoTaskWrapModule=SoTaskWrapModule, SiMoTaskWrapModule=SiMo
                       ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                       AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM,
                       StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN, DPARN=DPARN,
-                      Magnitude=Magnitude, FbankEnc=FbankEnc, SingleRNN=SingleRNN,
+                      Magnitude=Magnitude, SpecAugment=SpecAugment, FbankEnc=FbankEnc, SingleRNN=SingleRNN,
                       DepthwiseSeparableConv1d=DepthwiseSeparableConv1d)
 
 
@@ -68,7 +84,9 @@ def run_wrap(name, c):
     noisy = det_wave(c["seed"], c["B"], c["L"], c.get("amp", 0.5))
     enroll = det_wave(c["seed"] + 1, c["B"], c["L_enroll"]) if "L_enroll" in c else None
     out = {"n_params": np.int64(sum(p.numel() for p in model.parameters()))}
+    torch.manual_seed(c["seed"])  # (SpecAugment draws from the global generator; nothing else on the path does)
     wav = model.inference(noisy.clone(), None if enroll is None else enroll.clone())
+    torch.manual_seed(c["seed"])
     out["wav"] = wav.numpy()
     # step through the same reference methods to capture taps (base_nn.py:690-722)
     feats, enr = model._get_feature(noisy.clone(), None if enroll is None else enroll.clone())

@@ -40,6 +40,7 @@ def test_wrapper_inference_matches_reference(golden_dir, name):
     noisy = det_wave(c["seed"], c["B"], c["L"], c.get("amp", 0.5))
     enroll = det_wave(c["seed"] + 1, c["B"], c["L_enroll"]) if "L_enroll" in c else None
     taps = {}
+    torch.manual_seed(c["seed"])  # (SpecAugment -- tse_skim_v2_short -- draws its mask from the global generator)
     wav = O.inference(noisy, sd, cases.oracle_cfg(name), enroll, taps)
     assert wav.shape == g["wav"].shape
     edge = 16 if c["enc"]["kind"] == "stft" else 0  # iSTFT edges are ill-conditioned
