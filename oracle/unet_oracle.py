@@ -248,8 +248,9 @@ def multihead_attention(x: torch.Tensor, w_in: torch.Tensor, w_out: torch.Tensor
 
 
 def mha_self_atten_layer(x: torch.Tensor, sd: SD, p: str, heads: int, position_encoding: bool,
-                         causal: bool = False) -> torch.Tensor:
-    """MhaSelfAttenLayer.forward, improved=False (lobe/attention.py:180-232): x [B, C, L] -> [B, C, L]."""
+                         causal: bool = False, improved: bool = False, bidirectional: bool = False) -> torch.Tensor:
+    """MhaSelfAttenLayer.forward (lobe/attention.py:180-232): x [B, C, L] -> [B, C, L].  improved: the first
+    feed-forward Linear is an LSTM over the sequence (:170-183, :221-222)."""
     y = x.transpose(1, 2)
     src = y
     if position_encoding:
@@ -258,8 +259,13 @@ def mha_self_atten_layer(x: torch.Tensor, sd: SD, p: str, heads: int, position_e
     a = multihead_attention(y, sd[p + "self_atten.atten.in_proj_weight"], sd[p + "self_atten.atten.out_proj.weight"],
                             heads, causal)
     y = layer_norm(src + a, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
-    ff = linear(torch.relu(linear(y, sd[p + "feedforward.0.weight"], sd[p + "feedforward.0.bias"])),
-                sd[p + "feedforward.3.weight"], sd[p + "feedforward.3.bias"])
+    if improved:
+        from . import dualpath_oracle as DP
+        r, _ = DP.lstm(y, sd, p + "recurrent.", bidirectional)
+        ff = linear(torch.relu(r), sd[p + "feedforward.2.weight"], sd[p + "feedforward.2.bias"])
+    else:
+        ff = linear(torch.relu(linear(y, sd[p + "feedforward.0.weight"], sd[p + "feedforward.0.bias"])),
+                    sd[p + "feedforward.3.weight"], sd[p + "feedforward.3.bias"])
     return layer_norm(y + ff, sd[p + "norm2.weight"], sd[p + "norm2.bias"]).transpose(1, 2)
 
 

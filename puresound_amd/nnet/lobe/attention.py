@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from ... import hip
-from .._plans import PlanCache, _f32, layernorm_plan, linear_plan
+from .._plans import PlanCache, _f32, layernorm_plan, linear_plan, lstm_plan
 
 
 class PositionalEncoding(nn.Module):
@@ -76,16 +76,22 @@ class MhaSelfAttenLayer(PlanCache, nn.Module):
         self.norm2 = nn.LayerNorm(feats_dim)
 
     def _build(self, device):
-        if self.improved:
-            raise NotImplementedError("MhaSelfAttenLayer(improved=True) (LSTM feed-forward) is not on the HIP path")
-        if self.training and (self.self_atten_dropout.p > 0 or self.feedforward[2].p > 0):
+        drops = [m for m in [self.self_atten_dropout] + list(self.feedforward) if isinstance(m, nn.Dropout)]
+        if self.training and any(d.p > 0 for d in drops):
             raise RuntimeError("MhaSelfAttenLayer: dropout is active; the HIP path is inference only -- call .eval()")
         at = self.self_atten.atten
         p = dict(w_in=hip.pack_wt(_f32(at.in_proj_weight, device)),
                  out=dict(wt=hip.pack_wt(_f32(at.out_proj.weight, device)), M=self.feats_dim),
-                 norm1=layernorm_plan(self.norm1, device), ff1=linear_plan(self.feedforward[0], device),
-                 ff2=linear_plan(self.feedforward[3], device), norm2=layernorm_plan(self.norm2, device))
-        if self.position_encoding:
+                 norm1=layernorm_plan(self.norm1, device), norm2=layernorm_plan(self.norm2, device))
+        if self.improved:
+            # the "improved" transformer (lobe/attention.py:170-183): the first feed-forward Linear is an LSTM over the
+            # sequence -- input projection GEMM + ps_lstm_f32 -- then ReLU -> Linear as the second GEMM's prologue
+            p["rnn"] = lstm_plan(self.recurrent, device)
+            p["ff2"] = linear_plan(self.feedforward[2], device)
+        else:
+            p["ff1"] = linear_plan(self.feedforward[0], device)
+            p["ff2"] = linear_plan(self.feedforward[3], device)
+        if self.position_encoding and not self.improved:
             p["pe"] = _f32(self.pos.pe[:, 0, :], device)            # [max_len, E]
         return p
 
@@ -96,6 +102,10 @@ class MhaSelfAttenLayer(PlanCache, nn.Module):
         n, e, ld = x.shape
         new = lambda rows: torch.empty(n, rows, ld, dtype=torch.float32, device=x.device)  # noqa: E731
         src = x
+        if self.position_encoding and self.improved:
+            # the reference's forward calls self.pos whenever position_encoding is set, and the improved layer never builds
+            # it (lobe/attention.py:165-168, 199-200): the same AttributeError
+            raise AttributeError("'MhaSelfAttenLayer' object has no attribute 'pos'")
         if self.position_encoding:
             if length > p["pe"].shape[0]:
                 raise RuntimeError("sequence longer than the positional table")
@@ -105,7 +115,12 @@ class MhaSelfAttenLayer(PlanCache, nn.Module):
         n1 = p["norm1"]
         y, _ = hip.proj_layernorm(att, frames, p["out"]["wt"], None, e, n1["gamma"], n1["beta"], n1["eps"], src,
                                   res_inside=True)
-        h, _ = hip.conv1x1(y, frames, p["ff1"]["wt"], p["ff1"]["M"], None, p["ff1"]["bias"], out=new(p["ff1"]["M"]))
+        if self.improved:
+            rnn = p["rnn"]
+            gx, _ = hip.conv1x1(y, frames, rnn["wih"], rnn["rows"], None, rnn["bias"], out=new(rnn["rows"]))
+            h, _ = hip.lstm(gx, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, length, pos_stride, None, None, False, 0, None)
+        else:
+            h, _ = hip.conv1x1(y, frames, p["ff1"]["wt"], p["ff1"]["M"], None, p["ff1"]["bias"], out=new(p["ff1"]["M"]))
         n2 = p["norm2"]
         pro = hip.make_prologue(0, False, None, 0.0, 0.0, None, None, None, pre_relu=True)
         s, _ = hip.conv1x1(h, frames, p["ff2"]["wt"], e, pro, p["ff2"]["bias"], res=y, out=new(e))

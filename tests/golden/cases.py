@@ -233,6 +233,16 @@ CASES = {
                     B=2, T=33, seed=15),
     # ---- DepthwiseSeparableConv1d on its own (lobe/cnn.py:9-106): the hid_channels transform and the skip connection
     # that no Conv-TasNet preset uses, every norm the lobe accepts, causal and not
+    # MhaSelfAttenLayer on its own (lobe/attention.py:115-232): the plain transformer block and the "improved" one (LSTM
+    # in place of the first feed-forward Linear), forward(x, causal)
+    "mha_plain": dict(kind="atten", cls="MhaSelfAttenLayer", args=(32, 48, 4),
+                      kw=dict(dropout=0.0, improved=False, position_encoding=True), causal=False, B=3, T=37, seed=81),
+    "mha_improved_bi": dict(kind="atten", cls="MhaSelfAttenLayer", args=(32, 24, 4),
+                            kw=dict(dropout=0.0, improved=True, bidirectional=True, position_encoding=False),
+                            causal=False, B=3, T=37, seed=82),
+    "mha_improved_causal": dict(kind="atten", cls="MhaSelfAttenLayer", args=(24, 40, 2),
+                                kw=dict(dropout=0.0, improved=True, bidirectional=False, position_encoding=False),
+                                causal=True, B=2, T=50, seed=83),
     "dsc_plain_ggn": dict(kind="lobe", cls="DepthwiseSeparableConv1d", args=(12, 20),
                           kw=dict(norm_cls="gGN", kernel=5, dilation=3), B=2, T=61, seed=61),
     "dsc_transform_skip_gln": dict(kind="lobe", cls="DepthwiseSeparableConv1d", args=(12, 20),
@@ -435,7 +445,7 @@ def build(ns, name):
         return build_masker(ns, c["masker"])
     if c["kind"] == "encdec":
         return build_encoder(ns, c["enc"])
-    if c["kind"] in ("rnn", "lobe"):
+    if c["kind"] in ("rnn", "lobe", "atten"):
         return getattr(ns, c["cls"])(*c["args"], **c["kw"])
     if c["kind"] == "unet":
         return getattr(ns, c["cls"])(**c["kw"])

@@ -58,6 +58,7 @@ from puresound.nnet.dpcrn import DPCRN  # noqa: E402
 from puresound.nnet.dparn import DPARN  # noqa: E402
 from puresound.nnet.lobe.trivial import Magnitude, SpecAugment  # noqa: E402
 from puresound.nnet.lobe.rnn import SingleRNN  # noqa: E402
+from puresound.nnet.lobe.attention import MhaSelfAttenLayer  # noqa: E402
 from puresound.nnet.lobe.cnn import DepthwiseSeparableConv1d  # noqa: E402
 
 import cases  # noqa: E402
@@ -68,6 +69,7 @@ REF = cases.namespace(SoTaskWrapModule=SoTaskWrapModule, SiMoTaskWrapModule=SiMo
                       AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM,
                       StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN, DPARN=DPARN,
                       Magnitude=Magnitude, SpecAugment=SpecAugment, FbankEnc=FbankEnc, SingleRNN=SingleRNN,
+                      MhaSelfAttenLayer=MhaSelfAttenLayer,
                       DepthwiseSeparableConv1d=DepthwiseSeparableConv1d)
 
 
@@ -172,6 +174,15 @@ def run_lobe(name, c):
     model.load_state_dict(det_state_dict(model))
     x = _uniform(c["seed"], (c["B"], c["args"][0], c["T"]))
     return {"x": x.numpy(), "y": model(x.clone()).numpy()}
+
+
+@torch.no_grad()
+def run_atten(name, c):
+    """MhaSelfAttenLayer on its own: x [B, C, T] -> y, forward(x, causal)"""
+    model = cases.build(REF, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    x = _uniform(c["seed"], (c["B"], c["args"][0], c["T"]))
+    return {"x": x.numpy(), "y": model(x.clone(), causal=c["causal"]).numpy()}
 
 
 @torch.no_grad()
@@ -330,7 +341,7 @@ def main():
     dump_state_dict_keys()
     for name, c in cases.CASES.items():
         fn = {"wrap": run_wrap, "masker": run_masker, "encdec": run_encdec, "rnn": run_rnn,
-              "lobe": run_lobe, "stream": run_stream, "unet": run_unet, "fbank": run_fbank, "loss": run_loss, "simo": run_simo, "func": run_func}[c["kind"]]
+              "lobe": run_lobe, "atten": run_atten, "stream": run_stream, "unet": run_unet, "fbank": run_fbank, "loss": run_loss, "simo": run_simo, "func": run_func}[c["kind"]]
         if only and name not in only:
             continue
         out = fn(name, c)

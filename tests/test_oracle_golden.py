@@ -328,3 +328,17 @@ def test_mask_functions_and_magphase_match_reference(golden_dir):
         # phases: compare on the unit circle (atan2 is discontinuous at +-pi) where the bin is not numerically empty
         big = want[..., 0] > 1e-3 * want[..., 0].max()
         assert np.abs(np.exp(1j * got[..., 1]) - np.exp(1j * want[..., 1]))[big].max() < 1e-3
+
+
+@pytest.mark.parametrize("name", [n for n, c in cases.CASES.items() if c["kind"] == "atten"])
+def test_mha_self_atten_layer_matches_reference(golden_dir, name):
+    """MhaSelfAttenLayer on its own (lobe/attention.py:115-232), plain and "improved" (LSTM feed-forward), causal or not."""
+    from oracle import unet_oracle as UO
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    sd = {k: v.double() for k, v in det_state_dict(cases.build(PA.NS, name)).items()}
+    kw = c["kw"]
+    y = UO.mha_self_atten_layer(torch.tensor(g["x"]).double(), sd, "", c["args"][2], kw["position_encoding"], c["causal"],
+                                kw["improved"], kw.get("bidirectional", False))
+    assert y.shape == g["y"].shape
+    assert rel_max(y.numpy(), g["y"]) < TOL

@@ -95,3 +95,22 @@ def test_config3_with_the_residual_stream_in_bf16(PA, dev, size):
     e_hidden = _l2rel(out2[pick:pick + 1].cpu().numpy(), ref.numpy())
     assert e_hidden < 3e-2 and not torch.equal(out, out2)
     print(f"cfg3 {size}: l2-rel bf16 stream {e_stream:.2e}, fp32 residual stream {e_hidden:.2e}")
+
+
+@pytest.mark.parametrize("name", [n for n, c in cases.CASES.items() if c["kind"] == "atten"])
+def test_mha_self_atten_layer_matches_reference_golden(PA, dev, golden_dir, name):
+    """MhaSelfAttenLayer called on its own, incl. improved=True (lobe/attention.py:170-183: an LSTM in place of the first
+    feed-forward Linear), which round 3 refused; and the reference's own AttributeError for improved + position_encoding."""
+    import os
+    c = cases.CASES[name]
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    y = model(torch.tensor(g["x"]).to(dev), causal=c["causal"])
+    assert y.shape == g["y"].shape
+    assert rel_max(y.cpu().numpy(), g["y"]) < 1e-4
+    if c["kw"]["improved"]:
+        bad = PA.MhaSelfAttenLayer(*c["args"], improved=True, position_encoding=True).eval().to(dev)
+        with pytest.raises(AttributeError):
+            bad(torch.tensor(g["x"]).to(dev))
