@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 11
+#define PS_ABI_VERSION 12
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -340,6 +340,15 @@ int ps_lstm_f32(const ps_lstm_args* args, void* stream);
  * inter-segment pass, dprnn.py:162-171) -- and exactly ps_lstm_f32 for every other shape.  h0 is taken as an LSTM
  * output (|h0| <= 1; the two-term form holds up to |h0| < 32). */
 int ps_lstm_f16x2_f32(const ps_lstm_args* args, void* stream);
+/* The recurrence of ps_lstm_f16x2_f32 for H = 128 with gx FRAME-MAJOR, [N][ldt][ldm >= D*4H] (ps_conv1x1_f16x2_fmajor_f32): 16
+ * sequences per workgroup, v_mfma_f32_16x16x32_f16, the pre-activations streamed HBM -> LDS by DMA four steps ahead.
+ * The bottleneck LSTMs of DPCRN (dpcrn.py:34-81: bidirectional along frequency, Q = T, q_stride = 1, step_stride = ld;
+ * unidirectional along time, Q = F, q_stride = ld, step_stride = 1).  hout as ps_lstm_f32 ([N][D*H][ldt]).  No initial or
+ * final states (h0, c0, h_last, c_last must be NULL).  step_stride = 1 needs 16-byte-aligned rows and q_stride and, when
+ * steps % 4 != 0, D = 1 and room for the padded group inside the row (those frames are written as zeros).
+ * ps_lstm_fmajor_ok(args, ldm) = 1 when a launch qualifies, else PS_E_UNSUPPORTED. */
+int ps_lstm_fmajor_ok(const ps_lstm_args* args, int ldm);
+int ps_lstm_fmajor_f16x2_f32(const ps_lstm_args* args, int ldm, void* stream);
 
 /* 50 % overlapped segmentation of the dual-path maskers (SplitMerge.split / merge, lobe/trivial.py:178-241; SkiM.split /
  * merge, skim.py:334-408) on rows of frames:
@@ -500,6 +509,15 @@ int ps_conv1x1_f16_rows_ok(int N, int K, int M, int T);
 int ps_conv1x1_f16_rows(const void* x, const void* wt_planes, const ps_f16x2_range* rng, void* y, int N, int K, int M,
                         int T, int ldt, const ps_prologue* pro, const float* bias, const float* bias_n, const void* res,
                         double* ostats, void* stream);
+/* ps_conv1x1_f16x2_f32 (no prologue, residual or statistics) writing its output FRAME-MAJOR: y [N][ldt][ldm], ldm >= M a
+ * multiple of 4 -- the M outputs of a frame are consecutive -- instead of [N][M][ldt] (ldm = M + 64 keeps the 16 frames of
+ * one store instruction off a common 4 KiB stride).  This is the layout ps_lstm_fmajor_f16x2_f32 reads its
+ * gate pre-activations in: the LSTM input projection W_ih x + b of nn.LSTM (/root/reference/puresound/nnet/lobe/rnn.py:
+ * 9-55 as used by dpcrn.py:34-81) written so that one step of 16 sequences is 16 contiguous 2 KiB runs.  Register-B kernel
+ * only: ps_conv1x1_f16x2_fmajor_ok says whether a launch qualifies (as ps_conv1x1_f16_rows_ok, and ldm*ldt*4 < 2^31). */
+int ps_conv1x1_f16x2_fmajor_ok(int N, int K, int M, int T, int ldt, int ldm);
+int ps_conv1x1_f16x2_fmajor_f32(const float* x, const void* wt_planes, const ps_f16x2_range* rng, float* y, int N, int K,
+                                int M, int T, int ldt, int ldm, const float* bias, void* stream);
 /* partial maxima of |x| over the valid frames: amax [N][ps_absmax_parts()] */
 int ps_absmax_parts(void);
 int ps_absmax_f32(const float* x, float* amax, int N, int C, int T, int ldt, void* stream);

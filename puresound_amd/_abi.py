@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PURESOUND_HIP_LIB: an experimental build of the same library (tools/build_variant.sh); kernel experiments only
 LIB_PATH = os.environ.get("PURESOUND_HIP_LIB") or os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -92,6 +92,8 @@ SIGNATURES = {
     "ps_attn_weights_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ps_lstm_f32": (C.c_int, [C.POINTER(LstmArgs), _vp]),
     "ps_lstm_f16x2_f32": (C.c_int, [C.POINTER(LstmArgs), _vp]),
+    "ps_lstm_fmajor_ok": (C.c_int, [C.POINTER(LstmArgs), C.c_int]),
+    "ps_lstm_fmajor_f16x2_f32": (C.c_int, [C.POINTER(LstmArgs), C.c_int, _vp]),
     "ps_unfold_taps_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 7 + [_vp, _vp, _vp, C.c_int, _vp]),
     "ps_unfold_taps_out_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 8 + [_vp, _vp, _vp, C.c_int, _vp]),
     "ps_gated_product_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [C.POINTER(Prologue), C.POINTER(Prologue), _vp]),
@@ -129,6 +131,8 @@ SIGNATURES = {
     "ps_conv_tasnet_ranged_f32": (C.c_int, [C.POINTER(TcnBlock), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                             C.c_int, _vp, C.c_size_t, _vp, C.c_int, _vp]),
     "ps_conv1x1_f16_rows_ok": (C.c_int, [C.c_int] * 4),
+    "ps_conv1x1_f16x2_fmajor_ok": (C.c_int, [C.c_int] * 6),
+    "ps_conv1x1_f16x2_fmajor_f32": (C.c_int, [_vp, _vp, C.POINTER(F16x2Range), _vp] + [C.c_int] * 6 + [_vp, _vp]),
     "ps_conv1x1_f16_rows": (C.c_int, [_vp, _vp, C.POINTER(F16x2Range), _vp] + [C.c_int] * 5 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
     "ps_conv_tasnet_bf16_rows": (C.c_int, [C.POINTER(TcnBlock), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                            C.c_int, _vp, C.c_size_t, _vp]),

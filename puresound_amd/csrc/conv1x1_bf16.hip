@@ -79,6 +79,7 @@ struct BfArgs {
   int ablate;  // profiling only (ps_debug_flags bits 24..26): 1 = no MFMA, 2 = no epilogue, 4 = no activation split
   int x_bf16, y_bf16;  // the rows of x / y are bf16 in HBM (PLANES = 1 only; bias, residual, statistics stay fp32 / fp64)
   int delay, groups;   // interleaved kernel: start offset (cycles) between the `groups` phases of workgroups
+  int fm_ld;           // register-B kernel, frame-major output: floats between consecutive frames (>= M)
   int pair_r;          // interleaved kernel, two m-tiles: > 0 = workgroups per (utterance, m-tile) row; the two
                        // workgroups that read the same activation tiles are placed on the same XCD (see bf16_launch)
   // PLANES = 2: activations are multiplied by a power of two before the fp16 split, accumulators by
@@ -1461,7 +1462,7 @@ static bool rb_ok(const BfArgs& a, int N, int* Gr_out) {
   return true;
 }
 
-template <bool R16>
+template <bool R16, bool FM = false>
 static void rb_launch(const BfArgs& a, int N, bool tr, int Gr, hipStream_t stream) {
   const bool stats = a.ostats != nullptr, res = a.res != nullptr;
   BfArgs& b = const_cast<BfArgs&>(a);
@@ -1476,6 +1477,10 @@ static void rb_launch(const BfArgs& a, int N, bool tr, int Gr, hipStream_t strea
   }
 #define PS_RB(TRV, STV, RSV) \
   hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<TRV, STV, RSV, R16>), dim3(Gr, 1), dim3(256), 0, stream, a)
+  if constexpr (FM) {  // (split_gemm admits no prologue, residual or statistics here)
+    hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<false, false, false, false, true>), dim3(Gr, 1), dim3(256), 0, stream, a);
+    return;
+  }
   if (tr) {
     if (stats) PS_RB(true, true, false);
     else if (res) PS_RB(true, false, true);
@@ -1649,7 +1654,8 @@ extern "C" int ps_conv1x1_bf16_f32(const float* x, const void* wt_planes, float*
 
 static int split_gemm(const void* x_any, int x_bf16, const void* wt_planes, const ps_f16x2_range* rng, void* y_any,
                       int y_bf16, int N, int K, int M, int T, int ldt, int planes, const ps_prologue* pro,
-                      const float* bias, const float* bias_n, const float* res, double* ostats, void* stream);
+                      const float* bias, const float* bias_n, const float* res, double* ostats, void* stream,
+                      int fm_ld = 0);
 
 extern "C" int ps_conv1x1_bf16_io(const void* x_any, int x_bf16, const void* wt_planes, void* y_any, int y_bf16, int N,
                                   int K, int M, int T, int ldt, int planes, const ps_prologue* pro, const float* bias,
@@ -1670,6 +1676,23 @@ extern "C" int ps_conv1x1_f16x2_f32(const float* x, const void* wt_planes, const
     return PS_E_INVALID;
   }
   return split_gemm(x, 0, wt_planes, rng, y, 0, N, K, M, T, ldt, 2, pro, bias, bias_n, res, ostats, stream);
+}
+
+extern "C" int ps_conv1x1_f16x2_fmajor_ok(int N, int K, int M, int T, int ldt, int ldm) {
+  return ps_conv1x1_f16_rows_ok(N, K, M, T) && ldm >= M && ldm % 4 == 0 && (long long)ldm * ldt * 4 < (1LL << 31);
+}
+
+extern "C" int ps_conv1x1_f16x2_fmajor_f32(const float* x, const void* wt_planes, const ps_f16x2_range* rng, float* y, int N,
+                                           int K, int M, int T, int ldt, int ldm, const float* bias, void* stream) {
+  if (!rng || rng->w_exp < -100 || rng->w_exp > 100 || rng->x_bound < 0.f || (rng->x_amax && rng->x_amax_parts <= 0)) {
+    set_error("ps_conv1x1_f16x2_fmajor_f32: range descriptor missing or out of range (w_exp within +-100, x_bound >= 0)");
+    return PS_E_INVALID;
+  }
+  if (ldm < M || ldm % 4) {
+    set_error("ps_conv1x1_f16x2_fmajor_f32: ldm=%d must be a multiple of 4 >= M=%d", ldm, M);
+    return PS_E_INVALID;
+  }
+  return split_gemm(x, 0, wt_planes, rng, y, 0, N, K, M, T, ldt, 2, nullptr, bias, nullptr, nullptr, nullptr, stream, ldm);
 }
 
 extern "C" int ps_conv1x1_f16_rows_ok(int N, int K, int M, int T) {
@@ -1736,7 +1759,9 @@ extern "C" int ps_absmax_f32(const float* x, float* amax, int N, int C, int T, i
 
 static int split_gemm(const void* x_any, int x_bf16, const void* wt_planes, const ps_f16x2_range* rng, void* y_any,
                       int y_bf16, int N, int K, int M, int T, int ldt, int planes, const ps_prologue* pro,
-                      const float* bias, const float* bias_n, const float* res, double* ostats, void* stream) {
+                      const float* bias, const float* bias_n, const float* res, double* ostats, void* stream,
+                      int fm_ld) {
+  const bool fmajor = fm_ld > 0;
   const float* x = (const float*)x_any;
   float* y = (float*)y_any;
   const bool rows16 = planes == 2 && x_bf16 && y_bf16;  // ps_conv1x1_f16_rows
@@ -1814,7 +1839,15 @@ static int split_gemm(const void* x_any, int x_bf16, const void* wt_planes, cons
       a.x_amax = rng->x_bound > 0.f ? nullptr : rng->x_amax;
       a.x_amax_parts = rng->x_amax_parts;
       a.y_amax = rng->y_amax;
-      if (rows16) {
+      if (fmajor) {
+        int Gr = 0;
+        a.fm_ld = fm_ld;
+        if (tr || res || ostats || !rb_ok(a, N, &Gr) || fm_ld < M || fm_ld % 4 || (long long)fm_ld * ldt * 4 >= (1LL << 31)) {
+          set_error("ps_conv1x1_f16x2_fmajor_f32: this launch cannot run on the register-B kernel (ps_conv1x1_f16x2_fmajor_ok)");
+          return PS_E_UNSUPPORTED;
+        }
+        rb_launch<false, true>(a, N, false, Gr, st);
+      } else if (rows16) {
         int Gr = 0;
         if (!rb_ok(a, N, &Gr)) {
           set_error("ps_conv1x1_f16_rows: this launch cannot run on the register-B kernel (ps_conv1x1_f16_rows_ok)");

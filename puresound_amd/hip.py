@@ -5,6 +5,7 @@ memory and streams only; all arithmetic happens in the HIP kernels.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -247,6 +248,34 @@ def conv1x1_f16x2(x: torch.Tensor, t: int, wt_planes: torch.Tensor, w_exp: int, 
     return y, stats, amax
 
 
+FMAJOR_PAD = int(os.environ.get("PS_FMAJOR_PAD", "64"))   # floats between the M outputs of consecutive frames
+
+
+def fmajor_ld(m: int) -> int:
+    """Frame stride of the frame-major gate pre-activations: M + 64 floats, so that the 16 frames one store instruction of
+    the GEMM covers (and the 16 sequences one LSTM step reads) do not sit a multiple of 4 KiB apart."""
+    return m + FMAJOR_PAD
+
+
+def conv1x1_f16x2_fmajor_ok(n: int, k: int, m: int, t: int, ldt: int) -> bool:
+    return bool(lib().ps_conv1x1_f16x2_fmajor_ok(n, k, m, t, ldt, fmajor_ld(m)))
+
+
+def conv1x1_f16x2_fmajor(x: torch.Tensor, t: int, wt_planes: torch.Tensor, w_exp: int, m: int,
+                         bias: Optional[torch.Tensor] = None, x_bound: float = 0.0,
+                         x_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ps_conv1x1_f16x2_fmajor_f32: the fp16x2 GEMM writing y FRAME-MAJOR, a [N, ldt, M] view of rows fmajor_ld(M) apart
+    (the gate pre-activations of lstm_fmajor).  Raises when the launch does not qualify (conv1x1_f16x2_fmajor_ok)."""
+    require_device(x, "conv1x1_f16x2_fmajor")
+    n, k, ldt = x.shape
+    ldm = fmajor_ld(m)
+    y = torch.empty(n, ldt, ldm, dtype=torch.float32, device=x.device)[..., :m]
+    rng = F16x2Range(int(w_exp), float(x_bound), ptr(x_amax), x_amax.shape[1] if x_amax is not None else 0, None)
+    check(lib().ps_conv1x1_f16x2_fmajor_f32(ptr(x), ptr(wt_planes), C.byref(rng), ptr(y), n, k, m, t, ldt, ldm, ptr(bias),
+                                            stream_ptr(x.device)), "ps_conv1x1_f16x2_fmajor_f32")
+    return y
+
+
 def absmax(x: torch.Tensor, t: int) -> torch.Tensor:
     """padded rows [N, C, ldt] -> [N, ps_absmax_parts()] partial maxima of |x| over the t valid frames."""
     require_device(x, "absmax")
@@ -370,6 +399,40 @@ def lstm(gx: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int, q: int, 
     else:
         check(lib().ps_lstm_f32(C.byref(a), stream_ptr(gx.device)), "ps_lstm_f32")
     return (hout, (h_last, c_last)) if h_last is not None else (hout, None)
+
+
+def _lstm_fmajor_args(gx_fm: torch.Tensor, whh_t: torch.Tensor, hout, hidden, dirs, q, q_stride, steps, step_stride):
+    n, ldt, rows = gx_fm.shape
+    a = LstmArgs()
+    a.gx, a.whh_t, a.hout = ptr(gx_fm), ptr(whh_t), ptr(hout)
+    a.N, a.H, a.D, a.Q, a.q_stride, a.steps, a.step_stride = n, hidden, dirs, q, q_stride, steps, step_stride
+    a.ldt, a.ldq, a.state_shift = ldt, 0, 0
+    return a
+
+
+def lstm_fmajor_ok(n: int, ldt: int, hidden: int, dirs: int, q: int, q_stride: int, steps: int, step_stride: int) -> bool:
+    """Does ps_lstm_fmajor_f16x2_f32 take this pass?  (shape / stride conditions only: H = 128, no states, slabs < 2 GiB)"""
+    if hidden != 128 or dirs not in (1, 2) or (q - 1) * q_stride + (steps - 1) * step_stride >= ldt:
+        return False
+    return ldt * fmajor_ld(dirs * 512) * 4 < 2 ** 31
+
+
+def lstm_fmajor(gx_fm: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int, q: int, q_stride: int, steps: int,
+                step_stride: int) -> torch.Tensor:
+    """ps_lstm_fmajor_f16x2_f32: LSTM recurrence over FRAME-MAJOR gate pre-activations gx [N, ldt, D*4H] (from
+    conv1x1_f16x2_fmajor; the frames may be padded rows: stride(1) >= D*4H) -> hout [N, D*H, ldt]; H = 128, zero initial
+    states, fp16x2 recurrent product."""
+    require_device(gx_fm, "lstm_fmajor")
+    n, ldt, rows = gx_fm.shape
+    if rows != dirs * 4 * hidden or tuple(whh_t.shape) != (dirs, hidden, 4 * hidden):
+        raise RuntimeError("lstm_fmajor: gx must be [N, ldt, D*4H] and whh_t [D, H, 4H]")
+    ldm = gx_fm.stride(1)
+    if gx_fm.stride(2) != 1 or gx_fm.stride(0) != ldt * ldm:
+        raise RuntimeError("lstm_fmajor: gx must be a [N, ldt, :D*4H] view of contiguous frame rows")
+    hout = torch.empty(n, dirs * hidden, ldt, dtype=torch.float32, device=gx_fm.device)
+    a = _lstm_fmajor_args(gx_fm, whh_t, hout, hidden, dirs, q, q_stride, steps, step_stride)
+    check(lib().ps_lstm_fmajor_f16x2_f32(C.byref(a), ldm, stream_ptr(gx_fm.device)), "ps_lstm_fmajor_f16x2_f32")
+    return hout
 
 
 def chan_layernorm(x: torch.Tensor, t: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float,

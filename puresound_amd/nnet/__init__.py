@@ -11,7 +11,7 @@ from .lobe.trivial import FiLM, Gate, Magnitude, SpecAugment
 from .skim import MemLSTM, SegLSTM, SkiM
 from .unet import Unet, UnetTcn
 from .dpcrn import DPCRN, DPRNNblock2D
-from .dparn import DPARN, DPARNblock2D
+from .dparn import DPARN, DPARN_Mout, DPARNblock2D
 from .lobe.attention import MhaSelfAttenLayer
 from .lobe.rnn import SingleRNN
 from .lobe.cnn import DepthwiseSeparableConv1d
@@ -28,5 +28,5 @@ class _Namespace(SimpleNamespace):
 NS = _Namespace(SoTaskWrapModule=SoTaskWrapModule, SiMoTaskWrapModule=SiMoTaskWrapModule, SDRLoss=SDRLoss, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                      ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                      AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM, MemLSTM=MemLSTM, Unet=Unet, UnetTcn=UnetTcn,
-                DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, DPARN=DPARN, DPARNblock2D=DPARNblock2D,
+                DPCRN=DPCRN, DPRNNblock2D=DPRNNblock2D, DPARN=DPARN, DPARN_Mout=DPARN_Mout, DPARNblock2D=DPARNblock2D,
                 MhaSelfAttenLayer=MhaSelfAttenLayer, SingleRNN=SingleRNN, Magnitude=Magnitude, SpecAugment=SpecAugment, FbankEnc=FbankEnc, SegLSTM=SegLSTM, FiLM=FiLM, Gate=Gate, DepthwiseSeparableConv1d=DepthwiseSeparableConv1d)

@@ -16,6 +16,7 @@ import os
 
 FUSE_PROJ_LN = os.environ.get("PS_FUSE_PROJ_LN", "1") == "1"   # 0: separate projection GEMM + LayerNorm kernels
 FUSE_PROJ_LN_MAX_FRAMES = int(os.environ.get("PS_FUSE_PROJ_LN_MAX_FRAMES", "8192"))
+FMAJOR_LSTM = os.environ.get("PS_FMAJOR_LSTM", "1") == "1"      # 0: H = 128 recurrences stay on the channel-major kernels
 
 
 # Arithmetic of the LSTM input projections (the large GEMMs of the recurrent maskers: [4H*D x C] over every frame):
@@ -97,7 +98,7 @@ def linear_plan(lin: nn.Module, device) -> dict:
     if w.dim() == 3:
         w = w[:, :, 0]
     return dict(wt=hip.pack_wt(_f32(w, device)), bias=None if lin.bias is None else _f32(lin.bias, device),
-                M=w.shape[0], K=w.shape[1])
+                M=w.shape[0], K=w.shape[1], w_rows=_f32(w, device))
 
 
 def layernorm_plan(ln: nn.Module, device) -> dict:
@@ -109,6 +110,33 @@ def layernorm_plan(ln: nn.Module, device) -> dict:
     return dict(gamma=_f32(ln.gamma, device), beta=_f32(ln.beta, device), eps=float(ln.eps))
 
 
+def _proj_norm(x, hseq, t, rnn, proj, norm, amax):
+    """x + LN(proj(h)) behind a recurrence (second half of lstm_path)."""
+    n, _, ldt = x.shape
+    dev = x.device
+    # the fused projection + LayerNorm kernel is the short-row kernel (16-frame workgroups): on long rows (the 2-D
+    # maps of DPCRN / DPARN: F * ld frames) the MFMA GEMM plus a LayerNorm pass is faster
+    if proj["M"] <= 256 and FUSE_PROJ_LN and t <= FUSE_PROJ_LN_MAX_FRAMES:
+        if amax is not None and rnn["planes"] == 2 and t >= 128:
+            try:   # the row kernel hands the next GEMM its input range for free
+                y, _, amax[0] = hip.proj_layernorm(hseq, t, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"],
+                                                   norm["eps"], x, want_amax=True)
+                return y
+            except RuntimeError:
+                amax[0] = None
+        y, _ = hip.proj_layernorm(hseq, t, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"], norm["eps"], x)
+        return y
+    p = torch.empty(n, proj["M"], ldt, dtype=torch.float32, device=dev)
+    if rnn["planes"] == 2 and proj["K"] >= 64:
+        # the recurrence's arithmetic for its projection too: h is an LSTM output, |h| < 1 is its range
+        if "f16x2" not in proj:
+            proj["f16x2"] = hip.pack_wt_f16x2(proj["w_rows"])
+        hip.conv1x1_f16x2(hseq, t, proj["f16x2"][0], proj["f16x2"][1], proj["M"], None, proj["bias"], out=p, x_bound=1.0)
+    else:
+        hip.conv1x1(hseq, t, proj["wt"], proj["M"], None, proj["bias"], out=p)
+    return hip.chan_layernorm(p, t, norm["gamma"], norm["beta"], norm["eps"], res=x)
+
+
 def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int, q_stride: int, steps: int,
               step_stride: int, h0=None, c0=None, want_state: bool = False, state_shift: int = 0, state_out=None,
               amax: Optional[list] = None):
@@ -118,7 +146,6 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
     n, _, ldt = x.shape
     dev = x.device
     planes = rnn["planes"]
-    gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev)
     x_amax = amax[0] if amax is not None else None
     if amax is not None:
         amax[0] = None
@@ -126,29 +153,27 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
         if "wih_f16x2" not in rnn:
             rnn["wih_f16x2"] = hip.pack_wt_f16x2(rnn["wih_rows"])
         wf, we = rnn["wih_f16x2"]
+        # H = 128 without carried states (the bottleneck LSTMs of DPCRN / DPARN): gate pre-activations frame-major and the
+        # 16-sequence fp16x2 recurrence that streams them (ps_lstm_fmajor_f16x2_f32)
+        if (FMAJOR_LSTM and rnn["H"] == 128 and h0 is None and c0 is None and not want_state and state_out is None
+                and state_shift == 0 and hip.lstm_fmajor_ok(n, ldt, rnn["H"], rnn["D"], q, q_stride, steps, step_stride)
+                and hip.conv1x1_f16x2_fmajor_ok(n, rnn["I"], rnn["rows"], t, ldt)):
+            gx_fm = hip.conv1x1_f16x2_fmajor(x, t, wf, we, rnn["rows"], rnn["bias"],
+                                             x_amax=x_amax if x_amax is not None else hip.absmax(x, t))
+            hseq = hip.lstm_fmajor(gx_fm, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride)
+            return _proj_norm(x, hseq, t, rnn, proj, norm, amax), None
+        gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev)
         hip.conv1x1_f16x2(x, t, wf, we, rnn["rows"], None, rnn["bias"], out=gx,
                           x_amax=x_amax if x_amax is not None else hip.absmax(x, t))
     elif planes and rnn["I"] >= 64:
+        gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev)
         planes = 3 if planes == 2 else planes
         if planes not in rnn["wih_planes"]:
             rnn["wih_planes"][planes] = hip.pack_wt_bf16(rnn["wih_rows"], planes)
         hip.conv1x1_bf16(x, t, rnn["wih_planes"][planes], rnn["rows"], None, rnn["bias"], out=gx)
     else:
+        gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev)
         hip.conv1x1(x, t, rnn["wih"], rnn["rows"], None, rnn["bias"], out=gx)
     hseq, state = hip.lstm(gx, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride, h0, c0, want_state,
                            state_shift, state_out, f16x2=rnn["planes"] == 2)
-    # the fused projection + LayerNorm kernel is the short-row kernel (16-frame workgroups): on long rows (the 2-D
-    # maps of DPCRN / DPARN: F * ld frames) the MFMA GEMM plus a LayerNorm pass is faster
-    if proj["M"] <= 256 and FUSE_PROJ_LN and t <= FUSE_PROJ_LN_MAX_FRAMES:
-        if amax is not None and rnn["planes"] == 2 and t >= 128:
-            try:   # the row kernel hands the next GEMM its input range for free
-                y, _, amax[0] = hip.proj_layernorm(hseq, t, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"],
-                                                   norm["eps"], x, want_amax=True)
-                return y, state
-            except RuntimeError:
-                amax[0] = None
-        y, _ = hip.proj_layernorm(hseq, t, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"], norm["eps"], x)
-        return y, state
-    p, _ = hip.conv1x1(hseq, t, proj["wt"], proj["M"], None, proj["bias"],
-                       out=torch.empty(n, proj["M"], ldt, dtype=torch.float32, device=dev))
-    return hip.chan_layernorm(p, t, norm["gamma"], norm["beta"], norm["eps"], res=x), state
+    return _proj_norm(x, hseq, t, rnn, proj, norm, amax), state

@@ -11,7 +11,7 @@ from ..ops import op_module, same_shape
 from ._plans import PlanCache, layernorm_plan, linear_plan, lstm_path, lstm_plan
 from .lobe.attention import MhaSelfAttenLayer
 from .lobe.rnn import SingleRNN
-from .unet import Unet
+from .unet import Unet, _unet_shape
 
 
 class DPARNblock2D(PlanCache, nn.Module):
@@ -67,9 +67,9 @@ class DPARN(Unet):
                  kernel_t: Tuple = (2, 2, 2, 2, 2), stride_t: Tuple = (1, 1, 1, 1, 1),
                  dilation_t: Tuple = (1, 1, 1, 1, 1), kernel_f: Tuple = (5, 3, 3, 3, 3),
                  stride_f: Tuple = (2, 2, 1, 1, 1), dilation_f: Tuple = (1, 1, 1, 1, 1), delay: Tuple = (0, 0, 0, 0, 0),
-                 rnn_hidden: int = 128, nhead: int = 1, spectral_compress: bool = False):
+                 rnn_hidden: int = 128, nhead: int = 1, spectral_compress: bool = False, _multi_output: int = 1):
         super().__init__(input_type, input_dim, activation_type, norm_type, dropout, channels, transpose_t_size,
-                         skip_conv, kernel_t, stride_t, dilation_t, kernel_f, stride_f, dilation_f, delay)
+                         skip_conv, kernel_t, stride_t, dilation_t, kernel_f, stride_f, dilation_f, delay, _multi_output)
         self.transpose_delay = transpose_delay
         self.rnn_hidden = rnn_hidden
         self.spectral_compress = spectral_compress
@@ -96,4 +96,36 @@ class DPARN(Unet):
         a = dict(Unet.get_args.fget(self))
         a.pop("multi_output")
         a.update(transpose_delay=self.transpose_delay, rnn_hidden=self.rnn_hidden)
+        return a
+
+
+@op_module("dparn_mout_fwd", _unet_shape)
+class DPARN_Mout(DPARN):
+    """dparn.py:249-401: DPARN whose last transposed convolution carries `multi_output` masks; the output is
+    [N, multi_output, C, T] (the masks are consecutive channel groups of the decoder's output rows, so the reshape of
+    dparn.py:351-358 is a view of them).  Constructor order as the reference (dparn.py:250-272)."""
+
+    def __init__(self, input_type: str = "RI", input_dim: int = 512, activation_type: str = "PReLU",
+                 norm_type: str = "bN2d", dropout: float = 0.05, channels: Tuple = (1, 32, 32, 32, 64, 128),
+                 transpose_t_size: int = 2, transpose_delay: bool = False, skip_conv: bool = False,
+                 kernel_t: Tuple = (2, 2, 2, 2, 2), stride_t: Tuple = (1, 1, 1, 1, 1),
+                 dilation_t: Tuple = (1, 1, 1, 1, 1), kernel_f: Tuple = (5, 3, 3, 3, 3),
+                 stride_f: Tuple = (2, 2, 1, 1, 1), dilation_f: Tuple = (1, 1, 1, 1, 1), delay: Tuple = (0, 0, 0, 0, 0),
+                 multi_output: int = 2, rnn_hidden: int = 128, nhead: int = 1, spectral_compress: bool = False):
+        super().__init__(input_type, input_dim, activation_type, norm_type, dropout, channels, transpose_t_size,
+                         transpose_delay, skip_conv, kernel_t, stride_t, dilation_t, kernel_f, stride_f, dilation_f,
+                         delay, rnn_hidden, nhead, spectral_compress, _multi_output=multi_output)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [N, C, T] -> [N, multi_output, C, T] (dparn.py:308-376)."""
+        hip.require_device(x, "DPARN_Mout.forward")
+        x4, t = self._split_in(x)
+        return self._merge_out(self.forward_padded4(x4, t), t)
+
+    @property
+    def get_args(self) -> Dict:
+        """dparn.py:378-401 (as there: nhead is not listed)."""
+        a = dict(Unet.get_args.fget(self))
+        a.update(transpose_delay=self.transpose_delay, rnn_hidden=self.rnn_hidden,
+                 spectral_compress=self.spectral_compress)
         return a

@@ -333,6 +333,12 @@ CASES = {
                                 kernel_t=(2, 2, 2), kernel_f=(5, 3, 3), stride_t=(1, 1, 1), stride_f=(2, 2, 1),
                                 dilation_t=(1, 1, 1), dilation_f=(1, 1, 1), delay=(0, 0, 0), rnn_hidden=12, nhead=2,
                                 dropout=0.0), B=2, T=18, seed=57),
+    # dparn.py:249-401: two masks out of the last transposed convolution, frames trimmed at the front
+    "dparn_mout_small": dict(kind="unet", cls="DPARN_Mout", oracle="dparn",
+                             kw=dict(input_type="RI", input_dim=32, channels=(1, 4, 6, 8), transpose_delay=True,
+                                     kernel_t=(2, 2, 2), kernel_f=(5, 3, 3), stride_t=(1, 1, 1), stride_f=(2, 2, 1),
+                                     dilation_t=(1, 1, 1), dilation_f=(1, 1, 1), delay=(0, 0, 0), multi_output=3,
+                                     rnn_hidden=10, nhead=1, dropout=0.0), B=2, T=19, seed=58),
     "enc_free": dict(kind="encdec", enc=dict(kind="free", win=32, hop=16, C=20), B=3, L=500, seed=16),
     "enc_free_relu_ragged": dict(kind="encdec", enc=dict(kind="free", win=20, hop=6, C=9, relu=True),
                                  B=2, L=211, seed=17),
@@ -464,8 +470,10 @@ def unet_args(spec):
              tcn_layer="normal", tcn_kernel=3, tcn_dim=256, tcn_dilated_basic=2, per_tcn_stack=5, repeat_tcn=4,
              tcn_with_embed=[1, 0, 0, 0, 0], tcn_use_film=False, tcn_norm="gLN", dconv_norm="gGN", causal=False,
              spectral_compress=False)
-    if spec["cls"] in ("DPCRN", "DPARN"):
+    if spec["cls"] in ("DPCRN", "DPARN", "DPARN_Mout"):
         a["nhead"] = 1
+        if spec["cls"] == "DPARN_Mout":
+            a["multi_output"] = 2
         a.update(channels=(1, 32, 32, 32, 64, 128), kernel_t=(2, 2, 2, 2, 2), stride_t=(1, 1, 1, 1, 1),
                  dilation_t=(1, 1, 1, 1, 1), kernel_f=(5, 3, 3, 3, 3), stride_f=(2, 2, 1, 1, 1),
                  dilation_f=(1, 1, 1, 1, 1), delay=(0, 0, 0, 0, 0))

@@ -55,7 +55,7 @@ from puresound.nnet.skim import SkiM  # noqa: E402
 from puresound.streaming.skim_inference import StreamingSkiM  # noqa: E402
 from puresound.nnet.unet import Unet, UnetTcn  # noqa: E402
 from puresound.nnet.dpcrn import DPCRN  # noqa: E402
-from puresound.nnet.dparn import DPARN  # noqa: E402
+from puresound.nnet.dparn import DPARN, DPARN_Mout  # noqa: E402
 from puresound.nnet.lobe.trivial import Magnitude, SpecAugment  # noqa: E402
 from puresound.nnet.lobe.rnn import SingleRNN  # noqa: E402
 from puresound.nnet.lobe.attention import MhaSelfAttenLayer  # noqa: E402
@@ -67,7 +67,7 @@ from detweights import det_state_dict, det_wave  # noqa: E402
 REF = cases.namespace(SoTaskWrapModule=SoTaskWrapModule, SiMoTaskWrapModule=SiMoTaskWrapModule, SDRLoss=SDRLoss, TCN=TCN, ConvTasNet=ConvTasNet, GatedTCN=GatedTCN,
                       ConvEncDec=ConvEncDec, FreeEncDec=FreeEncDec,
                       AttentiveStatisticsPooling=AttentiveStatisticsPooling, DPRNN=DPRNN, SkiM=SkiM,
-                      StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN, DPARN=DPARN,
+                      StreamingSkiM=StreamingSkiM, Unet=Unet, UnetTcn=UnetTcn, DPCRN=DPCRN, DPARN=DPARN, DPARN_Mout=DPARN_Mout,
                       Magnitude=Magnitude, SpecAugment=SpecAugment, FbankEnc=FbankEnc, SingleRNN=SingleRNN,
                       MhaSelfAttenLayer=MhaSelfAttenLayer,
                       DepthwiseSeparableConv1d=DepthwiseSeparableConv1d)

@@ -689,7 +689,7 @@ def test_lstm_f16x2_entry_is_the_fp32_kernel_off_its_shape(H, dev):
         assert torch.equal(a[..., :s * k], b[..., :s * k]), (hid, k, s, mode)
 
 
-@pytest.mark.parametrize("n,c,t", [(2, 16, 77), (1, 128, 300), (2, 512, 65)])
+@pytest.mark.parametrize("n,c,t", [(2, 16, 77), (1, 128, 300), (2, 512, 65), (2, 200, 130), (1, 70, 64)])
 def test_chan_layernorm_kernel(H, dev, n, c, t):
     x, res, mul = _rand((n, c, t), 71, -2, 2), _rand((n, c, t), 72), _rand((n, c, t), 73)
     g, b, slope = _rand((c,), 74, 0.5, 1.5), _rand((c,), 75, -0.3, 0.3), torch.tensor([0.2])
@@ -700,6 +700,16 @@ def test_chan_layernorm_kernel(H, dev, n, c, t):
     y = H.chan_layernorm(H.pad_rows(x.to(dev)), t, g.to(dev), b.to(dev), 1e-8, slope=slope.to(dev), sigmoid=True,
                          mul=H.pad_rows(mul.to(dev)))
     assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 2e-5
+    # C <= 256 runs with the thread's channels in registers (one pass over x); debug bit 23 keeps the three-pass kernel: the
+    # same sums in the same order, bit for bit
+    from puresound_amd import _abi
+    old = _abi.lib().ps_debug_flags(1 << 23)
+    try:
+        y3 = H.chan_layernorm(H.pad_rows(x.to(dev)), t, g.to(dev), b.to(dev), 1e-8, slope=slope.to(dev), sigmoid=True,
+                              mul=H.pad_rows(mul.to(dev)))
+    finally:
+        _abi.lib().ps_debug_flags(old)
+    assert torch.equal(y3[..., :t], y[..., :t])
 
 
 @pytest.mark.parametrize("name", RNN_CASES)

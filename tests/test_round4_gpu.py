@@ -23,6 +23,12 @@ def PA():
     return PA
 
 
+@pytest.fixture(scope="module")
+def H():
+    import puresound_amd.hip as H
+    return H
+
+
 def _rand(shape, seed, lo=-1.0, hi=1.0):
     g = np.random.Generator(np.random.Philox(key=seed))
     return torch.tensor(g.uniform(lo, hi, shape), dtype=torch.float32)
@@ -114,3 +120,127 @@ def test_mha_self_atten_layer_matches_reference_golden(PA, dev, golden_dir, name
         bad = PA.MhaSelfAttenLayer(*c["args"], improved=True, position_encoding=True).eval().to(dev)
         with pytest.raises(AttributeError):
             bad(torch.tensor(g["x"]).to(dev))
+
+
+# ------------------------------------------------------------------------------------------------
+# frame-major gate pre-activations + the 16-sequence fp16x2 recurrence at H = 128 (DPCRN's bottleneck LSTMs)
+# ------------------------------------------------------------------------------------------------
+def _rand4(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def test_conv1x1_f16x2_frame_major_is_the_row_major_result_transposed(H, dev):
+    """ps_conv1x1_f16x2_fmajor_f32 writes y [N][ldt][M]: bit for bit ps_conv1x1_f16x2_f32's [N][M][ldt] (same kernel, same
+    accumulation order, only the epilogue's addresses differ), pad frames included; M = 512 and 1024, two utterances."""
+    from puresound_amd import _abi
+    n, k, t = 2, 128, 300
+    x = H.pad_rows(_rand4((n, k, t), 401).to(dev))
+    ldt = x.shape[-1]
+    old = _abi.lib().ps_debug_flags(1 << 28)   # the register-B kernel at any size
+    try:
+        for m in (512, 1024):
+            w = _rand4((m, k), 402 + m, -0.3, 0.3).to(dev)
+            b = _rand4((m,), 403, -0.5, 0.5).to(dev)
+            wf, we = H.pack_wt_f16x2(w)
+            assert H.conv1x1_f16x2_fmajor_ok(n, k, m, t, ldt)
+            amax = H.absmax(x, t)
+            y_rm, _, _ = H.conv1x1_f16x2(x, t, wf, we, m, None, b, x_amax=amax)
+            y_fm = H.conv1x1_f16x2_fmajor(x, t, wf, we, m, b, x_amax=amax)
+            torch.cuda.synchronize()
+            assert y_fm.shape == (n, ldt, m) and y_fm.stride(1) == H.fmajor_ld(m)
+            assert torch.equal(y_fm.transpose(1, 2), y_rm), m
+            ref = torch.einsum("mk,nkt->nmt", w.double().cpu(), x[..., :t].double().cpu()) + b.double().cpu()[None, :, None]
+            assert rel_max(y_rm[..., :t].cpu().numpy(), ref.numpy()) < 2e-6
+    finally:
+        _abi.lib().ps_debug_flags(old)
+    assert not H.conv1x1_f16x2_fmajor_ok(n, 100, 512, t, ldt)      # K not a multiple of 32
+    assert not H.conv1x1_f16x2_fmajor_ok(n, 128, 384, t, ldt)      # M not a multiple of 256
+
+
+@pytest.mark.parametrize("mode,bi,n,f,t,wscale", [
+    ("intra", True, 2, 9, 37, 1.0),      # DPCRN's intra pass: sequences = frames (ragged last block of 16), steps = rows
+    ("intra", False, 3, 5, 16, 1.5),     # exactly one block per utterance, saturating recurrent weights
+    ("inter", False, 2, 9, 37, 1.0),     # inter pass: sequences = rows, 37 consecutive frames (partial last step group)
+    ("inter", True, 1, 20, 24, 1.0),     # consecutive frames in both directions (whole step groups), two blocks
+    ("inter", False, 2, 3, 130, 1e-3),   # more steps than the ring, vanishing recurrent weights, second row of frames
+])
+def test_lstm_frame_major_f16x2_kernel(H, dev, mode, bi, n, f, t, wscale):
+    """ps_lstm_fmajor_f16x2_f32 (H = 128, 16 sequences per workgroup, LDS-DMA ring) against the oracle's LSTM and the
+    fp32 channel-major kernel on the same pre-activations."""
+    import torch.nn as nn
+    from oracle import dualpath_oracle as DP
+    from puresound_amd.nnet._plans import lstm_plan
+    hid, c = 128, 12
+    m = nn.LSTM(c, hid, num_layers=1, bidirectional=bi, batch_first=True)
+    sd = {k: _rand(tuple(v.shape), 410 + i, -0.4, 0.4) for i, (k, v) in enumerate(m.state_dict().items())}
+    m.load_state_dict(sd)
+    if wscale != 1.0:
+        sd = {kk: (v * wscale if "weight_hh" in kk else v) for kk, v in sd.items()}
+        m.load_state_dict(sd)
+    d = 2 if bi else 1
+    x = _rand4((n, c, f, t), 411)
+    if mode == "intra":   # one sequence per frame, steps along the rows
+        ref, _ = DP.lstm(x.permute(0, 3, 2, 1).reshape(n * t, f, c), sd, "", bi)
+    else:
+        ref, _ = DP.lstm(x.permute(0, 2, 3, 1).reshape(n * f, t, c), sd, "", bi)
+    p = lstm_plan(m.to(dev), torch.device(dev))
+    xp = H.pad_rows(x.reshape(n, c * f, t).to(dev)).view(n, c, f, -1)
+    ld = xp.shape[-1]
+    frames = (f - 1) * ld + t
+    gx, _ = H.conv1x1(xp.view(n, c, f * ld), frames, p["wih"], p["rows"], None, p["bias"])
+    gx_fm = torch.zeros(n, f * ld, H.fmajor_ld(d * 4 * hid), device=dev)[..., :d * 4 * hid]   # frames as padded rows
+    gx_fm.copy_(gx.transpose(1, 2))
+    q, qs, steps, ss = (t, 1, f, ld) if mode == "intra" else (f, ld, t, 1)
+    assert H.lstm_fmajor_ok(n, f * ld, hid, d, q, qs, steps, ss)
+    base, _ = H.lstm(gx, p["whh_t"], hid, d, q, qs, steps, ss)
+    hout = H.lstm_fmajor(gx_fm, p["whh_t"], hid, d, q, qs, steps, ss)
+    torch.cuda.synchronize()
+
+    def seqs(h):
+        h4 = h.view(n, d * hid, f, ld)[..., :t].cpu()
+        return (h4.permute(0, 3, 2, 1).reshape(n * t, f, -1) if mode == "intra" else h4.permute(0, 2, 3, 1).reshape(n * f, t, -1))
+    tol = 2e-5 if steps < 64 else 5e-5
+    assert rel_max(seqs(base).numpy(), ref.numpy()) < tol
+    e = rel_max(seqs(hout).numpy(), ref.numpy())
+    assert e < tol, e
+    assert rel_max(seqs(hout).numpy(), seqs(base).numpy()) < tol / 2
+    if mode == "inter" and t % 4:    # the padded step group of a row is written as zeros
+        pad = hout.view(n, d * hid, f, ld)[..., t:(t + 3) // 4 * 4]
+        assert float(pad.abs().max()) == 0.0
+
+
+def test_lstm_frame_major_refuses_what_it_does_not_cover(H, dev):
+    gx = torch.zeros(1, 128, 256, device=dev)
+    whh = torch.zeros(1, 64, 256, device=dev)
+    assert not H.lstm_fmajor_ok(1, 128, 64, 1, 4, 1, 8, 4)
+    with pytest.raises(RuntimeError, match="ps_lstm_fmajor_ok"):
+        H.lstm_fmajor(gx, whh, 64, 1, 4, 1, 8, 4)
+
+
+def test_dpcrn_preset_takes_the_frame_major_recurrence(PA, dev):
+    """ns_dpcrn_v0_causal in the fp16x2 arithmetic: with and without the frame-major LSTM path the enhanced waveform agrees
+    to fp32 class with the exact-fp32 run (the GEMM needs a full-size batch to qualify: 32 x 1 s here)."""
+    import cases
+    from detweights import det_state_dict
+    from puresound_amd.nnet import _plans
+    model = cases.build(PA.NS, "ns_dpcrn_short").eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    model.masker.set_gemm_precision("fp32")
+    g = torch.Generator().manual_seed(77)
+    x = ((torch.rand(32, 16000, generator=g) * 2 - 1) * 0.5).to(dev)
+    ref = model.inference(x)
+    model.masker.set_gemm_precision("fp16x2")
+    outs = {}
+    for on in (True, False):
+        old = _plans.FMAJOR_LSTM
+        _plans.FMAJOR_LSTM = on
+        try:
+            outs[on] = model.inference(x)
+        finally:
+            _plans.FMAJOR_LSTM = old
+    for on, y in outs.items():
+        err = float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref))
+        assert err < 2e-5, (on, err)
+    assert not torch.equal(outs[True], outs[False])   # (the two paths are different kernels)
