@@ -1119,10 +1119,15 @@ def test_unfold2d_kernel(H, dev, transposed):
     assert rel_max(got.numpy(), ref.numpy()) < 1e-6
 
 
-@pytest.mark.parametrize("transposed,m", [(False, 4), (True, 40), (False, 100)])
-def test_conv2d_implicit_gemm_kernel(H, dev, transposed, m):
+@pytest.mark.parametrize("transposed,m,c1,c2", [(False, 4, 3, 2), (True, 40, 3, 2), (False, 100, 3, 2), (True, 2, 3, 2),
+                                                (True, 2, 40, 24), (False, 40, 20, 12), (True, 100, 30, 34), (True, 32, 16, 16)])
+def test_conv2d_implicit_gemm_kernel(H, dev, transposed, m, c1, c2):
+    """ps_conv2d_f32 against torch's Conv2d / ConvTranspose2d: the LDS-staged kernel (weights through LDS, compacted tap
+    table; several 32-k chunks at the larger channel counts), the <= 4-channel kernel (m = 2: the mask layer) and the round-3
+    kernel (debug bit 23)."""
     import torch.nn.functional as F
-    n, c1, c2, f, t = 2, 3, 2, 11, 150
+    from puresound_amd import _abi
+    n, f, t = 2, 11, 150
     x1, x2 = _rand((n, c1, f, t), 151), _rand((n, c2, f, t), 152)
     x = torch.cat([x1, x2], 1)
     kf, kt, sf = 3, 2, 2
@@ -1138,10 +1143,19 @@ def test_conv2d_implicit_gemm_kernel(H, dev, transposed, m):
         ref = F.conv_transpose2d(x, w, b, stride=(sf, 1), padding=(kf // 2, 0), output_padding=(op, 0))[..., (kt - 1):]
         w2, shift = w.permute(1, 0, 2, 3).reshape(m, -1), kt - 1
     ref = torch.where(ref >= 0, ref, 0.2 * ref)
-    y = H.conv2d(pad(x1), pad(x2), H.pack_wt(w2.contiguous().to(dev)), b.to(dev), m, t, ref.shape[2], kf, kt, sf, 1, 1,
-                 kf // 2, shift, transposed, "prelu", slope.to(dev))
-    assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 2e-5
-    assert float(y[..., t:].abs().max()) == 0.0
+    outs = []
+    for flags in (0, 1 << 23):
+        old = _abi.lib().ps_debug_flags(flags)
+        try:
+            y = H.conv2d(pad(x1), pad(x2), H.pack_wt(w2.contiguous().to(dev)), b.to(dev), m, t, ref.shape[2], kf, kt, sf, 1, 1,
+                         kf // 2, shift, transposed, "prelu", slope.to(dev))
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
+        assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 2e-5, flags
+        assert float(y[..., t:].abs().max()) == 0.0
+        outs.append(y)
+    assert rel_max(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 1e-5
 
 
 UNET_CASES = [n for n, c in cases.CASES.items() if c["kind"] == "unet"]

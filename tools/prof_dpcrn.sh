@@ -15,5 +15,13 @@ with open(f"gpurun_out/prof_{sys.argv[1]}_kernels.txt", "w") as o:
         line = (f'{r["Name"][:86]:86s} {float(r["Calls"])/fw:7.1f}/fwd {float(r["AverageNs"])/1e3:9.2f} us '
                 f'{float(r["TotalDurationNs"])/fw/1e6:7.3f} ms/fwd {float(r["Percentage"]):5.1f}%')
         print("  ", line); o.write(line + "\n")
+# the ten convolutions of the last forward, in launch order (5 down, 5 up)
+t = glob.glob(f"gpurun_out/prof_{sys.argv[1]}/*/*kernel_trace.csv")[0]
+rows = [r for r in csv.DictReader(open(t)) if "conv2d_" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+with open(f"gpurun_out/prof_{sys.argv[1]}_kernels.txt", "a") as o:
+    for r in rows[-10:]:
+        line = f'conv2d launch: {r["Kernel_Name"][:40]:40s} grid {r["Grid_Size_X"]}x{r["Grid_Size_Y"]}x{r["Grid_Size_Z"]} {(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:9.1f} us'
+        print("  ", line); o.write(line + "\n")
 PY
 rm -rf $out
