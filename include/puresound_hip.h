@@ -510,8 +510,8 @@ int ps_conv1x1_f16_rows(const void* x, const void* wt_planes, const ps_f16x2_ran
                         int T, int ldt, const ps_prologue* pro, const float* bias, const float* bias_n, const void* res,
                         double* ostats, void* stream);
 /* ps_conv1x1_f16x2_f32 (no prologue, residual or statistics) writing its output FRAME-MAJOR: y [N][ldt][ldm], ldm >= M a
- * multiple of 4 -- the M outputs of a frame are consecutive -- instead of [N][M][ldt] (ldm = M + 64 keeps the 16 frames of
- * one store instruction off a common 4 KiB stride).  This is the layout ps_lstm_fmajor_f16x2_f32 reads its
+ * multiple of 4 -- the M outputs of a frame are consecutive -- instead of [N][M][ldt] (ldm = M is what the host side uses; a
+ * skew between frames made no measurable difference).  This is the layout ps_lstm_fmajor_f16x2_f32 reads its
  * gate pre-activations in: the LSTM input projection W_ih x + b of nn.LSTM (/root/reference/puresound/nnet/lobe/rnn.py:
  * 9-55 as used by dpcrn.py:34-81) written so that one step of 16 sequences is 16 contiguous 2 KiB runs.  Register-B kernel
  * only: ps_conv1x1_f16x2_fmajor_ok says whether a launch qualifies (as ps_conv1x1_f16_rows_ok, and ldm*ldt*4 < 2^31). */

@@ -1470,9 +1470,10 @@ static void rb_launch(const BfArgs& a, int N, bool tr, int Gr, hipStream_t strea
   b.delay = 0;
   // two m-tiles: workgroups 8 apart share a run of frame tiles, one m-tile each (see the kernel); needs an even grid
   // whose halves get whole, equal runs
-  b.pair_r = (a.tiles_m == 2 && Gr % 16 == 0 && !(g_debug_flags & 64)) ? 1 : 0;
-  if (b.pair_r) {  // (a pair's run of frame tiles must stay within PP_MAXU utterances too)
-    const long long fr = (long long)a.tiles_t * N, pw2 = (fr + Gr / 2 - 1) / (Gr / 2);
+  b.pair_r = ((a.tiles_m == 2 || a.tiles_m == 4) && Gr % (8 * a.tiles_m) == 0 && !(g_debug_flags & 64)) ? 1 : 0;
+  if (b.pair_r) {  // (a pair's / quad's run of frame tiles must stay within PP_MAXU utterances too)
+    const int gp = Gr / a.tiles_m;
+    const long long fr = (long long)a.tiles_t * N, pw2 = (fr + gp - 1) / gp;
     if ((pw2 + a.tiles_t - 2) / a.tiles_t + 1 > PP_MAXU) b.pair_r = 0;
   }
 #define PS_RB(TRV, STV, RSV) \

@@ -1122,7 +1122,7 @@ extern "C" int ps_lstm_fmajor_f16x2_f32(const ps_lstm_args* args, int ldm, void*
     return args ? PS_E_UNSUPPORTED : PS_E_INVALID;
   }
   const ps_lstm_args& a = *args;
-  LstmFm k{a, ldm, (a.Q + 15) / 16, 0};
+  LstmFm k{a, ldm, (g_debug_flags >> 24) & 15, (a.Q + 15) / 16, 0};
   k.total = a.N * k.nblk;
   // one workgroup per CU (148 KiB of LDS), the directions side by side; a multiple of 8 for the XCD-aware block order
   int cap = device_cus() / a.D / 8 * 8;
@@ -1131,7 +1131,8 @@ extern "C" int ps_lstm_fmajor_f16x2_f32(const ps_lstm_args* args, int ldm, void*
   dim3 grid((unsigned)(want < cap ? want : cap), 1, a.D);
   const int sp = (a.steps + 3) / 4 * 4;
   const bool contig = a.step_stride == 1 && a.q_stride % 4 == 0 && a.ldt % 4 == 0 && !((uintptr_t)a.hout & 15) &&
-                      (a.steps % 4 == 0 || (a.D == 1 && (long long)(a.Q - 1) * a.q_stride + sp <= a.ldt));
+                      (a.steps % 4 == 0 || (a.D == 1 && (long long)(a.Q - 1) * a.q_stride + sp <= a.ldt)) &&
+                      !(g_debug_flags & (1 << 20));  // (bit 20: 4-byte h' stores for consecutive frames too; tests run both)
   {
     LaunchTimer timer("lstm", (hipStream_t)stream);
     if (contig)

@@ -248,12 +248,12 @@ def conv1x1_f16x2(x: torch.Tensor, t: int, wt_planes: torch.Tensor, w_exp: int, 
     return y, stats, amax
 
 
-FMAJOR_PAD = int(os.environ.get("PS_FMAJOR_PAD", "64"))   # floats between the M outputs of consecutive frames
+FMAJOR_PAD = int(os.environ.get("PS_FMAJOR_PAD", "0"))   # floats between the M outputs of consecutive frames
 
 
 def fmajor_ld(m: int) -> int:
-    """Frame stride of the frame-major gate pre-activations: M + 64 floats, so that the 16 frames one store instruction of
-    the GEMM covers (and the 16 sequences one LSTM step reads) do not sit a multiple of 4 KiB apart."""
+    """Frame stride of the frame-major gate pre-activations: M (+ PS_FMAJOR_PAD floats; a 256-byte skew between frames was
+    tried against a suspected 4 KiB channel stride and made no difference: 1.40 / 1.39 / 1.31 ms per launch at 64 / 0 / 32)."""
     return m + FMAJOR_PAD
 
 
@@ -361,7 +361,8 @@ def attn_weights(logits: torch.Tensor, t: int, lengths: Optional[torch.Tensor] =
 
 def lstm(gx: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int, q: int, q_stride: int, steps: int,
          step_stride: int, h0: Optional[torch.Tensor] = None, c0: Optional[torch.Tensor] = None,
-         want_state: bool = False, state_shift: int = 0, state_out: Optional[tuple] = None, f16x2: bool = False):
+         want_state: bool = False, state_shift: int = 0, state_out: Optional[tuple] = None, f16x2: bool = False,
+         out: Optional[torch.Tensor] = None):
     """LSTM recurrence over gate pre-activations gx padded [N,D*4H,ldt] -> hout [N,D*H,ldt]
     (+ final (h, c) in state layout [N,D*H,ldq] when want_state / state_out).  f16x2: ps_lstm_f16x2_f32 (the
     recurrent product in two fp16 terms per operand where a kernel for it exists, else the fp32 kernels)."""
@@ -369,7 +370,9 @@ def lstm(gx: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int, q: int, 
     n, rows, ldt = gx.shape
     if rows != dirs * 4 * hidden or tuple(whh_t.shape) != (dirs, hidden, 4 * hidden):
         raise RuntimeError("lstm: gx must be [N, D*4H, ldt] and whh_t [D, H, 4H]")
-    hout = torch.empty(n, dirs * hidden, ldt, dtype=torch.float32, device=gx.device)
+    hout = out if out is not None else torch.empty(n, dirs * hidden, ldt, dtype=torch.float32, device=gx.device)
+    if tuple(hout.shape) != (n, dirs * hidden, ldt) or not hout.is_contiguous():
+        raise RuntimeError("lstm: out must be a contiguous [N, D*H, ldt] tensor")
     a = LstmArgs()
     a.gx, a.whh_t, a.hout = ptr(gx), ptr(whh_t), ptr(hout)
     ldq = padded_frames(q)
@@ -418,7 +421,7 @@ def lstm_fmajor_ok(n: int, ldt: int, hidden: int, dirs: int, q: int, q_stride: i
 
 
 def lstm_fmajor(gx_fm: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int, q: int, q_stride: int, steps: int,
-                step_stride: int) -> torch.Tensor:
+                step_stride: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """ps_lstm_fmajor_f16x2_f32: LSTM recurrence over FRAME-MAJOR gate pre-activations gx [N, ldt, D*4H] (from
     conv1x1_f16x2_fmajor; the frames may be padded rows: stride(1) >= D*4H) -> hout [N, D*H, ldt]; H = 128, zero initial
     states, fp16x2 recurrent product."""
@@ -429,7 +432,9 @@ def lstm_fmajor(gx_fm: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int
     ldm = gx_fm.stride(1)
     if gx_fm.stride(2) != 1 or gx_fm.stride(0) != ldt * ldm:
         raise RuntimeError("lstm_fmajor: gx must be a [N, ldt, :D*4H] view of contiguous frame rows")
-    hout = torch.empty(n, dirs * hidden, ldt, dtype=torch.float32, device=gx_fm.device)
+    hout = out if out is not None else torch.empty(n, dirs * hidden, ldt, dtype=torch.float32, device=gx_fm.device)
+    if tuple(hout.shape) != (n, dirs * hidden, ldt) or not hout.is_contiguous():
+        raise RuntimeError("lstm_fmajor: out must be a contiguous [N, D*H, ldt] tensor")
     a = _lstm_fmajor_args(gx_fm, whh_t, hout, hidden, dirs, q, q_stride, steps, step_stride)
     check(lib().ps_lstm_fmajor_f16x2_f32(C.byref(a), ldm, stream_ptr(gx_fm.device)), "ps_lstm_fmajor_f16x2_f32")
     return hout

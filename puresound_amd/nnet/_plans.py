@@ -137,6 +137,23 @@ def _proj_norm(x, hseq, t, rnn, proj, norm, amax):
     return hip.chan_layernorm(p, t, norm["gamma"], norm["beta"], norm["eps"], res=x)
 
 
+def _h_rows(rnn: dict, x: torch.Tensor, t: int, q: int, steps: int):
+    """Output rows of a recurrence.  When the sequences do not cover the span of t frames (the 2-D maps of DPCRN / DPARN:
+    F rows of ld frames, pad frames between them) the recurrence never writes the pad frames, and what follows it --
+    projection, LayerNorm, the next GEMM's range maximum -- runs over the whole span: the rows then come from a zeroed
+    buffer kept with the plan (pads stay zero from call to call), so stale memory (a NaN, an Inf) cannot reach the maximum.
+    None = let the kernel wrapper allocate (every frame is written)."""
+    if q * steps >= t:
+        return None
+    n, _, ldt = x.shape
+    key = (n, ldt, x.device)
+    bufs = rnn.setdefault("h_rows", {})
+    if key not in bufs:
+        bufs.clear()
+        bufs[key] = torch.zeros(n, rnn["D"] * rnn["H"], ldt, dtype=torch.float32, device=x.device)
+    return bufs[key]
+
+
 def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int, q_stride: int, steps: int,
               step_stride: int, h0=None, c0=None, want_state: bool = False, state_shift: int = 0, state_out=None,
               amax: Optional[list] = None):
@@ -160,7 +177,8 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
                 and hip.conv1x1_f16x2_fmajor_ok(n, rnn["I"], rnn["rows"], t, ldt)):
             gx_fm = hip.conv1x1_f16x2_fmajor(x, t, wf, we, rnn["rows"], rnn["bias"],
                                              x_amax=x_amax if x_amax is not None else hip.absmax(x, t))
-            hseq = hip.lstm_fmajor(gx_fm, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride)
+            hseq = hip.lstm_fmajor(gx_fm, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride,
+                                   out=_h_rows(rnn, x, t, q, steps))
             return _proj_norm(x, hseq, t, rnn, proj, norm, amax), None
         gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev)
         hip.conv1x1_f16x2(x, t, wf, we, rnn["rows"], None, rnn["bias"], out=gx,
@@ -175,5 +193,5 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
         gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev)
         hip.conv1x1(x, t, rnn["wih"], rnn["rows"], None, rnn["bias"], out=gx)
     hseq, state = hip.lstm(gx, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride, h0, c0, want_state,
-                           state_shift, state_out, f16x2=rnn["planes"] == 2)
+                           state_shift, state_out, f16x2=rnn["planes"] == 2, out=_h_rows(rnn, x, t, q, steps))
     return _proj_norm(x, hseq, t, rnn, proj, norm, amax), state

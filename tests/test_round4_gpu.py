@@ -154,6 +154,17 @@ def test_conv1x1_f16x2_frame_major_is_the_row_major_result_transposed(H, dev):
             assert rel_max(y_rm[..., :t].cpu().numpy(), ref.numpy()) < 2e-6
     finally:
         _abi.lib().ps_debug_flags(old)
+    # a launch that fills the chip: 512 workgroups, the four m-tiles of a frame tile on four workgroups of one XCD
+    n2, t2, m2 = 8, 2000, 1024
+    x2 = H.pad_rows(_rand4((n2, k, t2), 405).to(dev))
+    w2 = _rand4((m2, k), 406, -0.3, 0.3).to(dev)
+    wf2, we2 = H.pack_wt_f16x2(w2)
+    am2 = H.absmax(x2, t2)
+    y_rm, _, _ = H.conv1x1_f16x2(x2, t2, wf2, we2, m2, None, None, x_amax=am2)
+    y_fm = H.conv1x1_f16x2_fmajor(x2, t2, wf2, we2, m2, None, x_amax=am2)
+    assert torch.equal(y_fm.transpose(1, 2), y_rm)
+    ref = torch.einsum("mk,nkt->nmt", w2.double().cpu(), x2[..., :t2].double().cpu())
+    assert rel_max(y_rm[..., :t2].cpu().numpy(), ref.numpy()) < 2e-6
     assert not H.conv1x1_f16x2_fmajor_ok(n, 100, 512, t, ldt)      # K not a multiple of 32
     assert not H.conv1x1_f16x2_fmajor_ok(n, 128, 384, t, ldt)      # M not a multiple of 256
 

@@ -107,6 +107,8 @@ def cfg4_data_parallel(args, world):
 def dpcrn(args):
     """The real egs/ns model (ns_dpcrn_v0_causal: conv-STFT 512/128 + DPCRN + complex mask + iSTFT), 32 x 4 s."""
     dev = "cuda:0"
+    if os.environ.get("PS_FLAGS"):   # experiments: ps_debug_flags for the whole run
+        _abi.lib().ps_debug_flags(int(os.environ["PS_FLAGS"], 0))
     model = cases.build(PA.NS, "ns_dpcrn_short").eval()
     model.load_state_dict(det_state_dict(model))
     model.to(dev)
