@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PURESOUND_HIP_LIB: an experimental build of the same library (tools/build_variant.sh); kernel experiments only
 LIB_PATH = os.environ.get("PURESOUND_HIP_LIB") or os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -131,6 +131,8 @@ SIGNATURES = {
     "ps_conv_tasnet_ranged_f32": (C.c_int, [C.POINTER(TcnBlock), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                             C.c_int, _vp, C.c_size_t, _vp, C.c_int, _vp]),
     "ps_conv1x1_f16_rows_ok": (C.c_int, [C.c_int] * 4),
+    "ps_conv1x1_f16x2_ln_ok": (C.c_int, [C.c_int] * 4),
+    "ps_conv1x1_f16x2_ln_f32": (C.c_int, [_vp, _vp, C.POINTER(F16x2Range), _vp] + [C.c_int] * 5 + [_vp, _vp, _vp, C.c_float, _vp, _vp]),
     "ps_conv1x1_f16x2_fmajor_ok": (C.c_int, [C.c_int] * 6),
     "ps_conv1x1_f16x2_fmajor_f32": (C.c_int, [_vp, _vp, C.POINTER(F16x2Range), _vp] + [C.c_int] * 6 + [_vp, _vp]),
     "ps_conv1x1_f16_rows": (C.c_int, [_vp, _vp, C.POINTER(F16x2Range), _vp] + [C.c_int] * 5 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),

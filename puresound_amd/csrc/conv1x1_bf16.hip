@@ -80,6 +80,9 @@ struct BfArgs {
   int x_bf16, y_bf16;  // the rows of x / y are bf16 in HBM (PLANES = 1 only; bias, residual, statistics stay fp32 / fp64)
   int delay, groups;   // interleaved kernel: start offset (cycles) between the `groups` phases of workgroups
   int fm_ld;           // register-B kernel, frame-major output: floats between consecutive frames (>= M)
+  const float* ln_gamma;  // register-B kernel, LayerNorm epilogue (ps_conv1x1_f16x2_ln_f32): 128 channels
+  const float* ln_beta;
+  float ln_eps;
   int pair_r;          // interleaved kernel, two m-tiles: > 0 = workgroups per (utterance, m-tile) row; the two
                        // workgroups that read the same activation tiles are placed on the same XCD (see bf16_launch)
   // PLANES = 2: activations are multiplied by a power of two before the fp16 split, accumulators by
@@ -1462,7 +1465,7 @@ static bool rb_ok(const BfArgs& a, int N, int* Gr_out) {
   return true;
 }
 
-template <bool R16, bool FM = false>
+template <bool R16, bool FM = false, bool LNE = false>
 static void rb_launch(const BfArgs& a, int N, bool tr, int Gr, hipStream_t stream) {
   const bool stats = a.ostats != nullptr, res = a.res != nullptr;
   BfArgs& b = const_cast<BfArgs&>(a);
@@ -1480,6 +1483,10 @@ static void rb_launch(const BfArgs& a, int N, bool tr, int Gr, hipStream_t strea
   hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<TRV, STV, RSV, R16>), dim3(Gr, 1), dim3(256), 0, stream, a)
   if constexpr (FM) {  // (split_gemm admits no prologue, residual or statistics here)
     hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<false, false, false, false, true>), dim3(Gr, 1), dim3(256), 0, stream, a);
+    return;
+  }
+  if constexpr (LNE) {
+    hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<false, false, false, false, false, true>), dim3(Gr, 1), dim3(256), 0, stream, a);
     return;
   }
   if (tr) {
@@ -1694,6 +1701,61 @@ extern "C" int ps_conv1x1_f16x2_fmajor_f32(const float* x, const void* wt_planes
     return PS_E_INVALID;
   }
   return split_gemm(x, 0, wt_planes, rng, y, 0, N, K, M, T, ldt, 2, nullptr, bias, nullptr, nullptr, nullptr, stream, ldm);
+}
+
+extern "C" int ps_conv1x1_f16x2_ln_ok(int N, int K, int C, int T) { return C == 128 && ps_conv1x1_f16_rows_ok(N, K, 256, T); }
+
+extern "C" int ps_conv1x1_f16x2_ln_f32(const float* x, const void* wt_planes, const ps_f16x2_range* rng, float* y, int N, int K,
+                                       int C, int T, int ldt, const float* bias, const float* gamma, const float* beta,
+                                       float eps, const float* res, void* stream) {
+  if (!rng || rng->w_exp < -100 || rng->w_exp > 100 || rng->x_bound < 0.f || (rng->x_amax && rng->x_amax_parts <= 0)) {
+    set_error("ps_conv1x1_f16x2_ln_f32: range descriptor missing or out of range (w_exp within +-100, x_bound >= 0)");
+    return PS_E_INVALID;
+  }
+  if (!x || !wt_planes || !y || !gamma || !beta || N <= 0 || K <= 0 || T <= 0 || N > 65535 || !(eps >= 0.f)) {
+    set_error("ps_conv1x1_f16x2_ln_f32: null pointer or non-positive size (N=%d K=%d C=%d T=%d)", N, K, C, T);
+    return PS_E_INVALID;
+  }
+  if (C != 128 || ldt < T || ldt % kTileT != 0 || ((uintptr_t)wt_planes & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) ||
+      (long long)128 * ldt * 4 >= (1LL << 31)) {
+    set_error("ps_conv1x1_f16x2_ln_f32: C = 128 channels, ldt a multiple of %d >= T, 16-byte aligned parameters (ps_conv1x1_f16x2_ln_ok)",
+              kTileT);
+    return PS_E_UNSUPPORTED;
+  }
+  BfArgs a{};
+  a.x = x, a.wt = (const unsigned short*)wt_planes, a.y = y, a.bias = bias, a.res = res;
+  a.K = K, a.M = 256, a.T = T, a.ldt = ldt, a.N = N;  // (the weight image has 256 rows, the upper 128 of them zero)
+  a.ksteps = (K + XB_K - 1) / XB_K, a.tiles_t = (T + XB_T - 1) / XB_T, a.tiles_m = 1;
+  a.ablate = (g_debug_flags >> 24) & 15;
+  a.stamps = (unsigned long long*)g_debug_buffer;
+  a.ln_gamma = gamma, a.ln_beta = beta, a.ln_eps = eps;
+  int x_exp = -4;
+  if (rng->x_bound > 0.f) {
+    int e;
+    frexpf(rng->x_bound, &e);
+    x_exp = 15 - e;
+    x_exp = x_exp < -100 ? -100 : (x_exp > 100 ? 100 : x_exp);
+  }
+  a.xscale = ldexpf(1.f, x_exp);
+  a.winv = ldexpf(1.f, -rng->w_exp);
+  a.x_amax = rng->x_bound > 0.f ? nullptr : rng->x_amax;
+  a.x_amax_parts = rng->x_amax_parts;
+  a.y_amax = rng->y_amax;  // [N][ps_conv1x1_stats_parts(256, T)] partial maxima of |y| (the next GEMM's input range) or NULL
+  int Gr = 0;
+  if (!rb_ok(a, N, &Gr)) {
+    set_error("ps_conv1x1_f16x2_ln_f32: this launch cannot run on the register-B kernel (ps_conv1x1_f16x2_ln_ok)");
+    return PS_E_UNSUPPORTED;
+  }
+  {
+    LaunchTimer timer("conv1x1_bf16", (hipStream_t)stream);
+    rb_launch<false, false, true>(a, N, false, Gr, (hipStream_t)stream);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("ps_conv1x1_f16x2_ln_f32: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
 }
 
 extern "C" int ps_conv1x1_f16_rows_ok(int N, int K, int M, int T) {

@@ -16,6 +16,7 @@ import os
 
 FUSE_PROJ_LN = os.environ.get("PS_FUSE_PROJ_LN", "1") == "1"   # 0: separate projection GEMM + LayerNorm kernels
 FUSE_PROJ_LN_MAX_FRAMES = int(os.environ.get("PS_FUSE_PROJ_LN_MAX_FRAMES", "8192"))
+FUSE_GEMM_LN = os.environ.get("PS_FUSE_GEMM_LN", "1") == "1"    # 0: projection GEMM and LayerNorm + skip as two launches
 FMAJOR_LSTM = os.environ.get("PS_FMAJOR_LSTM", "1") == "1"      # 0: H = 128 recurrences stay on the channel-major kernels
 
 
@@ -126,6 +127,19 @@ def _proj_norm(x, hseq, t, rnn, proj, norm, amax):
                 amax[0] = None
         y, _ = hip.proj_layernorm(hseq, t, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"], norm["eps"], x)
         return y
+    if (FUSE_GEMM_LN and rnn["planes"] == 2 and proj["M"] == 128 and proj["K"] % 32 == 0
+            and hip.conv1x1_f16x2_ln_ok(n, proj["K"], 128, t)):
+        # projection, LayerNorm and skip as ONE launch: the fp16x2 GEMM with the norm as its epilogue (|h| < 1 is its range)
+        if "f16x2_ln" not in proj:
+            w256 = torch.zeros(256, proj["K"], dtype=torch.float32, device=dev)
+            w256[:128] = proj["w_rows"]
+            proj["f16x2_ln"] = hip.pack_wt_f16x2(w256)
+        wf, we = proj["f16x2_ln"]
+        if amax is not None:   # the maxima of |y| ride along: the next recurrence's GEMM needs no pass of its own over y
+            y, amax[0] = hip.conv1x1_f16x2_ln(hseq, t, wf, we, 128, proj["bias"], norm["gamma"], norm["beta"], norm["eps"], x,
+                                              x_bound=1.0, want_amax=True)
+            return y
+        return hip.conv1x1_f16x2_ln(hseq, t, wf, we, 128, proj["bias"], norm["gamma"], norm["beta"], norm["eps"], x, x_bound=1.0)
     p = torch.empty(n, proj["M"], ldt, dtype=torch.float32, device=dev)
     if rnn["planes"] == 2 and proj["K"] >= 64:
         # the recurrence's arithmetic for its projection too: h is an LSTM output, |h| < 1 is its range

@@ -34,14 +34,16 @@ class DPRNNblock2D(PlanCache, nn.Module):
                     inter=(lstm_plan(self.inter_rnn.rnn, device, self.gemm_precision), linear_plan(self.inter_rnn.proj, device),
                            layernorm_plan(self.inter_norm, device)))
 
-    def forward_padded(self, x: torch.Tensor, t: int) -> torch.Tensor:
-        """[N, CH, F, ld] -> [N, CH, F, ld]."""
+    def forward_padded(self, x: torch.Tensor, t: int, amax=None) -> torch.Tensor:
+        """[N, CH, F, ld] -> [N, CH, F, ld].  amax: the one-element list of lstm_path (fp16x2 arithmetic: the maxima of |x|
+        travel from recurrence to recurrence and from block to block instead of being measured before every GEMM)."""
         p = self._plan_get(x.device, self._build)
         n, ch, f, ld = x.shape
         y = x.view(n, ch, f * ld)
         frames = (f - 1) * ld + t                      # frames of the flattened (f, t) axis that hold data
-        y, _ = lstm_path(y, frames, *p["intra"], q=t, q_stride=1, steps=f, step_stride=ld)
-        y, _ = lstm_path(y, frames, *p["inter"], q=f, q_stride=ld, steps=t, step_stride=1)
+        amax = [None] if amax is None else amax
+        y, _ = lstm_path(y, frames, *p["intra"], q=t, q_stride=1, steps=f, step_stride=ld, amax=amax)
+        y, _ = lstm_path(y, frames, *p["inter"], q=f, q_stride=ld, steps=t, step_stride=1, amax=amax)
         return y.view(n, ch, f, ld)
 
     def forward(self, x: torch.Tensor, intra_skip: bool = True, inter_skip: bool = True) -> torch.Tensor:
@@ -78,8 +80,9 @@ class DPCRN(Unet):
             raise NotImplementedError("DPCRN on HIP: spectral_compress (it returns a complex tensor in the reference)")
         p = self._plan_get(x4.device, self._build_unet)
         skip = self._down(x4, t, p)
-        y = self.dprnn_block1.forward_padded(skip[-1], t)
-        y = self.dprnn_block2.forward_padded(y, t)
+        amax = [None]
+        y = self.dprnn_block1.forward_padded(skip[-1], t, amax)
+        y = self.dprnn_block2.forward_padded(y, t, amax)
         return self._up(y, skip, t, p, self.transpose_delay)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -255,3 +255,39 @@ def test_dpcrn_preset_takes_the_frame_major_recurrence(PA, dev):
         err = float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref))
         assert err < 2e-5, (on, err)
     assert not torch.equal(outs[True], outs[False])   # (the two paths are different kernels)
+
+
+@pytest.mark.parametrize("n,k,t,flags", [(2, 128, 300, 1 << 28), (3, 256, 1000, 1 << 28), (16, 256, 2000, 0)])
+def test_gemm_with_layernorm_epilogue(H, dev, n, k, t, flags):
+    """ps_conv1x1_f16x2_ln_f32: y = res + LayerNorm_128(W x + b) in one launch (the projection behind a recurrence, |x| < 1)
+    against float64 and against the two-launch path it replaces (fp16x2 GEMM, then ps_chan_layernorm_f32)."""
+    from puresound_amd import _abi
+    import torch.nn.functional as F
+    c = 128
+    x = _rand4((n, k, t), 501, -0.95, 0.95)
+    w, b = _rand4((c, k), 502, -0.3, 0.3), _rand4((c,), 503, -0.5, 0.5)
+    g, be = _rand4((c,), 504, 0.5, 1.5), _rand4((c,), 505, -0.3, 0.3)
+    res = _rand4((n, c, t), 506)
+    p = torch.einsum("mk,nkt->nmt", w.double(), x.double()) + b.double()[None, :, None]
+    ref = res.double() + F.layer_norm(p.transpose(1, 2), (c,), g.double(), be.double(), 1e-5).transpose(1, 2)
+    xp, rp = H.pad_rows(x.to(dev)), H.pad_rows(res.to(dev))
+    w256 = torch.zeros(256, k)
+    w256[:c] = w
+    wf, we = H.pack_wt_f16x2(w256.to(dev))
+    wf1, we1 = H.pack_wt_f16x2(w.to(dev))
+    old = _abi.lib().ps_debug_flags(flags)
+    try:
+        assert H.conv1x1_f16x2_ln_ok(n, k, c, t)
+        y = H.conv1x1_f16x2_ln(xp, t, wf, we, c, b.to(dev), g.to(dev), be.to(dev), 1e-5, rp, x_bound=1.0)
+        y_nores = H.conv1x1_f16x2_ln(xp, t, wf, we, c, None, g.to(dev), be.to(dev), 1e-5, None, x_bound=1.0)
+        p2, _, _ = H.conv1x1_f16x2(xp, t, wf1, we1, c, None, b.to(dev), x_bound=1.0)
+        y2 = H.chan_layernorm(p2, t, g.to(dev), be.to(dev), 1e-5, res=rp)
+        torch.cuda.synchronize()
+    finally:
+        _abi.lib().ps_debug_flags(old)
+    assert rel_max(y[..., :t].cpu().numpy(), ref.numpy()) < 5e-6
+    assert rel_max(y[..., :t].cpu().numpy(), y2[..., :t].cpu().numpy()) < 5e-6
+    p0 = torch.einsum("mk,nkt->nmt", w.double(), x.double())
+    ref0 = F.layer_norm(p0.transpose(1, 2), (c,), g.double(), be.double(), 1e-5).transpose(1, 2)
+    assert rel_max(y_nores[..., :t].cpu().numpy(), ref0.numpy()) < 5e-6
+    assert not H.conv1x1_f16x2_ln_ok(n, k, 64, t) and not H.conv1x1_f16x2_ln_ok(n, 100, c, t)
