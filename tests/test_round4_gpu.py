@@ -162,7 +162,8 @@ def test_conv1x1_f16x2_frame_major_is_the_row_major_result_transposed(H, dev):
     am2 = H.absmax(x2, t2)
     y_rm, _, _ = H.conv1x1_f16x2(x2, t2, wf2, we2, m2, None, None, x_amax=am2)
     y_fm = H.conv1x1_f16x2_fmajor(x2, t2, wf2, we2, m2, None, x_amax=am2)
-    assert torch.equal(y_fm.transpose(1, 2), y_rm)
+    cov = (t2 + 127) // 128 * 128   # (the GEMM writes whole 128-frame tiles up to T; rows are padded to an odd tile count)
+    assert torch.equal(y_fm.transpose(1, 2)[..., :cov], y_rm[..., :cov])
     ref = torch.einsum("mk,nkt->nmt", w2.double().cpu(), x2[..., :t2].double().cpu())
     assert rel_max(y_rm[..., :t2].cpu().numpy(), ref.numpy()) < 2e-6
     assert not H.conv1x1_f16x2_fmajor_ok(n, 100, 512, t, ldt)      # K not a multiple of 32
