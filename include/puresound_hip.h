@@ -518,16 +518,21 @@ int ps_conv1x1_f16_rows(const void* x, const void* wt_planes, const ps_f16x2_ran
 int ps_conv1x1_f16x2_fmajor_ok(int N, int K, int M, int T, int ldt, int ldm);
 int ps_conv1x1_f16x2_fmajor_f32(const float* x, const void* wt_planes, const ps_f16x2_range* rng, float* y, int N, int K,
                                 int M, int T, int ldt, int ldm, const float* bias, void* stream);
-/* Projection + LayerNorm over channels + skip in one launch: y[n][c][t] = res[n][c][t] + LN_c(W x + b)[c], C = 128 output
- * channels (nn.Linear + nn.LayerNorm + the residual behind each recurrence of DPRNNblock2D / DPARNblock2D,
- * /root/reference/puresound/nnet/dpcrn.py:56-80, dparn.py:81-108), the GEMM in the fp16x2 arithmetic of
- * ps_conv1x1_f16x2_f32 with the LayerNorm (two-pass variance, eps inside the root, as nn.LayerNorm) as its epilogue.
- * wt_planes: the fp16x2 image of W zero padded to 256 rows; bias [128] or NULL; gamma, beta [128], 16-byte aligned; res
- * [N][128][ldt] or NULL.  Register-B kernel only: ps_conv1x1_f16x2_ln_ok(N, K, C, T) says whether a launch qualifies. */
+/* Projection + LayerNorm over channels + skip in one launch, C = 128 output channels:
+ *   res_inside = 0:  y[n][c][t] = res[n][c][t] + LN_c(W f(x) + b)[c]   (nn.Linear + nn.LayerNorm + the residual behind each
+ *                    recurrence of DPRNNblock2D / DPARNblock2D, /root/reference/puresound/nnet/dpcrn.py:56-80, dparn.py:81-108)
+ *   res_inside = 1:  y = LN_c(W f(x) + b + res)                        (the post-norm blocks of MhaSelfAttenLayer,
+ *                    lobe/attention.py:202-232: out_proj + residual + norm1, feed-forward + residual + norm2)
+ * The GEMM runs in the fp16x2 arithmetic of ps_conv1x1_f16x2_f32 with the LayerNorm (two-pass variance, eps inside the root,
+ * as nn.LayerNorm) as its epilogue; f = the prologue `pro` (NULL, a per-channel affine map and / or a PReLU: the ReLU in
+ * front of the second feed-forward layer is the PReLU of slope 0).  wt_planes: the fp16x2 image of W zero padded to 256 rows;
+ * bias [128] or NULL; gamma, beta [128], 16-byte aligned; res [N][128][ldt] or NULL; rng->y_amax as ps_conv1x1_f16x2_f32
+ * with ps_conv1x1_stats_parts(256, T) parts.  Register-B kernel only: ps_conv1x1_f16x2_ln_ok(N, K, C, T) says whether a
+ * launch qualifies. */
 int ps_conv1x1_f16x2_ln_ok(int N, int K, int C, int T);
 int ps_conv1x1_f16x2_ln_f32(const float* x, const void* wt_planes, const ps_f16x2_range* rng, float* y, int N, int K, int C,
-                            int T, int ldt, const float* bias, const float* gamma, const float* beta, float eps,
-                            const float* res, void* stream);
+                            int T, int ldt, const ps_prologue* pro, const float* bias, const float* gamma, const float* beta,
+                            float eps, const float* res, int res_inside, void* stream);
 /* partial maxima of |x| over the valid frames: amax [N][ps_absmax_parts()] */
 int ps_absmax_parts(void);
 int ps_absmax_f32(const float* x, float* amax, int N, int C, int T, int ldt, void* stream);

@@ -132,7 +132,8 @@ SIGNATURES = {
                                             C.c_int, _vp, C.c_size_t, _vp, C.c_int, _vp]),
     "ps_conv1x1_f16_rows_ok": (C.c_int, [C.c_int] * 4),
     "ps_conv1x1_f16x2_ln_ok": (C.c_int, [C.c_int] * 4),
-    "ps_conv1x1_f16x2_ln_f32": (C.c_int, [_vp, _vp, C.POINTER(F16x2Range), _vp] + [C.c_int] * 5 + [_vp, _vp, _vp, C.c_float, _vp, _vp]),
+    "ps_conv1x1_f16x2_ln_f32": (C.c_int, [_vp, _vp, C.POINTER(F16x2Range), _vp] + [C.c_int] * 5
+                                + [C.POINTER(Prologue), _vp, _vp, _vp, C.c_float, _vp, C.c_int, _vp]),
     "ps_conv1x1_f16x2_fmajor_ok": (C.c_int, [C.c_int] * 6),
     "ps_conv1x1_f16x2_fmajor_f32": (C.c_int, [_vp, _vp, C.POINTER(F16x2Range), _vp] + [C.c_int] * 6 + [_vp, _vp]),
     "ps_conv1x1_f16_rows": (C.c_int, [_vp, _vp, C.POINTER(F16x2Range), _vp] + [C.c_int] * 5 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),

@@ -79,6 +79,91 @@ __global__ __launch_bounds__(ATT_SQ * 64) void self_attention_kernel(AttArgs a) 
   }
 }
 
+// ---- round 4: the same attention for L <= 64 positions, head dimension known at compile time -----------------------------
+// ns_dparn_v0_causal at 32 x 4 s runs four of these launches over 16,032 sequences x 8 heads of 64 positions (dh = 16):
+// 33.6 GFLOP and 2.1 GB each -- and the kernel above took 11.8 ms per launch, 58 % of the forward
+// (profiles/r04_dparn_kernels_before.txt): its loops run to ATT_MAXD = 64 with the head dimension as a run-time predicate
+// (4 x the instructions at dh = 16, 128 registers of q / o), every key costs 2 dh one-float LDS reads and two exps (online
+// softmax), and neighbouring workgroups -- which share every 128-byte line of the q / k / v rows, 16 bytes each -- sit on
+// eight different XCDs, so every line comes from HBM eight times.
+// Here: DH is a template parameter; K and V sit in LDS as [key][sequence][DH + 4] and are read 16 bytes at a time (a
+// broadcast per sequence); a thread (sequence, query) computes its L <= 64 scores into registers, takes the maximum,
+// exponentiates once per key and accumulates P V -- softmax(q k / sqrt(dh)) v in the reference's order of operations;
+// workgroup ids are renumbered so that the eight workgroups sharing a line run on ONE XCD, back to back.
+template <int DH>
+__global__ __launch_bounds__(ATT_SQ * 64) void self_attention_l64_kernel(AttArgs a) {
+  constexpr int RS = DH + 4;  // floats per (key, sequence) row: 16-byte aligned, rows of the 4 sequences in different banks
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // k[L][SQ][RS] | v[L][SQ][RS]
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int per = gridDim.x >> 3;  // (the grid is a multiple of 8 workgroups along x)
+  const int q0 = ((blockIdx.x & 7) * per + (blockIdx.x >> 3)) * ATT_SQ;
+  float* ks = sm;
+  float* vs = sm + a.L * ATT_SQ * RS;
+  const float* base = a.qkv + (size_t)n * 3 * a.E * a.ld;
+  for (int idx = threadIdx.x; idx < DH * a.L * ATT_SQ; idx += ATT_SQ * 64) {
+    const int s = idx % ATT_SQ, pos = (idx / ATT_SQ) % a.L, d = idx / (ATT_SQ * a.L);
+    const int q = q0 + s;
+    float kv = 0.f, vv = 0.f;
+    if (q < a.Q) {
+      const size_t fr = (size_t)q * a.q_stride + (size_t)pos * a.pos_stride;
+      kv = base[(size_t)(a.E + h * DH + d) * a.ld + fr];
+      vv = base[(size_t)(2 * a.E + h * DH + d) * a.ld + fr];
+    }
+    ks[(pos * ATT_SQ + s) * RS + d] = kv;
+    vs[(pos * ATT_SQ + s) * RS + d] = vv;
+  }
+  const int s = threadIdx.x % ATT_SQ, i = threadIdx.x / ATT_SQ;
+  const int q = q0 + s;
+  const bool live = q < a.Q && i < a.L;
+  const size_t fr = live ? (size_t)q * a.q_stride + (size_t)i * a.pos_stride : 0;
+  float qv[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) qv[d] = live ? base[(size_t)(h * DH + d) * a.ld + fr] * a.scale : 0.f;
+  __syncthreads();
+  if (!live) return;
+  const int jend = a.causal ? i + 1 : a.L;
+  float sc[64];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    float acc = -INFINITY;
+    if (j < jend) {  // (j < jend <= L <= 64)
+      const f32x4* kr = reinterpret_cast<const f32x4*>(ks + (j * ATT_SQ + s) * RS);
+      acc = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < DH / 4; ++d4) {
+        const f32x4 k4 = kr[d4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fmaf(qv[4 * d4 + e], k4[e], acc);
+      }
+      m = fmaxf(m, acc);
+    }
+    sc[j] = acc;
+  }
+  float z = 0.f;
+  float o[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    if (j < jend) {
+      const float p = expf(sc[j] - m);
+      z += p;
+      const f32x4* vr = reinterpret_cast<const f32x4*>(vs + (j * ATT_SQ + s) * RS);
+#pragma unroll
+      for (int d4 = 0; d4 < DH / 4; ++d4) {
+        const f32x4 v4 = vr[d4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[4 * d4 + e] = fmaf(p, v4[e], o[4 * d4 + e]);
+      }
+    }
+  }
+  const float rz = 1.f / z;
+  float* dst = a.out + (size_t)n * a.E * a.ld + fr;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) dst[(size_t)(h * DH + d) * a.ld] = o[d] * rz;
+}
+
 // y[n][c][pos*pos_stride + q*q_stride] = x[...] + pe[pos][c]   (PositionalEncoding.forward, lobe/attention.py:27-35)
 __global__ __launch_bounds__(256) void add_position_kernel(const float* __restrict__ x, const float* __restrict__ pe,
                                                            float* __restrict__ y, int E, int Q, int q_stride,
@@ -123,6 +208,20 @@ extern "C" int ps_self_attention_f32(const float* qkv, float* out, int N, int E,
     return PS_E_INVALID;
   }
   AttArgs a{qkv, out, E, heads, Q, q_stride, L, pos_stride, ld, causal, 1.f / sqrtf((float)dh)};
+  // L <= 64 positions with a head dimension of 16 / 32 / 64: the register-score kernel (ps_debug_flags bit 23 keeps the
+  // general one; tests run both)
+  const size_t lds64 = (size_t)2 * L * ATT_SQ * (dh + 4) * sizeof(float);
+  if (L <= 64 && (dh == 16 || dh == 32 || dh == 64) && lds64 <= 64 * 1024 && !(g_debug_flags & (1 << 23))) {
+    LaunchTimer timer("self_attention", (hipStream_t)stream);
+    dim3 g((((Q + ATT_SQ - 1) / ATT_SQ) + 7) / 8 * 8, heads, N);
+    if (dh == 16)
+      hipLaunchKernelGGL((self_attention_l64_kernel<16>), g, dim3(ATT_SQ * 64), lds64, (hipStream_t)stream, a);
+    else if (dh == 32)
+      hipLaunchKernelGGL((self_attention_l64_kernel<32>), g, dim3(ATT_SQ * 64), lds64, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((self_attention_l64_kernel<64>), g, dim3(ATT_SQ * 64), lds64, (hipStream_t)stream, a);
+    return att_status("ps_self_attention_f32");
+  }
   {
     LaunchTimer timer("self_attention", (hipStream_t)stream);
     hipLaunchKernelGGL(self_attention_kernel, dim3((Q + ATT_SQ - 1) / ATT_SQ, heads, N), dim3(ATT_SQ * 64), lds,

@@ -83,6 +83,7 @@ struct BfArgs {
   const float* ln_gamma;  // register-B kernel, LayerNorm epilogue (ps_conv1x1_f16x2_ln_f32): 128 channels
   const float* ln_beta;
   float ln_eps;
+  int ln_inside;  // 1: y = LN(W f(x) + b + res) (post-norm transformer blocks) instead of res + LN(W f(x) + b)
   int pair_r;          // interleaved kernel, two m-tiles: > 0 = workgroups per (utterance, m-tile) row; the two
                        // workgroups that read the same activation tiles are placed on the same XCD (see bf16_launch)
   // PLANES = 2: activations are multiplied by a power of two before the fp16 split, accumulators by
@@ -1486,7 +1487,10 @@ static void rb_launch(const BfArgs& a, int N, bool tr, int Gr, hipStream_t strea
     return;
   }
   if constexpr (LNE) {
-    hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<false, false, false, false, false, true>), dim3(Gr, 1), dim3(256), 0, stream, a);
+    if (tr)
+      hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<true, false, false, false, false, true>), dim3(Gr, 1), dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL((conv1x1_f16x2_rb_kernel<false, false, false, false, false, true>), dim3(Gr, 1), dim3(256), 0, stream, a);
     return;
   }
   if (tr) {
@@ -1706,8 +1710,8 @@ extern "C" int ps_conv1x1_f16x2_fmajor_f32(const float* x, const void* wt_planes
 extern "C" int ps_conv1x1_f16x2_ln_ok(int N, int K, int C, int T) { return C == 128 && ps_conv1x1_f16_rows_ok(N, K, 256, T); }
 
 extern "C" int ps_conv1x1_f16x2_ln_f32(const float* x, const void* wt_planes, const ps_f16x2_range* rng, float* y, int N, int K,
-                                       int C, int T, int ldt, const float* bias, const float* gamma, const float* beta,
-                                       float eps, const float* res, void* stream) {
+                                       int C, int T, int ldt, const ps_prologue* pro, const float* bias, const float* gamma,
+                                       const float* beta, float eps, const float* res, int res_inside, void* stream) {
   if (!rng || rng->w_exp < -100 || rng->w_exp > 100 || rng->x_bound < 0.f || (rng->x_amax && rng->x_amax_parts <= 0)) {
     set_error("ps_conv1x1_f16x2_ln_f32: range descriptor missing or out of range (w_exp within +-100, x_bound >= 0)");
     return PS_E_INVALID;
@@ -1723,13 +1727,23 @@ extern "C" int ps_conv1x1_f16x2_ln_f32(const float* x, const void* wt_planes, co
     return PS_E_UNSUPPORTED;
   }
   BfArgs a{};
+  bool tr = false;
+  if (pro) {
+    a.pro = *pro;
+    tr = pro->norm != PS_NORM_NONE || pro->prelu;
+    if (pro->pre_relu || pro->post_tanh || pro->norm == PS_NORM_GLOBAL || (pro->norm == PS_NORM_AFFINE && (!pro->gamma || !pro->beta)) ||
+        (pro->prelu && !pro->slope) || K > 512) {
+      set_error("ps_conv1x1_f16x2_ln_f32: the prologue may be a per-channel affine map and / or a PReLU (a ReLU is the PReLU of slope 0)");
+      return PS_E_UNSUPPORTED;
+    }
+  }
   a.x = x, a.wt = (const unsigned short*)wt_planes, a.y = y, a.bias = bias, a.res = res;
   a.K = K, a.M = 256, a.T = T, a.ldt = ldt, a.N = N;  // (the weight image has 256 rows, the upper 128 of them zero)
   a.ksteps = (K + XB_K - 1) / XB_K, a.tiles_t = (T + XB_T - 1) / XB_T, a.tiles_m = 1;
   a.ablate = (g_debug_flags >> 24) & 15;
   a.stamps = (unsigned long long*)g_debug_buffer;
-  a.ln_gamma = gamma, a.ln_beta = beta, a.ln_eps = eps;
-  int x_exp = -4;
+  a.ln_gamma = gamma, a.ln_beta = beta, a.ln_eps = eps, a.ln_inside = res_inside && res ? 1 : 0;
+  int x_exp = (tr && a.pro.norm != PS_NORM_NONE) ? -2 : -4;
   if (rng->x_bound > 0.f) {
     int e;
     frexpf(rng->x_bound, &e);
@@ -1748,7 +1762,7 @@ extern "C" int ps_conv1x1_f16x2_ln_f32(const float* x, const void* wt_planes, co
   }
   {
     LaunchTimer timer("conv1x1_bf16", (hipStream_t)stream);
-    rb_launch<false, false, true>(a, N, false, Gr, (hipStream_t)stream);
+    rb_launch<false, false, true>(a, N, tr, Gr, (hipStream_t)stream);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -283,10 +283,12 @@ def conv1x1_f16x2_ln_ok(n: int, k: int, c: int, t: int) -> bool:
 def conv1x1_f16x2_ln(x: torch.Tensor, t: int, wt_planes: torch.Tensor, w_exp: int, c: int, bias: Optional[torch.Tensor],
                      gamma: torch.Tensor, beta: torch.Tensor, eps: float, res: Optional[torch.Tensor],
                      x_bound: float = 0.0, x_amax: Optional[torch.Tensor] = None,
-                     out: Optional[torch.Tensor] = None, want_amax: bool = False):
+                     out: Optional[torch.Tensor] = None, want_amax: bool = False, pro: Optional[Prologue] = None,
+                     res_inside: bool = False):
     """ps_conv1x1_f16x2_ln_f32: y = res + LayerNorm_channels(W x + b) in one launch (C = 128; wt_planes = pack_wt_f16x2 of
-    W zero padded to 256 rows).  Raises when the launch does not qualify (conv1x1_f16x2_ln_ok).  want_amax: returns
-    (y, [N, parts] partial maxima of |y|) -- the x_amax of the next fp16x2 GEMM."""
+    W zero padded to 256 rows), or y = LayerNorm(W x + b + res) with res_inside; `pro`: affine / PReLU prologue on x.
+    Raises when the launch does not qualify (conv1x1_f16x2_ln_ok).  want_amax: returns (y, [N, parts] partial maxima of
+    |y|) -- the x_amax of the next fp16x2 GEMM."""
     require_device(x, "conv1x1_f16x2_ln")
     n, k, ldt = x.shape
     y = out if out is not None else torch.empty(n, c, ldt, dtype=torch.float32, device=x.device)
@@ -294,8 +296,9 @@ def conv1x1_f16x2_ln(x: torch.Tensor, t: int, wt_planes: torch.Tensor, w_exp: in
         raise ValueError(f"conv1x1_f16x2_ln: the residual must be a contiguous {(n, c, ldt)} tensor")
     amax = torch.zeros(n, lib().ps_conv1x1_stats_parts(256, t), dtype=torch.float32, device=x.device) if want_amax else None
     rng = F16x2Range(int(w_exp), float(x_bound), ptr(x_amax), x_amax.shape[1] if x_amax is not None else 0, ptr(amax))
-    check(lib().ps_conv1x1_f16x2_ln_f32(ptr(x), ptr(wt_planes), C.byref(rng), ptr(y), n, k, c, t, ldt, ptr(bias), ptr(gamma),
-                                        ptr(beta), float(eps), ptr(res), stream_ptr(x.device)), "ps_conv1x1_f16x2_ln_f32")
+    check(lib().ps_conv1x1_f16x2_ln_f32(ptr(x), ptr(wt_planes), C.byref(rng), ptr(y), n, k, c, t, ldt,
+                                        C.byref(pro) if pro is not None else None, ptr(bias), ptr(gamma), ptr(beta), float(eps),
+                                        ptr(res), int(res_inside), stream_ptr(x.device)), "ps_conv1x1_f16x2_ln_f32")
     return (y, amax) if want_amax else y
 
 

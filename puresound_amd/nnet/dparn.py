@@ -35,17 +35,30 @@ class DPARNblock2D(PlanCache, nn.Module):
                     inter=(lstm_plan(self.inter_rnn.rnn, device, self.gemm_precision), linear_plan(self.inter_rnn.proj, device),
                            layernorm_plan(self.inter_norm, device)))
 
-    def forward_padded(self, x: torch.Tensor, t: int) -> torch.Tensor:
-        """[N, CH, F, ld] -> [N, CH, F, ld]."""
+    def forward_padded(self, x: torch.Tensor, t: int, amax=None) -> torch.Tensor:
+        """[N, CH, F, ld] -> [N, CH, F, ld].  amax: lstm_path's one-element list (fp16x2 arithmetic: the maxima of |x| travel
+        from block to block)."""
         p = self._plan_get(x.device, self._build)
         n, ch, f, ld = x.shape
         y = x.view(n, ch, f * ld)
         frames = (f - 1) * ld + t
-        a = self.intra_atten1.forward_padded(y, frames, t, 1, f, ld)
-        a = self.intra_atten2.forward_padded(a, frames, t, 1, f, ld)
+        amax = [None] if amax is None else amax
+        a, bound = self.intra_atten1.forward_padded(y, frames, t, 1, f, ld, x_amax=amax[0], want_bound=True)
+        a, bound = self.intra_atten2.forward_padded(a, frames, t, 1, f, ld, want_bound=True, x_bound=bound or 0.0)
         fn = p["fc_norm"]
-        y, _ = hip.proj_layernorm(a, frames, p["fc"]["wt"], p["fc"]["bias"], ch, fn["gamma"], fn["beta"], fn["eps"], y)
-        y, _ = lstm_path(y, frames, *p["inter"], q=f, q_stride=ld, steps=t, step_stride=1)
+        amax[0] = None
+        if (self.gemm_precision == "fp16x2" and bound is not None and ch == 128 and hip.conv1x1_f16x2_ln_ok(n, ch, 128, frames)):
+            # Linear + LayerNorm + skip as one launch (the LayerNorm epilogue of the fp16x2 GEMM); its maxima feed the recurrence
+            if "f16x2_ln" not in p["fc"]:
+                w256 = torch.zeros(256, ch, dtype=torch.float32, device=x.device)
+                w256[:ch] = p["fc"]["w_rows"]
+                p["fc"]["f16x2_ln"] = hip.pack_wt_f16x2(w256)
+            wf, we = p["fc"]["f16x2_ln"]
+            y, amax[0] = hip.conv1x1_f16x2_ln(a, frames, wf, we, ch, p["fc"]["bias"], fn["gamma"], fn["beta"], fn["eps"], y,
+                                              x_bound=bound, want_amax=True)
+        else:
+            y, _ = hip.proj_layernorm(a, frames, p["fc"]["wt"], p["fc"]["bias"], ch, fn["gamma"], fn["beta"], fn["eps"], y)
+        y, _ = lstm_path(y, frames, *p["inter"], q=f, q_stride=ld, steps=t, step_stride=1, amax=amax)
         return y.view(n, ch, f, ld)
 
     def forward(self, x: torch.Tensor, intra_skip: bool = True, inter_skip: bool = True) -> torch.Tensor:
@@ -81,8 +94,9 @@ class DPARN(Unet):
             raise NotImplementedError("DPARN on HIP: spectral_compress (it returns a complex tensor in the reference)")
         p = self._plan_get(x4.device, self._build_unet)
         skip = self._down(x4, t, p)
-        y = self.dprnn_block1.forward_padded(skip[-1], t)
-        y = self.dprnn_block2.forward_padded(y, t)
+        amax = [None]
+        y = self.dprnn_block1.forward_padded(skip[-1], t, amax)
+        y = self.dprnn_block2.forward_padded(y, t, amax)
         return self._up(y, skip, t, p, self.transpose_delay)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

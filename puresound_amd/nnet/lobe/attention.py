@@ -93,11 +93,60 @@ class MhaSelfAttenLayer(PlanCache, nn.Module):
             p["ff2"] = linear_plan(self.feedforward[3], device)
         if self.position_encoding and not self.improved:
             p["pe"] = _f32(self.pos.pe[:, 0, :], device)            # [max_len, E]
+        if self.gemm_precision == "fp16x2" and not self.improved and self.feats_dim == 128:
+            # the layer's five GEMMs in the fp16x2 arithmetic (two fp16 terms per operand, fp32 accumulation), the two
+            # LayerNorms as epilogues of theirs.  Input ranges without extra passes: a LayerNorm's output is bounded by
+            # sqrt(C) max|gamma| + max|beta| (host constants, read once here); q / k / v and the hidden layer leave their
+            # maxima behind (y_amax); the attention output is a convex combination of v rows.
+            def pad256(w):
+                w256 = torch.zeros(256, w.shape[1], dtype=torch.float32, device=device)
+                w256[:w.shape[0]] = w
+                return hip.pack_wt_f16x2(w256)
+
+            def ln_bound(ln):
+                return float(math.sqrt(self.feats_dim) * ln["gamma"].abs().max() + ln["beta"].abs().max()) * 1.0001
+
+            w_ff1 = _f32(self.feedforward[0].weight, device)
+            p["f16x2"] = dict(w_in=hip.pack_wt_f16x2(_f32(at.in_proj_weight, device)),
+                              out=pad256(_f32(at.out_proj.weight, device)),
+                              ff1=hip.pack_wt_f16x2(w_ff1), ff2=pad256(_f32(self.feedforward[3].weight, device)),
+                              zero_slope=torch.zeros(1, dtype=torch.float32, device=device),
+                              bound1=ln_bound(p["norm1"]), bound2=ln_bound(p["norm2"]))
         return p
 
+    def _forward_f16x2(self, x, src, frames, q, q_stride, length, pos_stride, causal, p, f, x_amax, x_bound):
+        """The layer in the fp16x2 arithmetic: in_proj GEMM -> attention -> (out_proj + residual + norm1) as one launch ->
+        Linear -> (ReLU + Linear + residual + norm2) as one launch."""
+        n, e, ld = x.shape
+        hid = p["ff1"]["M"]
+        if self.position_encoding:   # |pe| <= 1 on top of whatever range the caller knew
+            x_bound = x_bound + 1.0 if x_bound > 0 else 0.0
+            x_amax = x_amax + 1.0 if x_amax is not None else None
+        if x_bound <= 0 and x_amax is None:
+            x_amax = hip.absmax(x, frames)
+        qkv, _, qkv_amax = hip.conv1x1_f16x2(x, frames, f["w_in"][0], f["w_in"][1], 3 * e, x_bound=x_bound,
+                                             x_amax=None if x_bound > 0 else x_amax, want_amax=True,
+                                             out=torch.empty(n, 3 * e, ld, dtype=torch.float32, device=x.device))
+        att = hip.self_attention(qkv, e, self.nhead, q, q_stride, length, pos_stride, causal)
+        n1, n2 = p["norm1"], p["norm2"]
+        y = hip.conv1x1_f16x2_ln(att, frames, f["out"][0], f["out"][1], e, None, n1["gamma"], n1["beta"], n1["eps"], src,
+                                 x_amax=qkv_amax, res_inside=True)
+        h, _, h_amax = hip.conv1x1_f16x2(y, frames, f["ff1"][0], f["ff1"][1], hid, None, p["ff1"]["bias"], x_bound=f["bound1"],
+                                         want_amax=True, out=torch.empty(n, hid, ld, dtype=torch.float32, device=x.device))
+        relu = hip.make_prologue(0, True, None, 0.0, 0.0, None, None, f["zero_slope"])
+        return hip.conv1x1_f16x2_ln(h, frames, f["ff2"][0], f["ff2"][1], e, p["ff2"]["bias"], n2["gamma"], n2["beta"], n2["eps"],
+                                    y, x_amax=h_amax, pro=relu, res_inside=True)
+
     def forward_padded(self, x: torch.Tensor, frames: int, q: int, q_stride: int, length: int, pos_stride: int,
-                       causal: bool = False) -> torch.Tensor:
-        """x padded [N, E, ld]: sequences (n, q) with `length` positions at q*q_stride + p*pos_stride."""
+                       causal: bool = False, x_amax: Optional[torch.Tensor] = None, want_bound: bool = False,
+                       x_bound: float = 0.0):
+        """x padded [N, E, ld]: sequences (n, q) with `length` positions at q*q_stride + p*pos_stride.  x_amax: partial maxima
+        of |x| / x_bound: a host bound on |x|, when the caller has them (fp16x2 arithmetic).  want_bound: return (y, bound) with bound >= max |y| when the
+        layer knows one (its last operation is a LayerNorm), else None."""
+        y, bound = self._forward_padded(x, frames, q, q_stride, length, pos_stride, causal, x_amax, x_bound)
+        return (y, bound) if want_bound else y
+
+    def _forward_padded(self, x, frames, q, q_stride, length, pos_stride, causal, x_amax, x_bound):
         p = self._plan_get(x.device, self._build)
         n, e, ld = x.shape
         new = lambda rows: torch.empty(n, rows, ld, dtype=torch.float32, device=x.device)  # noqa: E731
@@ -110,6 +159,10 @@ class MhaSelfAttenLayer(PlanCache, nn.Module):
             if length > p["pe"].shape[0]:
                 raise RuntimeError("sequence longer than the positional table")
             x = hip.add_position(x, p["pe"], q, q_stride, length, pos_stride)
+        f = p.get("f16x2")
+        if (f is not None and p["ff1"]["M"] % 32 == 0 and hip.conv1x1_f16x2_ln_ok(n, e, 128, frames)
+                and hip.conv1x1_f16x2_ln_ok(n, p["ff1"]["M"], 128, frames)):
+            return self._forward_f16x2(x, src, frames, q, q_stride, length, pos_stride, causal, p, f, x_amax, x_bound), f["bound2"]
         qkv, _ = hip.conv1x1(x, frames, p["w_in"], 3 * e, out=new(3 * e))
         att = hip.self_attention(qkv, e, self.nhead, q, q_stride, length, pos_stride, causal)
         n1 = p["norm1"]
@@ -124,7 +177,7 @@ class MhaSelfAttenLayer(PlanCache, nn.Module):
         n2 = p["norm2"]
         pro = hip.make_prologue(0, False, None, 0.0, 0.0, None, None, None, pre_relu=True)
         s, _ = hip.conv1x1(h, frames, p["ff2"]["wt"], e, pro, p["ff2"]["bias"], res=y, out=new(e))
-        return hip.chan_layernorm(s, frames, n2["gamma"], n2["beta"], n2["eps"])
+        return hip.chan_layernorm(s, frames, n2["gamma"], n2["beta"], n2["eps"]), None
 
     def forward(self, x: torch.Tensor, causal: bool = False, context_range: Optional[int] = None,
                 return_atten_weight: bool = False):

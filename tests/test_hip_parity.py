@@ -1289,10 +1289,23 @@ def test_fbank_encoder_matches_reference_golden(PA, dev, golden_dir, name):
     assert rel_max(y.cpu().numpy(), g["feats"]) < TOL
 
 
-def test_self_attention_kernel(H, dev):
+@pytest.mark.parametrize("e,heads,f,t,flags", [(16, 4, 9, 13, 0), (64, 4, 9, 13, 0), (64, 4, 9, 13, 1 << 23), (128, 8, 64, 37, 0),
+                                               (64, 2, 20, 9, 0), (64, 1, 30, 6, 0), (64, 1, 30, 6, 1 << 23)])
+def test_self_attention_kernel(H, dev, e, heads, f, t, flags):
     """ps_self_attention_f32 / ps_add_position_f32 against the oracle's multi-head attention, both sequence layouts
-    (positions contiguous in time; positions strided over frequency rows as in DPARN), with and without causal mask."""
-    n, e, heads, f, t = 2, 16, 4, 9, 13
+    (positions contiguous in time; positions strided over frequency rows as in DPARN), with and without causal mask.
+    Head dimensions 16 / 32 / 64 with at most 64 positions take the register-score kernel (debug bit 23: the general one);
+    (128, 8, 64, 37) is the DPARN bottleneck's shape with a ragged last workgroup."""
+    from puresound_amd import _abi
+    old_flags = _abi.lib().ps_debug_flags(flags)
+    try:
+        _self_attention_case(H, dev, e, heads, f, t)
+    finally:
+        _abi.lib().ps_debug_flags(old_flags)
+
+
+def _self_attention_case(H, dev, e, heads, f, t):
+    n = 2
     x = _rand((n, e, f, t), 141)
     w_in, w_out = _rand((3 * e, e), 142, -0.4, 0.4), _rand((e, e), 143, -0.4, 0.4)
     xp = H.pad_rows(x.reshape(n, e * f, t).to(dev)).view(n, e, f, -1)

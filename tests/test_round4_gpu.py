@@ -292,3 +292,22 @@ def test_gemm_with_layernorm_epilogue(H, dev, n, k, t, flags):
     ref0 = F.layer_norm(p0.transpose(1, 2), (c,), g.double(), be.double(), 1e-5).transpose(1, 2)
     assert rel_max(y_nores[..., :t].cpu().numpy(), ref0.numpy()) < 5e-6
     assert not H.conv1x1_f16x2_ln_ok(n, k, 64, t) and not H.conv1x1_f16x2_ln_ok(n, 100, c, t)
+
+
+def test_dparn_preset_in_the_fp16x2_arithmetic(PA, dev):
+    """ns_dparn_v0_causal with the masker in the fp16x2 arithmetic -- the attention layers' five GEMMs with the LayerNorms as
+    epilogues, ranges from LayerNorm bounds and the GEMMs' own maxima, the frame-major recurrence -- against the exact-fp32
+    forward of the same model: fp32 class (32 x 1 s: the launches need a full-size batch to qualify)."""
+    model = cases.build(PA.NS, "ns_dparn_short").eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    g = torch.Generator().manual_seed(78)
+    x = ((torch.rand(32, 16000, generator=g) * 2 - 1) * 0.5).to(dev)
+    model.masker.set_gemm_precision("fp32")
+    ref = model.inference(x)
+    model.masker.set_gemm_precision("fp16x2")
+    y = model.inference(x)
+    err = float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref))
+    print("ns_dparn fp16x2 vs fp32: l2-rel", err)
+    assert err < 2e-5, err
+    assert not torch.equal(y, ref)

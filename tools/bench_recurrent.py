@@ -109,7 +109,7 @@ def dpcrn(args):
     dev = "cuda:0"
     if os.environ.get("PS_FLAGS"):   # experiments: ps_debug_flags for the whole run
         _abi.lib().ps_debug_flags(int(os.environ["PS_FLAGS"], 0))
-    model = cases.build(PA.NS, "ns_dpcrn_short").eval()
+    model = cases.build(PA.NS, os.environ.get("PS_NS_CASE", "ns_dpcrn_short")).eval()
     model.load_state_dict(det_state_dict(model))
     model.to(dev)
     model.masker.set_gemm_precision(args.gemm)
