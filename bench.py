@@ -406,7 +406,8 @@ def main():
         torch.cuda.empty_cache()
         other = {}
         for name, fn in (("cfg3", lambda: BC.cfg3(dev, steps=5)), ("cfg4", lambda: BC.cfg4(dev, steps=10)),
-                         ("cfg5", lambda: BC.cfg5(dev, chunks=500)), ("ns_dpcrn", lambda: BC.ns_dpcrn(dev))):
+                         ("cfg5", lambda: BC.cfg5(dev, chunks=500)), ("ns_dpcrn", lambda: BC.ns_dpcrn(dev)),
+                         ("ns_dparn", lambda: BC.ns_dparn(dev))):
             try:
                 other[name] = fn()
             except Exception as e:  # a failure here must not take the headline line with it

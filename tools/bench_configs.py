@@ -109,24 +109,31 @@ def cfg4(dev, steps=10, warmup=3, batch=32, gemm="fp32", graph=True):
     return out
 
 
-def ns_dpcrn(dev, steps=3, warmup=2, batch=32, gemm="fp16x2"):
+def ns_dparn(dev, steps=3, warmup=2, batch=32, gemm="fp16x2"):
+    """egs/ns/model.py:128-171 (ns_dparn_v0_causal: the DPCRN with self-attention along frequency, nhead = 8)."""
+    return ns_dpcrn(dev, steps, warmup, batch, gemm, case="ns_dparn_short", name="ns_dparn_v0_causal")
+
+
+def ns_dpcrn(dev, steps=3, warmup=2, batch=32, gemm="fp16x2", case="ns_dpcrn_short", name="ns_dpcrn_v0_causal"):
     """The real egs/ns model (ns_dpcrn_v0_causal, egs/ns/model.py:40-82: conv-STFT 512/128 + DPCRN(1,32,32,32,64,128; H=128)
     + complex mask + iSTFT), batch x 4 s; `gemm` = arithmetic of the LSTM input projections and linear layers."""
-    model = _build("ns_dpcrn_short", dev)
+    model = _build(case, dev)
     noisy = _waves(batch, 1234, dev)
-    out = {"workload": f"ns_dpcrn_v0_causal, {batch} x 4 s, 1 GPU, fp32 rows", "steps": steps}
+    out = {"workload": f"{name}, {batch} x 4 s, 1 GPU, fp32 rows", "steps": steps}
     model.masker.set_gemm_precision("fp32")
     ref = model.inference(noisy)
     # algorithmic bytes (fp32 rows, every layer reading its input and writing its output once; T = 501 frames): the ten
     # convolutions move 87,040 (channel x frequency) rows per frame, the four recurrent passes read and write the 128 x 64
     # bottleneck map once each; pre-activations, h' and the STFT are fusible and not counted
     alg = (87040 + 4 * 2 * 8192) * 501 * 4.0 * batch
-    out["algorithmic_bytes"] = alg
+    out["algorithmic_bytes"] = alg if case == "ns_dpcrn_short" else None
     for prec in ("fp32", gemm):
         model.masker.set_gemm_precision(prec)
         ms, y = _timed(lambda: model.inference(noisy), steps, warmup)
         out[prec] = {"ms": ms, "samples_s": batch * L / ms * 1e3, "roofline_frac": alg / (ms * 1e-3) / 8e12,
                      "l2_rel_vs_fp32": float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref))}
+        if case != "ns_dpcrn_short":   # (the byte count above is DPCRN's; the attention variant's q / k / v rows are fusible too)
+            out[prec]["roofline_frac"] = None
     out["roofline_note"] = ("bounded by the fp32 matrix pipe in the convolutions (651 GFLOP at 157 TFLOP/s = 4.1 ms) and by the "
                             "6.4 GB round trip of the LSTM gate pre-activations, not by the algorithmic bytes")
     return out
