@@ -18,13 +18,14 @@ struct Unfold2dArgs {
   const float* x2;
   float* y;
   int C1, C2, Fin, T, Tin, ld, kf, kt, sf, df, dt, pf, pt, Fout, transposed;
+  int n0;  // first utterance of this launch (the grid's z axis holds at most 65535 (utterance, tap row) pairs)
 };
 
 __global__ __launch_bounds__(256) void unfold2d_kernel(Unfold2dArgs a) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int fo = blockIdx.y;
   const int K = (a.C1 + a.C2) * a.kf * a.kt;
-  const int n = blockIdx.z / K, row = blockIdx.z % K;
+  const int n = a.n0 + blockIdx.z / K, row = blockIdx.z % K;
   if (t >= a.ld) return;
   const int jt = row % a.kt, jf = (row / a.kt) % a.kf, ci = row / (a.kt * a.kf);
   float v = 0.f;
@@ -181,15 +182,20 @@ extern "C" int ps_unfold2d_f32(const float* x1, int C1, const float* x2, int C2,
     set_error("ps_unfold2d_f32: bad argument (N=%d C=%d+%d F=%d->%d T=%d k=%dx%d)", N, C1, C2, Fin, Fout, T, kf, kt);
     return PS_E_INVALID;
   }
-  const long long z = (long long)N * (C1 + C2) * kf * kt;
-  if (z > 65535) {
-    set_error("ps_unfold2d_f32: N * Cin * kf * kt = %lld exceeds the grid limit 65535", z);
+  const long long K = (long long)(C1 + C2) * kf * kt;
+  if (K > 65535) {
+    set_error("ps_unfold2d_f32: Cin * kf * kt = %lld exceeds the grid limit 65535", K);
     return PS_E_UNSUPPORTED;
   }
-  Unfold2dArgs a{x1, x2, y, C1, C2, Fin, T, T_in, ld, kf, kt, stride_f, dil_f, dil_t, pad_f, pad_t, Fout, transposed};
+  Unfold2dArgs a{x1, x2, y, C1, C2, Fin, T, T_in, ld, kf, kt, stride_f, dil_f, dil_t, pad_f, pad_t, Fout, transposed, 0};
   {
     LaunchTimer timer("unfold2d", (hipStream_t)stream);
-    hipLaunchKernelGGL(unfold2d_kernel, dim3((ld + 255) / 256, Fout, (unsigned)z), dim3(256), 0, (hipStream_t)stream, a);
+    const int per = (int)(65535 / K);  // utterances per launch (tse_unet_tcn at 32 utterances: 81,920 tap rows)
+    for (int n0 = 0; n0 < N; n0 += per) {
+      a.n0 = n0;
+      const int nb = N - n0 < per ? N - n0 : per;
+      hipLaunchKernelGGL(unfold2d_kernel, dim3((ld + 255) / 256, Fout, (unsigned)(nb * K)), dim3(256), 0, (hipStream_t)stream, a);
+    }
   }
   return unet_status("ps_unfold2d_f32");
 }

@@ -311,3 +311,18 @@ def test_dparn_preset_in_the_fp16x2_arithmetic(PA, dev):
     print("ns_dparn fp16x2 vs fp32: l2-rel", err)
     assert err < 2e-5, err
     assert not torch.equal(y, ref)
+
+
+def test_unfold2d_batches_beyond_the_grid_limit(H, dev):
+    """ps_unfold2d_f32 at (utterances x tap rows) > 65535 -- tse_unet_tcn_v0 at the benchmark's batch of 32 has 81,920 and was
+    refused before round 4: the launch is split at utterance boundaries, every utterance equal to its own single launch."""
+    n, c1, c2, f, t = 60, 100, 28, 3, 5
+    kf, kt, sf = 5, 2, 1
+    x1, x2 = _rand4((n, c1, f, t), 601), _rand4((n, c2, f, t), 602)
+    pad = lambda v: H.pad_rows(v.reshape(v.shape[0], -1, t).to(dev)).view(v.shape[0], v.shape[1], f, -1)  # noqa: E731
+    assert n * (c1 + c2) * kf * kt > 65535
+    big = H.unfold2d(pad(x1), pad(x2), t, f, kf, kt, sf, 1, 1, kf // 2, kt - 1, False)
+    for i in (0, 50, 51, 52, 59):
+        one = H.unfold2d(pad(x1[i:i + 1]), pad(x2[i:i + 1]), t, f, kf, kt, sf, 1, 1, kf // 2, kt - 1, False)
+        assert torch.equal(big[i:i + 1], one), i
+    assert float(big.abs().max()) > 0
