@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 13
+#define PS_ABI_VERSION 14
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -275,6 +275,14 @@ int ps_unfold2d_f32(const float* x1, int C1, const float* x2, int C2, float* y, 
 int ps_conv2d_f32(const float* x1, int C1, const float* x2, int C2, const float* wt, const float* bias, float* y, int N,
                   int M, int Fin, int T_in, int T, int ld, int kf, int kt, int stride_f, int dil_f, int dil_t, int pad_f,
                   int pad_t, int Fout, int transposed, int act, const float* slope, void* stream);
+/* The same convolution without activation, leaving partial (sum, sum of squares) of its outputs over the valid frames behind:
+ * ostats [N][ps_conv2d_stats_parts(M, Fout, ld)][2] doubles -- the statistics of the global LayerNorm (gLN) that follows the
+ * convolution in Unet / UnetTcn(norm_type="gLN") (unet.py:100-165, lobe/norm.py), consumed by ps_norm_activation_f32
+ * through a PS_NORM_GLOBAL prologue.  One partial per workgroup in its own slot (deterministic). */
+int ps_conv2d_stats_parts(int M, int Fout, int ld);
+int ps_conv2d_stats_f32(const float* x1, int C1, const float* x2, int C2, const float* wt, const float* bias, float* y, int N,
+                        int M, int Fin, int T_in, int T, int ld, int kf, int kt, int stride_f, int dil_f, int dil_t, int pad_f,
+                        int pad_t, int Fout, int transposed, double* ostats, void* stream);
 int ps_activation_f32(float* x, int kind, const float* slope, int64_t rows, int T, int ld, void* stream);
 /* gLN over [CH, F, T] (GlobLN on a 4-D map, lobe/norm.py:20-34) followed by an activation, in place on [N][rows_per_utt]
  * rows of ld frames (row r belongs to channel r / rows_per_channel).  pro = PS_NORM_GLOBAL with the producing GEMM's

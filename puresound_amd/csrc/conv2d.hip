@@ -25,6 +25,7 @@ struct Conv2dArgs {
   const float* slope;
   float* y;
   int C1, C2, Fin, T, Tin, ld, kf, kt, sf, df, dt, pf, pt, Fout, M, K, Kp, transposed, act;
+  double* stats;  // conv2d_lds_kernel only: [N][parts][2] partial (sum, sum of squares) of the outputs over the valid frames
 };
 
 constexpr int C2D_MAXK = 4096;  // table entries (Cin*kf*kt rounded up to 16)
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(Conv2dArgs a) {
   }
 
   const float s = a.slope ? a.slope[0] : 0.f;
+  float fsum = 0.f, fsq = 0.f;
   if (tcol < a.ld) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -308,10 +310,25 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(Conv2dArgs a) {
         const int m = m0 + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (m < a.M) {
           float v = acc[mb][r] + (a.bias ? a.bias[m] : 0.f);
+          if (tcol < a.T) fsum += v, fsq += v * v;  // (statistics of the pre-activation output: the gLN that follows)
           v = act_apply(v, a.act, s);
           a.y[(((size_t)n * a.M + m) * a.Fout + fo) * a.ld + tcol] = tcol < a.T ? v : 0.f;
         }
       }
+  }
+  if (a.stats) {  // one partial per workgroup, in the workgroup's own slot: deterministic
+    __shared__ double red[2][4];
+    const double ws = wave_sum((double)fsum), wq = wave_sum((double)fsq);
+    __syncthreads();
+    if (lane == 0) red[0][w] = ws, red[1][w] = wq;
+    __syncthreads();
+    if (tid == 0) {
+      const int parts = gridDim.x * gridDim.y * mtiles;
+      const int part = ((bz % mtiles) * gridDim.y + fo) * gridDim.x + bx;
+      double* dst = a.stats + ((size_t)n * parts + part) * 2;
+      dst[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      dst[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
   }
 }
 
@@ -426,10 +443,39 @@ __global__ __launch_bounds__(256) void conv2d_rows_kernel(Conv2dArgs a, int span
 
 using namespace ps;
 
+extern "C" int ps_conv2d_stats_parts(int M, int Fout, int ld) {
+  if (M <= 0 || Fout <= 0 || ld <= 0 || ld % 128) return 0;
+  const int mb = M <= 32 ? 1 : M <= 64 ? 2 : 4;
+  return (ld / 128) * Fout * ((M + 32 * mb - 1) / (32 * mb));
+}
+
+static int conv2d_launch(const float* x1, int C1, const float* x2, int C2, const float* wt, const float* bias, float* y, int N,
+                         int M, int Fin, int T_in, int T, int ld, int kf, int kt, int stride_f, int dil_f, int dil_t, int pad_f,
+                         int pad_t, int Fout, int transposed, int act, const float* slope, double* ostats, void* stream);
+
 extern "C" int ps_conv2d_f32(const float* x1, int C1, const float* x2, int C2, const float* wt, const float* bias,
                              float* y, int N, int M, int Fin, int T_in, int T, int ld, int kf, int kt, int stride_f,
                              int dil_f, int dil_t, int pad_f, int pad_t, int Fout, int transposed, int act,
                              const float* slope, void* stream) {
+  return conv2d_launch(x1, C1, x2, C2, wt, bias, y, N, M, Fin, T_in, T, ld, kf, kt, stride_f, dil_f, dil_t, pad_f, pad_t, Fout,
+                       transposed, act, slope, nullptr, stream);
+}
+
+extern "C" int ps_conv2d_stats_f32(const float* x1, int C1, const float* x2, int C2, const float* wt, const float* bias,
+                                   float* y, int N, int M, int Fin, int T_in, int T, int ld, int kf, int kt, int stride_f,
+                                   int dil_f, int dil_t, int pad_f, int pad_t, int Fout, int transposed, double* ostats,
+                                   void* stream) {
+  if (!ostats) {
+    set_error("ps_conv2d_stats_f32: ostats is NULL");
+    return PS_E_INVALID;
+  }
+  return conv2d_launch(x1, C1, x2, C2, wt, bias, y, N, M, Fin, T_in, T, ld, kf, kt, stride_f, dil_f, dil_t, pad_f, pad_t, Fout,
+                       transposed, 0, nullptr, ostats, stream);
+}
+
+static int conv2d_launch(const float* x1, int C1, const float* x2, int C2, const float* wt, const float* bias, float* y, int N,
+                         int M, int Fin, int T_in, int T, int ld, int kf, int kt, int stride_f, int dil_f, int dil_t, int pad_f,
+                         int pad_t, int Fout, int transposed, int act, const float* slope, double* ostats, void* stream) {
   if (!x1 || !wt || !y || N <= 0 || M <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && !x2) || Fin <= 0 || Fout <= 0 || T <= 0 ||
       T_in <= 0 || ld < T || ld < T_in || ld % 128 || kf <= 0 || kt <= 0 || stride_f <= 0 || dil_f <= 0 || dil_t <= 0 ||
       Fout > 65535 || act < 0 || act > 5 || (act == 2 && !slope)) {
@@ -454,17 +500,17 @@ extern "C" int ps_conv2d_f32(const float* x1, int C1, const float* x2, int C2, c
     return PS_E_UNSUPPORTED;
   }
   Conv2dArgs a{x1, x2, wt, bias, slope, y, C1, C2, Fin, T, T_in, ld, kf, kt, stride_f, dil_f, dil_t, pad_f, pad_t,
-               Fout, M, (int)K, Kp, transposed, act};
+               Fout, M, (int)K, Kp, transposed, act, ostats};
   dim3 grid(ld / 128, Fout, N * mtiles);
   {
     LaunchTimer timer("conv2d", (hipStream_t)stream);
-    const bool old_kernel = (g_debug_flags & (1 << 23)) != 0;  // (bit 23: the round-3 kernel; tests run both)
+    const bool old_kernel = (g_debug_flags & (1 << 23)) != 0 && !ostats;  // (bit 23: the round-3 kernel; tests run both)
     // <= 4 output channels: the row-block kernel when its table fits (span = input rows feeding 8 output rows)
     const int span = transposed ? ((C2D_R - 1) + (kf - 1) * dil_f) / stride_f + 2 : (C2D_R - 1) * stride_f + (kf - 1) * dil_f + 1;
     const long long nent = (long long)(C1 + C2) * span * kt;
     const int mm = M <= 2 ? 2 : 4;
     const size_t rows_lds = (size_t)((nent + 3) / 4 * 4) * 2 * sizeof(int) + (size_t)nent * C2D_R * mm * sizeof(float);
-    if (M <= 4 && !old_kernel && N <= 65535 && rows_lds <= 150 * 1024 && (Fout + C2D_R - 1) / C2D_R <= 65535) {
+    if (M <= 4 && !old_kernel && !ostats && N <= 65535 && rows_lds <= 150 * 1024 && (Fout + C2D_R - 1) / C2D_R <= 65535) {
       dim3 rgrid((ld + 511) / 512, (Fout + C2D_R - 1) / C2D_R, N);
       static bool lds_raised = false;  // (dynamic LDS above 64 KiB has to be allowed per kernel, once)
       if (!lds_raised) {

@@ -650,6 +650,24 @@ def conv2d(x1: torch.Tensor, x2: Optional[torch.Tensor], wt: torch.Tensor, bias:
     return y
 
 
+def conv2d_stats(x1: torch.Tensor, x2: Optional[torch.Tensor], wt: torch.Tensor, bias: Optional[torch.Tensor], m: int, t: int,
+                 f_out: int, kf: int, kt: int, stride_f: int, dil_f: int, dil_t: int, pad_f: int, pad_t: int, transposed: bool,
+                 t_in: Optional[int] = None):
+    """conv2d without activation + the partial (sum, sum of squares) of its outputs over the t valid frames ->
+    (y [N,M,f_out,ld], stats [N, parts, 2] fp64): the convolution in front of a gLN (ps_conv2d_stats_f32)."""
+    require_device(x1, "conv2d_stats")
+    n, c1, f_in, ld = x1.shape
+    c2 = 0 if x2 is None else x2.shape[1]
+    if x2 is not None and (x2.shape[0], x2.shape[2], x2.shape[3]) != (n, f_in, ld):
+        raise RuntimeError("conv2d_stats: the two sources must agree in N, F and ld")
+    y = torch.empty(n, m, f_out, ld, dtype=torch.float32, device=x1.device)
+    stats = torch.empty(n, lib().ps_conv2d_stats_parts(m, f_out, ld), 2, dtype=torch.float64, device=x1.device)
+    check(lib().ps_conv2d_stats_f32(ptr(x1), c1, ptr(x2), c2, ptr(wt), ptr(bias), ptr(y), n, m, f_in,
+                                    t if t_in is None else t_in, t, ld, kf, kt, stride_f, dil_f, dil_t, pad_f, pad_t, f_out,
+                                    int(transposed), ptr(stats), stream_ptr(x1.device)), "ps_conv2d_stats_f32")
+    return y, stats
+
+
 def activation_(x: torch.Tensor, kind: str, slope: Optional[torch.Tensor], t: int) -> torch.Tensor:
     """in place on [..., ld] rows."""
     require_device(x, "activation_")

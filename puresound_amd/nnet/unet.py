@@ -185,6 +185,12 @@ class Unet(PlanCache, nn.Module):
         pad = float(f_out * (ld - t))
         return hip.norm_activation_(y, t, pro, lay["bias_sum"] * pad, lay["bias_sq"] * pad, lay["act"], lay["slope"])
 
+    def _gln_act(self, y: torch.Tensor, stats: torch.Tensor, lay: dict, f_out: int, t: int) -> torch.Tensor:
+        """gLN + activation behind a convolution whose statistics cover the t valid frames only (no pad-column correction)."""
+        gln = lay["gln"]
+        pro = hip.make_prologue(PS_NORM_GLOBAL, False, stats, float(lay["M"] * f_out * t), gln[2], gln[0], gln[1], None)
+        return hip.norm_activation_(y, t, pro, 0.0, 0.0, lay["act"], lay["slope"])
+
     def _down(self, x4: torch.Tensor, t: int, p: dict) -> List[torch.Tensor]:
         """[N, CH0, F, ld] -> skip list (input first), unet.py:235-246."""
         skip = [x4]
@@ -199,6 +205,12 @@ class Unet(PlanCache, nn.Module):
             if "gln" not in lay and IMPLICIT_CONV and x.shape[1] * kf * kt <= 4096:
                 x = hip.conv2d(x, None, lay["wt"], lay["bias"], lay["M"], t, f_out, kf, kt, sf, df, dt, pf,
                                kt - self.delay[i] - 1, False, lay["act"], lay["slope"])
+            elif IMPLICIT_CONV and x.shape[1] * kf * kt <= 4096:
+                # gLN behind the convolution: the implicit GEMM leaves the statistics of its output behind (round 3 built the
+                # tap matrix for these layers: 43 + 47 ms per forward of tse_unet_tcn_v0 at 32 x 4 s)
+                y, stats = hip.conv2d_stats(x, None, lay["wt"], lay["bias"], lay["M"], t, f_out, kf, kt, sf, df, dt, pf,
+                                            kt - self.delay[i] - 1, False)
+                x = self._gln_act(y, stats, lay, f_out, t)
             else:
                 taps = hip.unfold2d(x, None, t, f_out, kf, kt, sf, df, dt, pf, kt - self.delay[i] - 1, False)
                 x = self._gemm_act(taps, lay, f_out, x.shape[3], t)
@@ -232,8 +244,13 @@ class Unet(PlanCache, nn.Module):
                 # T + ext frames, normalise over them, then drop the trimmed ones
                 if t + ext > ld:
                     raise NotImplementedError("U-Net on HIP: gLN decoder needs rows with room for the untrimmed frames")
-                taps = hip.unfold2d(x, x2, t + ext, f_out, kf, self.t_kernel, sf, df, dt, pf, 0, True, t_in=t)
-                x = self._gemm_act(taps, lay, f_out, ld, t + ext)
+                if IMPLICIT_CONV and (x.shape[1] + (0 if x2 is None else x2.shape[1])) * kf * self.t_kernel <= 4096:
+                    y, stats = hip.conv2d_stats(x, x2, lay["wt"], lay["bias"], lay["M"], t + ext, f_out, kf, self.t_kernel, sf,
+                                                df, dt, pf, 0, True, t_in=t)
+                    x = self._gln_act(y, stats, lay, f_out, t + ext)
+                else:
+                    taps = hip.unfold2d(x, x2, t + ext, f_out, kf, self.t_kernel, sf, df, dt, pf, 0, True, t_in=t)
+                    x = self._gemm_act(taps, lay, f_out, ld, t + ext)
                 if transpose_delay:   # keep frames [ext, ext + T): a 1x1 "convolution" with a negative time pad
                     x = hip.unfold2d(x, None, t, f_out, 1, 1, 1, 1, 1, 0, -ext, False, t_in=t + ext).view(
                         n, lay["M"], f_out, ld)
