@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 14
+#define PS_ABI_VERSION 15
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -356,6 +356,15 @@ int ps_lstm_f16x2_f32(const ps_lstm_args* args, void* stream);
  * steps % 4 != 0, D = 1 and room for the padded group inside the row (those frames are written as zeros).
  * ps_lstm_fmajor_ok(args, ldm) = 1 when a launch qualifies, else PS_E_UNSUPPORTED. */
 int ps_lstm_fmajor_ok(const ps_lstm_args* args, int ldm);
+/* The same for H = 256 (SkiM's segment LSTMs, /root/reference/puresound/nnet/skim.py:45-114) and H = 192 (the speaker LSTM of
+ * tse_skim_v1): W_hh as two fp16 terms is 1 MiB per direction and fits no CU, so it is streamed from L2 every step in
+ * MFMA-fragment order.  whh_image: the host-packed image [D][H/32][H/32][2][4][2][64][8] halves (wave, k-step, row block, gate,
+ * plane, lane, k): element (w, ks, rb, g, pl, lane, e) =
+ * plane pl of 2^(13 - e_d) * W_hh[g*H + 32 w + 16 rb + lane % 16][32 ks + 8 (lane / 16) + e], e_d from frexp(max |W_hh| of
+ * direction d); acc_scale [D] (host memory) = 2^(13 - e_d) * 1024.  args->whh_t is not read.  Initial / final states and
+ * state_shift as ps_lstm_f32.  hout [N][D*H][ldt]. */
+int ps_lstm_fmajor_h256_ok(const ps_lstm_args* args, int ldm);
+int ps_lstm_fmajor_h256_f16x2_f32(const ps_lstm_args* args, int ldm, const void* whh_image, const float* acc_scale, void* stream);
 int ps_lstm_fmajor_f16x2_f32(const ps_lstm_args* args, int ldm, void* stream);
 
 /* 50 % overlapped segmentation of the dual-path maskers (SplitMerge.split / merge, lobe/trivial.py:178-241; SkiM.split /

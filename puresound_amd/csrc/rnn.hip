@@ -1095,6 +1095,8 @@ __global__ __launch_bounds__(256) void lstm_m4_f16x2_kernel(LstmK k) {
 
 typedef unsigned u32x4l __attribute__((ext_vector_type(4)));
 #include "lstm_fm.inc"
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#include "lstm_fm256.inc"
 
 }  // namespace ps
 
@@ -1111,6 +1113,57 @@ static bool lstm_fmajor_fits(const ps_lstm_args& a, int ldm) {
   if (ldm < a.D * 512 || ldm % 4 || (long long)a.ldt * ldm * 4 >= (1LL << 31) || (long long)a.ldt * 128 * 4 >= (1LL << 31)) return false;
   if (((uintptr_t)a.gx & 15) || ((uintptr_t)a.hout & 3)) return false;
   return (long long)a.N * ((a.Q + 15) / 16) < (1LL << 30);
+}
+
+static bool lstm_h256_fits(const ps_lstm_args& a, int ldm) {
+  if (!a.gx || !a.hout || (a.H != 256 && a.H != 192) || a.D < 1 || a.D > 2 || a.N <= 0 || a.Q <= 0 || a.steps <= 0 || a.q_stride < 0 ||
+      a.step_stride < 0 || a.ldt <= 0 || (a.state_shift != 0 && a.state_shift != 1))
+    return false;
+  if ((long long)(a.Q - 1) * a.q_stride + (long long)(a.steps - 1) * a.step_stride >= a.ldt) return false;
+  if (ldm < a.D * 4 * a.H || ldm % 4 || ((uintptr_t)a.gx & 15) || ((uintptr_t)a.hout & 3)) return false;
+  if ((a.h0 || a.c0 || a.h_last || a.c_last) && a.ldq < a.Q) return false;
+  return (long long)a.N * a.Q < (1LL << 30);
+}
+
+extern "C" int ps_lstm_fmajor_h256_ok(const ps_lstm_args* args, int ldm) { return args && lstm_h256_fits(*args, ldm) ? 1 : 0; }
+
+extern "C" int ps_lstm_fmajor_h256_f16x2_f32(const ps_lstm_args* args, int ldm, const void* whh_image, const float* acc_scale,
+                                             void* stream) {
+  if (!args || !whh_image || !acc_scale || ((uintptr_t)whh_image & 15)) {
+    set_error("ps_lstm_fmajor_h256_f16x2_f32: null argument or unaligned weight image");
+    return PS_E_INVALID;
+  }
+  if (!lstm_h256_fits(*args, ldm)) {
+    set_error("ps_lstm_fmajor_h256_f16x2_f32: H = 256 or 192, D = 1 or 2, every frame inside the row, ldm >= D*4H (ps_lstm_fmajor_h256_ok)");
+    return PS_E_UNSUPPORTED;
+  }
+  const ps_lstm_args& a = *args;
+  LstmFm256 k{a, ldm, whh_image, {acc_scale[0], a.D > 1 ? acc_scale[1] : acc_scale[0]}};
+  if (!(k.up[0] > 0.f) || !(k.up[1] > 0.f)) {
+    set_error("ps_lstm_fmajor_h256_f16x2_f32: accumulator scales must be positive");
+    return PS_E_INVALID;
+  }
+  const long long seqs = (long long)a.N * a.Q;
+  dim3 grid((unsigned)((seqs + 15) / 16), 1, a.D);
+  const bool pairs = a.step_stride == 1 && a.q_stride % 2 == 0 && a.ldt % 2 == 0 && !((uintptr_t)a.hout & 7) &&
+                     (a.D == 1 || a.steps % 2 == 0) && !(g_debug_flags & (1 << 20));
+  {
+    LaunchTimer timer("lstm", (hipStream_t)stream);
+    if (a.H == 256 && pairs)
+      hipLaunchKernelGGL((lstm_fm_h256_kernel<256, 2>), grid, dim3(512), 0, (hipStream_t)stream, k);
+    else if (a.H == 256)
+      hipLaunchKernelGGL((lstm_fm_h256_kernel<256, 1>), grid, dim3(512), 0, (hipStream_t)stream, k);
+    else if (pairs)
+      hipLaunchKernelGGL((lstm_fm_h256_kernel<192, 2>), grid, dim3(384), 0, (hipStream_t)stream, k);
+    else
+      hipLaunchKernelGGL((lstm_fm_h256_kernel<192, 1>), grid, dim3(384), 0, (hipStream_t)stream, k);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("ps_lstm_fmajor_h256_f16x2_f32: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
 }
 
 extern "C" int ps_lstm_fmajor_ok(const ps_lstm_args* args, int ldm) { return args && lstm_fmajor_fits(*args, ldm) ? 1 : 0; }

@@ -466,6 +466,82 @@ def lstm_fmajor(gx_fm: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int
     return hout
 
 
+def pack_whh_h256(whh_t: torch.Tensor):
+    """weight_hh^T [D, H, 4H], H = 256 or 192 -> (fp16 image [D, H/32, H/32, 2, 4, 2, 64, 8], acc scales [D] as a Python list)
+    for lstm_fmajor_h256 (layout: include/puresound_hip.h).  Reads the maxima back to the host: plan-build time only."""
+    import math
+    d, hh, g = whh_t.shape
+    if hh not in (256, 192) or g != 4 * hh:
+        raise ValueError("pack_whh_h256: whh_t must be [D, H, 4H] with H = 256 or 192")
+    nw = hh // 32
+    imgs, scales = [], []
+    for i in range(d):
+        w = whh_t[i].detach().float().t().contiguous()            # [4H gate rows, H k]
+        wmax = float(w.abs().max())
+        if not (wmax < float("inf")):
+            raise ValueError("pack_whh_h256: the weight holds inf / NaN")
+        ex = max(math.frexp(wmax)[1], -27) if wmax > 0 else 0
+        sc = math.ldexp(1.0, 13 - ex)
+        rest = w * sc
+        planes = []
+        for _ in range(2):
+            hp = rest.to(torch.float16)
+            planes.append(hp)
+            rest = rest - hp.float()
+        pl = torch.stack(planes, 0)                                 # [pl, 4H, H]
+        pl = pl.reshape(2, 4, nw, 2, 16, nw, 4, 8)                  # pl, g, w, rb, row, ks, kg, e
+        pl = pl.permute(2, 5, 3, 1, 0, 6, 4, 7)                     # w, ks, rb, g, pl, kg, row, e
+        imgs.append(pl.reshape(nw, nw, 2, 4, 2, 64, 8))
+        scales.append(sc * 1024.0)
+    return torch.stack(imgs, 0).contiguous(), scales
+
+
+def lstm_fmajor_h256_ok(n: int, ldt: int, dirs: int, q: int, q_stride: int, steps: int, step_stride: int) -> bool:
+    return dirs in (1, 2) and (q - 1) * q_stride + (steps - 1) * step_stride < ldt
+
+
+def lstm_fmajor_h256(gx_fm: torch.Tensor, whh_image: torch.Tensor, acc_scale, dirs: int, q: int, q_stride: int, steps: int,
+                     step_stride: int, h0: Optional[torch.Tensor] = None, c0: Optional[torch.Tensor] = None,
+                     want_state: bool = False, state_shift: int = 0, state_out: Optional[tuple] = None,
+                     out: Optional[torch.Tensor] = None):
+    """ps_lstm_fmajor_h256_f16x2_f32: the H = 256 recurrence over FRAME-MAJOR pre-activations gx [N, ldt, D*1024] with W_hh
+    streamed from its packed image (pack_whh_h256) -> (hout [N, D*256, ldt], final (h, c) or None), states as lstm()."""
+    require_device(gx_fm, "lstm_fmajor_h256")
+    hidden = whh_image.shape[1] * 32
+    n, ldt, rows = gx_fm.shape
+    if (rows != dirs * 4 * hidden or hidden not in (256, 192) or whh_image.dtype != torch.float16
+            or tuple(whh_image.shape) != (dirs, hidden // 32, hidden // 32, 2, 4, 2, 64, 8)):
+        raise RuntimeError("lstm_fmajor_h256: gx must be [N, ldt, D*4H] and the image pack_whh_h256's")
+    ldm = gx_fm.stride(1)
+    if gx_fm.stride(2) != 1 or gx_fm.stride(0) != ldt * ldm:
+        raise RuntimeError("lstm_fmajor_h256: gx must be a [N, ldt, :D*1024] view of contiguous frame rows")
+    hout = out if out is not None else torch.empty(n, dirs * hidden, ldt, dtype=torch.float32, device=gx_fm.device)
+    a = LstmArgs()
+    a.gx, a.whh_t, a.hout = ptr(gx_fm), None, ptr(hout)
+    ldq = padded_frames(q)
+    for name, t in (("h0", h0), ("c0", c0)):
+        if t is not None and (tuple(t.shape[:2]) != (n, dirs * hidden) or t.shape[2] < q or not t.is_contiguous()):
+            raise RuntimeError(f"lstm_fmajor_h256: {name} must be a contiguous state tensor [N, D*H, ldq >= Q]")
+    if h0 is not None:
+        ldq = h0.shape[2]
+    elif c0 is not None:
+        ldq = c0.shape[2]
+    h_last = c_last = None
+    if state_out is not None:
+        h_last, c_last = state_out
+        ldq = h_last.shape[2]
+    elif want_state:
+        h_last = torch.zeros(n, dirs * hidden, ldq, dtype=torch.float32, device=gx_fm.device)
+        c_last = torch.zeros_like(h_last)
+    a.h0, a.c0, a.h_last, a.c_last = ptr(h0), ptr(c0), ptr(h_last), ptr(c_last)
+    a.N, a.H, a.D, a.Q, a.q_stride, a.steps, a.step_stride = n, hidden, dirs, q, q_stride, steps, step_stride
+    a.ldt, a.ldq, a.state_shift = ldt, ldq, state_shift
+    sc = (C.c_float * 2)(float(acc_scale[0]), float(acc_scale[-1]))
+    check(lib().ps_lstm_fmajor_h256_f16x2_f32(C.byref(a), ldm, ptr(whh_image), sc, stream_ptr(gx_fm.device)),
+          "ps_lstm_fmajor_h256_f16x2_f32")
+    return (hout, (h_last, c_last)) if h_last is not None else (hout, None)
+
+
 def chan_layernorm(x: torch.Tensor, t: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
                    res: Optional[torch.Tensor] = None, slope: Optional[torch.Tensor] = None, sigmoid: bool = False,
                    mul: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

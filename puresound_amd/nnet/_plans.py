@@ -194,6 +194,17 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
             hseq = hip.lstm_fmajor(gx_fm, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride,
                                    out=_h_rows(rnn, x, t, q, steps))
             return _proj_norm(x, hseq, t, rnn, proj, norm, amax), None
+        # H = 256 (SkiM's segment LSTMs): W_hh streamed from L2 in fragment order, states carried (ps_lstm_fmajor_h256_f16x2_f32)
+        if (FMAJOR_LSTM and rnn["H"] in (256, 192) and hip.lstm_fmajor_h256_ok(n, ldt, rnn["D"], q, q_stride, steps, step_stride)
+                and hip.conv1x1_f16x2_fmajor_ok(n, rnn["I"], rnn["rows"], t, ldt)):
+            if "whh_h256" not in rnn:
+                rnn["whh_h256"] = hip.pack_whh_h256(rnn["whh_t"])
+            gx_fm = hip.conv1x1_f16x2_fmajor(x, t, wf, we, rnn["rows"], rnn["bias"],
+                                             x_amax=x_amax if x_amax is not None else hip.absmax(x, t))
+            hseq, state = hip.lstm_fmajor_h256(gx_fm, rnn["whh_h256"][0], rnn["whh_h256"][1], rnn["D"], q, q_stride, steps,
+                                               step_stride, h0, c0, want_state, state_shift, state_out,
+                                               out=_h_rows(rnn, x, t, q, steps))
+            return _proj_norm(x, hseq, t, rnn, proj, norm, amax), state
         gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev)
         hip.conv1x1_f16x2(x, t, wf, we, rnn["rows"], None, rnn["bias"], out=gx,
                           x_amax=x_amax if x_amax is not None else hip.absmax(x, t))

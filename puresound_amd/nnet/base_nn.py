@@ -202,6 +202,26 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
 
     # -- the hot path -----------------------------------------------------------------------------
     @torch.no_grad()
+    def set_gemm_precision(self, name: str):
+        """One switch for the whole model (not in the reference: the HIP path's arithmetic): "fp16x2" | "fp32" | "bf16x3" |
+        "bf16" for every module of the masker and the speaker branch that has a choice (TCN stacks, recurrent maskers,
+        attention layers, SingleRNN)."""
+        from ._plans import PlanCache, _PLANES
+        if name not in _PLANES:
+            raise ValueError(f"gemm precision must be one of {sorted(_PLANES)}")
+        for root in (self.masker, self.speaker_net):
+            if root is None:
+                continue
+            for m in root.modules():
+                if isinstance(m, PlanCache):
+                    m.gemm_precision = name
+                    m._plan = None
+                elif hasattr(m, "gemm_precision"):
+                    m.gemm_precision = name
+            if hasattr(root, "set_gemm_precision") and not isinstance(root, PlanCache):
+                root.set_gemm_precision(name)
+        return self
+
     def inference(self, noisy: torch.Tensor, enroll: Optional[torch.Tensor] = None) -> torch.Tensor:
         """noisy [N,L] (+ enroll [N,L']) -> enhanced waveform [N,L_out] (base_nn.py:690-722)."""
         if noisy.device.type == "cpu":  # BASELINE configs[0] / the recipes' --backend cpu: stock ATen (nnet/cpu_path.py)

@@ -37,6 +37,21 @@ class SingleRNN(PlanCache, nn.Module):
         p = self._plan_get(x.device, self._build)
         rnn, proj = p["rnn"], p["proj"]
         n, _, ldt = x.shape
+        if (rnn["planes"] == 2 and rnn["I"] >= 64 and rnn["H"] in (256, 192)
+                and hip.lstm_fmajor_h256_ok(n, ldt, rnn["D"], 1, ldt, t, 1)
+                and hip.conv1x1_f16x2_fmajor_ok(n, rnn["I"], rnn["rows"], t, ldt)):
+            # fp16x2 arithmetic: frame-major pre-activations + the recurrence that streams W_hh (ps_lstm_fmajor_h256_f16x2_f32;
+            # the bidirectional 192-unit LSTM over the enrolment of tse_skim_v1: 4000 dependent steps), projection in fp16x2
+            if "wih_f16x2" not in rnn:
+                rnn["wih_f16x2"] = hip.pack_wt_f16x2(rnn["wih_rows"])
+                rnn["whh_h256"] = hip.pack_whh_h256(rnn["whh_t"])
+                proj["f16x2"] = hip.pack_wt_f16x2(proj["w_rows"])
+            gx_fm = hip.conv1x1_f16x2_fmajor(x, t, rnn["wih_f16x2"][0], rnn["wih_f16x2"][1], rnn["rows"], rnn["bias"],
+                                             x_amax=hip.absmax(x, t))
+            hseq, _ = hip.lstm_fmajor_h256(gx_fm, rnn["whh_h256"][0], rnn["whh_h256"][1], rnn["D"], 1, ldt, t, 1)
+            y, _, _ = hip.conv1x1_f16x2(hseq, t, proj["f16x2"][0], proj["f16x2"][1], proj["M"], None, proj["bias"], x_bound=1.0,
+                                        out=torch.empty(n, proj["M"], ldt, dtype=torch.float32, device=x.device))
+            return y
         gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=x.device)
         if rnn["planes"] and rnn["I"] >= 64:
             if rnn["planes"] not in rnn["wih_planes"]:

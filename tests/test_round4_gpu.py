@@ -326,3 +326,52 @@ def test_unfold2d_batches_beyond_the_grid_limit(H, dev):
         one = H.unfold2d(pad(x1[i:i + 1]), pad(x2[i:i + 1]), t, f, kf, kt, sf, 1, 1, kf // 2, kt - 1, False)
         assert torch.equal(big[i:i + 1], one), i
     assert float(big.abs().max()) > 0
+
+
+@pytest.mark.parametrize("bi,n,s,k,shift,wscale,hid", [
+    (True, 2, 9, 8, 0, 1.0, 256),      # 18 sequences (a ragged second block), even segment length: 8-byte h' stores, both directions
+    (False, 3, 5, 7, 1, 1.0, 256),     # odd segment length (4-byte stores), MemLSTM's shifted state hand-over, one direction
+    (True, 1, 20, 6, 0, 1.5, 256),     # saturating recurrent weights
+    (False, 2, 3, 30, 0, 1e-3, 256),   # vanishing recurrent weights, more steps
+    (True, 3, 1, 90, 0, 1.0, 192),     # H = 192 (6 waves): one sequence per utterance over 90 frames, both directions
+    (False, 2, 4, 9, 0, 1.0, 192),
+])
+def test_lstm_h256_streamed_weights_kernel(H, dev, bi, n, s, k, shift, wscale, hid):
+    """ps_lstm_fmajor_h256_f16x2_f32 (H = 256: W_hh streamed from its packed image, frame-major pre-activations, initial and
+    final states) on SkiM's segment layout (q = segment, k consecutive frames each) against the oracle's LSTM and the generic
+    fp32 kernel."""
+    import torch.nn as nn
+    from oracle import dualpath_oracle as DP
+    from puresound_amd.nnet._plans import lstm_plan
+    c = 12
+    m = nn.LSTM(c, hid, num_layers=1, bidirectional=bi, batch_first=True)
+    sd = {kk: _rand(tuple(v.shape), 430 + i, -0.25, 0.25) * (wscale if "weight_hh" in kk else 1.0)
+          for i, (kk, v) in enumerate(m.state_dict().items())}
+    m.load_state_dict(sd)
+    d = 2 if bi else 1
+    x = _rand4((n, c, s * k), 431)
+    seqs = x.transpose(1, 2).reshape(n * s, k, c)
+    h0 = _rand4((d, n * s, hid), 432, -0.5, 0.5)
+    c0 = _rand4((d, n * s, hid), 433, -0.5, 0.5)
+    p = lstm_plan(m.to(dev), torch.device(dev))
+    t = s * k
+    xp = H.pad_rows(x.to(dev))
+    ldt = xp.shape[-1]
+    gx, _ = H.conv1x1(xp, t, p["wih"], p["rows"], None, p["bias"])
+    gx_fm = gx.transpose(1, 2).contiguous()
+    to_state = lambda v: H.pad_rows(v.reshape(d, n, s, hid).permute(1, 0, 3, 2).reshape(n, d * hid, s).to(dev))  # noqa: E731
+    back = lambda v: v[..., :s].cpu().reshape(n, d, hid, s).permute(1, 0, 3, 2).reshape(d, n * s, hid)  # noqa: E731
+    img, scale = H.pack_whh_h256(p["whh_t"])
+    base, (bh, bc) = H.lstm(gx, p["whh_t"], hid, d, s, k, k, 1, to_state(h0), to_state(c0), want_state=True, state_shift=shift)
+    hout, (hl, cl) = H.lstm_fmajor_h256(gx_fm, img, scale, d, s, k, k, 1, to_state(h0), to_state(c0), want_state=True,
+                                        state_shift=shift)
+    torch.cuda.synchronize()
+    tol = 2e-5 if k < 20 else 1e-4
+    e = (rel_max(hout[..., :t].cpu().numpy(), base[..., :t].cpu().numpy()), rel_max(back(hl).numpy(), back(bh).numpy()),
+         rel_max(back(cl).numpy(), back(bc).numpy()))
+    assert max(e) < tol, e
+    if shift == 0:   # (the oracle's LSTM takes per-sequence initial states directly)
+        ref, (hn, cn) = DP.lstm(seqs, sd, "", bi, (h0, c0))
+        got = hout[..., :t].cpu().transpose(1, 2).reshape(n * s, k, d * hid)
+        e = (rel_max(got.numpy(), ref.numpy()), rel_max(back(hl).numpy(), hn.numpy()), rel_max(back(cl).numpy(), cn.numpy()))
+        assert max(e) < tol, e

@@ -36,10 +36,7 @@ def main():
             fn = (lambda: model.inference(noisy, enroll)) if spk else (lambda: model.inference(noisy))
             out = {"preset": name}
             for prec in ("fp32", "fp16x2"):
-                if hasattr(model.masker, "set_gemm_precision"):
-                    model.masker.set_gemm_precision(prec)
-                elif prec == "fp16x2":
-                    continue
+                model.set_gemm_precision(prec)
                 torch.manual_seed(0)
                 for _ in range(2):
                     y = fn()
