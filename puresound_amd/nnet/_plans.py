@@ -42,7 +42,11 @@ class PlanCache:
 
     _plan = None
     _plan_sig = None
-    gemm_precision = "fp32"  # arithmetic of the LSTM input projections built by this module (see _PLANES)
+    # arithmetic of the GEMMs (and, where kernels for it exist, the recurrent products) built by this module (see _PLANES).
+    # Round 4: "fp16x2" is the default here as it has been for the TCN blocks since round 2 -- fp32-class results (two fp16
+    # terms per operand, three products, fp32 accumulation: 1e-6 against exact fp32 products on every preset measured) at
+    # 1.6-3.4 x the speed on the egs presets; set_gemm_precision("fp32") selects exact fp32 products.
+    gemm_precision = "fp16x2"
 
     def set_gemm_precision(self, name: str):
         """"fp32" | "bf16x3" | "fp16x2" | "bf16" for the LSTM input projections of this module and of every module below

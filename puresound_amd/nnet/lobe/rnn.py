@@ -54,9 +54,10 @@ class SingleRNN(PlanCache, nn.Module):
             return y
         gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=x.device)
         if rnn["planes"] and rnn["I"] >= 64:
-            if rnn["planes"] not in rnn["wih_planes"]:
-                rnn["wih_planes"][rnn["planes"]] = hip.pack_wt_bf16(rnn["wih_rows"], rnn["planes"])
-            hip.conv1x1_bf16(x, t, rnn["wih_planes"][rnn["planes"]], rnn["rows"], None, rnn["bias"], out=gx)
+            planes = 3 if rnn["planes"] == 2 else rnn["planes"]   # (fp16x2 needs a range pass: the fp32-class bf16 split here)
+            if planes not in rnn["wih_planes"]:
+                rnn["wih_planes"][planes] = hip.pack_wt_bf16(rnn["wih_rows"], planes)
+            hip.conv1x1_bf16(x, t, rnn["wih_planes"][planes], rnn["rows"], None, rnn["bias"], out=gx)
         else:
             hip.conv1x1(x, t, rnn["wih"], rnn["rows"], None, rnn["bias"], out=gx)
         # one sequence per utterance: q = 1, the steps walk the frame axis

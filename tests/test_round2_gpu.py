@@ -92,6 +92,8 @@ def test_config4_input_projections_on_the_bf16_pipe(PA, dev, gemm, tol):
     name = "cfg4_short"
     model, sd = _build(PA, name, dev)
     other, _ = _build(PA, name, dev)
+    assert other.masker.gemm_precision == "fp16x2"     # (the default since round 4)
+    other.masker.set_gemm_precision("fp32")
     model.masker.set_gemm_precision(gemm)
     assert other.masker.gemm_precision == "fp32"
     noisy = det_wave(301, 32, 64000)
