@@ -32,7 +32,7 @@ def main():
             model = cases.build(PA.NS, name).eval()
             model.load_state_dict(det_state_dict(model))
             model.to(dev)
-            spk = bool(c.get("speaker_net") or c.get("spk"))
+            spk = bool(c.get("speaker_net") or c.get("spk") or getattr(model, "embedding_free_tse", False))
             fn = (lambda: model.inference(noisy, enroll)) if spk else (lambda: model.inference(noisy))
             out = {"preset": name}
             for prec in ("fp32", "fp16x2"):
