@@ -200,3 +200,23 @@ def test_abi_host_side_helpers_need_no_gpu():
     # argument validation happens before any launch
     rc = lib.ps_conv1x1_f32(None, None, None, 1, 16, 16, 10, 128, None, None, None, None, None, None)
     assert rc == -1 and b"null pointer" in lib.ps_last_error()
+
+
+def test_wrapper_level_gemm_precision_switch():
+    """SoTaskWrapModule.set_gemm_precision reaches every module of masker and speaker branch that has a choice; the default of
+    the recurrent / attention maskers is "fp16x2" like the TCN blocks'; unknown names raise."""
+    import cases
+    import puresound_amd.nnet as PA
+    from puresound_amd.nnet._plans import PlanCache
+    model = cases.build(PA.NS, "tse_skim_v1_short").eval()
+    mods = [m for root in (model.masker, model.speaker_net) for m in root.modules() if hasattr(m, "gemm_precision")]
+    assert len(mods) > 5 and all(m.gemm_precision == "fp16x2" for m in mods)
+    assert model.set_gemm_precision("fp32") is model
+    assert all(m.gemm_precision == "fp32" for m in mods)
+    assert any(isinstance(m, PlanCache) for m in model.speaker_net.modules())
+    with pytest.raises(ValueError, match="gemm precision"):
+        model.set_gemm_precision("fp8")
+    tcn = cases.build(PA.NS, "cfg3_short").eval()
+    tcn.set_gemm_precision("bf16x3")
+    assert all(m.gemm_precision == "bf16x3" for root in (tcn.masker, tcn.speaker_net) for m in root.modules()
+               if hasattr(m, "gemm_precision"))
