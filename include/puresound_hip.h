@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 15
+#define PS_ABI_VERSION 16
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -280,6 +280,16 @@ int ps_conv2d_f32(const float* x1, int C1, const float* x2, int C2, const float*
  * convolution in Unet / UnetTcn(norm_type="gLN") (unet.py:100-165, lobe/norm.py), consumed by ps_norm_activation_f32
  * through a PS_NORM_GLOBAL prologue.  One partial per workgroup in its own slot (deterministic). */
 int ps_conv2d_stats_parts(int M, int Fout, int ld);
+/* ps_conv2d_f32 / ps_conv2d_stats_f32 in the fp16x2 arithmetic (two fp16 terms per operand, three v_mfma_f32_16x16x32_f16
+ * products, fp32 accumulation; the activations' range is found by the kernel itself, wave by wave).  wimg: the host-packed
+ * image of 2^w_exp W: [channel tiles of MT][ceil(K/32)][2 planes][MT/16][4][16][8] halves with MT = 32 (M <= 32), 64 (M <= 64)
+ * or 128: element (tile, chunk, pl, rb, kg, row, e) = plane pl of 2^w_exp W[tile*MT + 16 rb + row][32 chunk + 8 kg + e] (zero
+ * outside W; w_exp puts max |2^w_exp W| into [2^13, 2^14)).  ostats: NULL, or the partial statistics of ps_conv2d_stats_f32
+ * (act is then applied to the stored values as given; pass 0 in front of a gLN). */
+int ps_conv2d_f16x2_f32(const float* x1, int C1, const float* x2, int C2, const void* wimg, int w_exp, const float* bias,
+                        float* y, int N, int M, int Fin, int T_in, int T, int ld, int kf, int kt, int stride_f, int dil_f,
+                        int dil_t, int pad_f, int pad_t, int Fout, int transposed, int act, const float* slope, double* ostats,
+                        void* stream);
 int ps_conv2d_stats_f32(const float* x1, int C1, const float* x2, int C2, const float* wt, const float* bias, float* y, int N,
                         int M, int Fin, int T_in, int T, int ld, int kf, int kt, int stride_f, int dil_f, int dil_t, int pad_f,
                         int pad_t, int Fout, int transposed, double* ostats, void* stream);

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PURESOUND_HIP_LIB: an experimental build of the same library (tools/build_variant.sh); kernel experiments only
 LIB_PATH = os.environ.get("PURESOUND_HIP_LIB") or os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -115,6 +115,7 @@ SIGNATURES = {
     "ps_unfold2d_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp] + [C.c_int] * 14 + [_vp]),
     "ps_conv2d_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 16 + [_vp, _vp]),
     "ps_conv2d_stats_parts": (C.c_int, [C.c_int] * 3),
+    "ps_conv2d_f16x2_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp] + [C.c_int] * 16 + [_vp, _vp, _vp]),
     "ps_conv2d_stats_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 15 + [_vp, _vp]),
     "ps_activation_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "ps_magnitude_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 6 + [_vp]),

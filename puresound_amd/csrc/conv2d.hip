@@ -332,6 +332,179 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(Conv2dArgs a) {
   }
 }
 
+// ---- the same implicit GEMM in the fp16x2 arithmetic (ps_conv2d_f16x2_f32) ------------------------------------------------
+// conv2d_lds_kernel is bound by the fp32 matrix pipe: 2048 / 4096 matrix-pipe cycles per wave and 32-k chunk at 64 / 128
+// channels (the 256 -> 64 layer of ns_dpcrn_v0: 3.1 ms, 65 TFLOP/s).  Here the products are v_mfma_f32_16x16x32_f16 on two
+// fp16 terms per operand (W 2^e = W_hi + W_lo from the host's image, x S = x_hi + x_lo split in registers; three products,
+// fp32 accumulation: the error class of the fp16x2 GEMMs): 24 / 48 issues of 16 cycles per chunk.  What remains is the
+// gather and the split of the B operand on the vector ALU (~170 instructions per chunk), which the wave's other work hides.
+//   * B: lane (col c = lane & 15, k-group kg = lane >> 4) loads x[k = 32 chunk + 8 kg + e][frame] for its two frames (column
+//     blocks cb = 0, 1: frames t0 + 32 w + 16 cb + c) -- exactly the MFMA's B fragment (8 consecutive k of one column).
+//   * The range of x is not known to the caller (PReLU outputs): every wave scales by a power of two S of its own, chosen
+//     from the maximum |x| it has seen so far (wave_max per chunk); when a chunk exceeds the current range the accumulators
+//     are multiplied by the ratio (a power of two: exact) and S drops.  Smaller values later keep S -- fp16 is floating
+//     point, their two terms still carry 22 bits -- and S only ever falls, so nothing overflows (|W_hi| < 2^14, |x S| < 2^15,
+//     K <= 4096: sums below 2^41).
+//   * A: the host packs W 2^e into MFMA-fragment order per (channel tile, chunk): [plane][row block][kg][row][8 k] halves;
+//     a chunk is MT x 128 bytes, copied to LDS by all threads (double buffered, one barrier per chunk); fragment reads are
+//     conflict-free 16-byte reads.  k runs in natural order (the table marks rows outside the input): layers whose taps
+//     need compaction (transposed with stride 2) stay on conv2d_lds_kernel.
+typedef _Float16 c2d_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned c2d_u32x4 __attribute__((ext_vector_type(4)));
+
+struct Conv2dF16Args {
+  Conv2dArgs g;       // (wt unused)
+  const void* wimg;   // [mtiles][Kq / 32][2][RB][4][16][8] halves
+  float winv;         // 2^-e
+};
+
+template <int MB>
+__global__ __launch_bounds__(256) void conv2d_f16x2_kernel(Conv2dF16Args fa) {
+  const Conv2dArgs& a = fa.g;
+  constexpr int MT = 32 * MB, RB = 2 * MB, CHB = MT * 128;  // channels, row blocks, bytes of an A chunk
+  extern __shared__ int c2d_tab[];
+  const int Kq = (a.Kp + 31) / 32 * 32;
+  int* const tab_off = c2d_tab;
+  int* const tab_shift = c2d_tab + Kq;
+  unsigned char* const As = reinterpret_cast<unsigned char*>(c2d_tab + 2 * Kq);  // [2][CHB]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, kg = lane >> 4;
+  int bx, fo, bz;
+  c2d_block(bx, fo, bz);
+  const int t0 = bx * 128;
+  const int mtiles = (a.M + MT - 1) / MT;
+  const int n = bz / mtiles, mt = bz % mtiles, m0 = mt * MT;
+  for (int k = tid; k < Kq; k += 256) {
+    int off, sh;
+    c2d_tap(a, k, fo, off, sh);
+    tab_off[k] = off;
+    tab_shift[k] = sh;
+  }
+  const int nch = Kq / 32;
+  const c2d_u32x4* wsrc = reinterpret_cast<const c2d_u32x4*>(fa.wimg) + (size_t)mt * nch * (CHB / 16);
+  c2d_u32x4 areg[MB];
+  auto a_fetch = [&](int ch) {
+#pragma unroll
+    for (int j = 0; j < MB; ++j) areg[j] = wsrc[(size_t)ch * (CHB / 16) + j * 256 + tid];
+  };
+  auto a_store = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < MB; ++j) reinterpret_cast<c2d_u32x4*>(As + buf * CHB)[j * 256 + tid] = areg[j];
+  };
+  a_fetch(0);
+  a_store(0);
+  __syncthreads();
+
+  const float* x1n = a.x1 + (size_t)n * a.C1 * a.Fin * a.ld;
+  const float* x2n = a.x2 ? a.x2 + (size_t)n * a.C2 * a.Fin * a.ld : a.x1;
+  const int tc0 = t0 + 32 * w + c, tc1 = tc0 + 16;
+  f32x4 acc[RB][2];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) acc[rb][0] = acc[rb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float S = 1.0995116e12f;  // 2^40: the first chunk with a non-zero value sets the scale
+  int se = 40;              // S = 2^se
+
+  float bv[2][8];
+  auto fetch = [&](int ch) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = ch * 32 + 8 * kg + e;
+      const int off = tab_off[k];
+      const int sh = tab_shift[k];
+      const float* src = (off & (1 << 30)) ? x2n : x1n;
+      const int o = off & ((1 << 30) - 1);
+      const int i0 = tc0 + sh, i1 = tc1 + sh;
+      const bool ok0 = off >= 0 && (unsigned)i0 < (unsigned)a.Tin, ok1 = off >= 0 && (unsigned)i1 < (unsigned)a.Tin;
+      const float v0 = src[ok0 ? o + i0 : 0], v1 = src[ok1 ? o + i1 : 0];  // unconditional loads of valid addresses
+      bv[0][e] = ok0 ? v0 : 0.f;
+      bv[1][e] = ok1 ? v1 : 0.f;
+    }
+  };
+  if (nch > 0) fetch(0);
+  for (int ch = 0; ch < nch; ++ch) {
+    // range of this chunk's values in the wave; the scale follows downwards
+    float m = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(fabsf(bv[0][e]), fabsf(bv[1][e])));
+    m = wave_max(m);
+    {
+      int ex = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255) - 127;  // |x| < 2^(ex + 1)
+      ex = ex > 100 ? 100 : ex;
+      const int want = 14 - ex;  // x 2^want < 2^15
+      if (m > 0.f && want < se) {  // uniform
+        const float r = ldexpf(1.f, want - se);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb][0] *= r, acc[rb][1] *= r;
+        se = want;
+        S = ldexpf(1.f, se);
+      }
+    }
+    c2d_f16x8 bh[2], bl[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xs = bv[cb][e] * S;
+        const _Float16 hi = (_Float16)xs;
+        bh[cb][e] = hi;
+        bl[cb][e] = (_Float16)(xs - (float)hi);
+      }
+    if (ch + 1 < nch) {
+      a_fetch(ch + 1);
+      fetch(ch + 1);
+    }
+    const c2d_f16x8* ab = reinterpret_cast<const c2d_f16x8*>(As + (ch & 1) * CHB) + lane;  // + (plane * RB + rb) * 64
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const c2d_f16x8 ahi = ab[rb * 64], alo = ab[(RB + rb) * 64];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bh[cb], acc[rb][cb], 0, 0, 0);
+        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bh[cb], acc[rb][cb], 0, 0, 0);
+        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bl[cb], acc[rb][cb], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < nch) a_store((ch + 1) & 1);
+    __syncthreads();
+  }
+
+  const float osc = fa.winv * ldexpf(1.f, -se);
+  const float s = a.slope ? a.slope[0] : 0.f;
+  float fsum = 0.f, fsq = 0.f;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mrow = m0 + 16 * rb + 4 * kg + r;
+      if (mrow < a.M) {
+        const float b = a.bias ? a.bias[mrow] : 0.f;
+        float* row = a.y + (((size_t)n * a.M + mrow) * a.Fout + fo) * a.ld;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const int t = cb ? tc1 : tc0;
+          float v = acc[rb][cb][r] * osc + b;
+          if (t < a.T) fsum += v, fsq += v * v;
+          v = act_apply(v, a.act, s);
+          if (t < a.ld) row[t] = t < a.T ? v : 0.f;
+        }
+      }
+    }
+  if (a.stats) {
+    __shared__ double red[2][4];
+    const double ws = wave_sum((double)fsum), wq = wave_sum((double)fsq);
+    __syncthreads();
+    if (lane == 0) red[0][w] = ws, red[1][w] = wq;
+    __syncthreads();
+    if (tid == 0) {
+      const int parts = gridDim.x * gridDim.y * mtiles;
+      const int part = (mt * gridDim.y + fo) * gridDim.x + bx;
+      double* dst = a.stats + ((size_t)n * parts + part) * 2;
+      dst[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      dst[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+  }
+}
+
 // ---- four output channels at most (the mask layer of a U-Net decoder: 64 -> 2 channels, 5 x 2 taps, 256 output rows) -------
 // The MFMA tile is 32 channels wide: 2 useful rows of 32 (168 GFLOP issued for 10 at 32 x 4 s, 3.3 ms of the forward).  Here
 // the matrix pipe is left alone: a thread owns two frames (t, t + 256) of R = 8 consecutive output rows and all M channels
@@ -442,6 +615,52 @@ __global__ __launch_bounds__(256) void conv2d_rows_kernel(Conv2dArgs a, int span
 }  // namespace ps
 
 using namespace ps;
+
+extern "C" int ps_conv2d_f16x2_f32(const float* x1, int C1, const float* x2, int C2, const void* wimg, int w_exp,
+                                   const float* bias, float* y, int N, int M, int Fin, int T_in, int T, int ld, int kf, int kt,
+                                   int stride_f, int dil_f, int dil_t, int pad_f, int pad_t, int Fout, int transposed, int act,
+                                   const float* slope, double* ostats, void* stream) {
+  if (!x1 || !wimg || !y || N <= 0 || M <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && !x2) || Fin <= 0 || Fout <= 0 || T <= 0 ||
+      T_in <= 0 || ld < T || ld < T_in || ld % 128 || kf <= 0 || kt <= 0 || stride_f <= 0 || dil_f <= 0 || dil_t <= 0 ||
+      Fout > 65535 || act < 0 || act > 5 || (act == 2 && !slope) || w_exp < -100 || w_exp > 100 || ((uintptr_t)wimg & 15)) {
+    set_error("ps_conv2d_f16x2_f32: bad argument (N=%d M=%d C=%d+%d F=%d->%d T=%d k=%dx%d act=%d)", N, M, C1, C2, Fin, Fout, T,
+              kf, kt, act);
+    return PS_E_INVALID;
+  }
+  const long long K = (long long)(C1 + C2) * kf * kt;
+  const int Kp = (int)((K + 15) / 16 * 16);
+  if (Kp > C2D_MAXK || (long long)(C1 > C2 ? C1 : C2) * Fin * ld >= (1LL << 30)) {
+    set_error("ps_conv2d_f16x2_f32: Cin*kf*kt = %lld exceeds %d, or an utterance of the input exceeds 2^30 elements", K, C2D_MAXK);
+    return PS_E_UNSUPPORTED;
+  }
+  const int mb = M <= 32 ? 1 : M <= 64 ? 2 : 4;
+  const int mtiles = (M + 32 * mb - 1) / (32 * mb);
+  if ((long long)N * mtiles > 65535) {
+    set_error("ps_conv2d_f16x2_f32: N * channel tiles exceeds the grid limit");
+    return PS_E_UNSUPPORTED;
+  }
+  Conv2dF16Args fa{{x1, x2, nullptr, bias, slope, y, C1, C2, Fin, T, T_in, ld, kf, kt, stride_f, dil_f, dil_t, pad_f, pad_t,
+                    Fout, M, (int)K, Kp, transposed, act, ostats},
+                   wimg, ldexpf(1.f, -w_exp)};
+  dim3 grid(ld / 128, Fout, N * mtiles);
+  const int Kq = (Kp + 31) / 32 * 32;
+  const size_t lds = (size_t)2 * Kq * sizeof(int) + (size_t)2 * 32 * mb * 128;
+  {
+    LaunchTimer timer("conv2d", (hipStream_t)stream);
+    if (mb == 1)
+      hipLaunchKernelGGL((conv2d_f16x2_kernel<1>), grid, dim3(256), lds, (hipStream_t)stream, fa);
+    else if (mb == 2)
+      hipLaunchKernelGGL((conv2d_f16x2_kernel<2>), grid, dim3(256), lds, (hipStream_t)stream, fa);
+    else
+      hipLaunchKernelGGL((conv2d_f16x2_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream, fa);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("ps_conv2d_f16x2_f32: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
 
 extern "C" int ps_conv2d_stats_parts(int M, int Fout, int ld) {
   if (M <= 0 || Fout <= 0 || ld <= 0 || ld % 128) return 0;

@@ -726,6 +726,51 @@ def conv2d(x1: torch.Tensor, x2: Optional[torch.Tensor], wt: torch.Tensor, bias:
     return y
 
 
+def pack_conv2d_f16x2(w2: torch.Tensor):
+    """[M, K] fp32 (BatchNorm folded) -> (image of 2^w_exp W for ps_conv2d_f16x2_f32, w_exp); layout: include/puresound_hip.h.
+    Reads the maximum back to the host: plan-build time only."""
+    import math
+    m, k = w2.shape
+    wmax = float(w2.detach().abs().max())
+    if not (wmax < float("inf")):
+        raise ValueError("pack_conv2d_f16x2: the weight holds inf / NaN")
+    w_exp = 13 - math.frexp(wmax)[1] + 1 if wmax > 0 else 0
+    mt = 32 if m <= 32 else 64 if m <= 64 else 128
+    tiles, nch = (m + mt - 1) // mt, (k + 31) // 32
+    rest = torch.zeros(tiles * mt, nch * 32, dtype=torch.float32, device=w2.device)
+    rest[:m, :k] = torch.ldexp(w2.detach().float(), torch.tensor(w_exp, device=w2.device))
+    planes = []
+    for _ in range(2):
+        hp = rest.to(torch.float16)
+        planes.append(hp)
+        rest = rest - hp.float()
+    img = torch.stack(planes, 0).reshape(2, tiles, mt // 16, 16, nch, 4, 8)      # pl, tile, rb, row, chunk, kg, e
+    img = img.permute(1, 4, 0, 2, 5, 3, 6).contiguous()                          # tile, chunk, pl, rb, kg, row, e
+    return img, w_exp
+
+
+def conv2d_f16x2(x1: torch.Tensor, x2: Optional[torch.Tensor], wimg: torch.Tensor, w_exp: int, bias: Optional[torch.Tensor],
+                 m: int, t: int, f_out: int, kf: int, kt: int, stride_f: int, dil_f: int, dil_t: int, pad_f: int, pad_t: int,
+                 transposed: bool, act: str = "none", slope: Optional[torch.Tensor] = None, t_in: Optional[int] = None,
+                 want_stats: bool = False):
+    """conv2d / conv2d_stats in the fp16x2 arithmetic (ps_conv2d_f16x2_f32; weights from pack_conv2d_f16x2).  Returns y, or
+    (y, stats) with want_stats (the activation should then be "none": a gLN follows)."""
+    require_device(x1, "conv2d_f16x2")
+    n, c1, f_in, ld = x1.shape
+    c2 = 0 if x2 is None else x2.shape[1]
+    if x2 is not None and (x2.shape[0], x2.shape[2], x2.shape[3]) != (n, f_in, ld):
+        raise RuntimeError("conv2d_f16x2: the two sources must agree in N, F and ld")
+    y = torch.empty(n, m, f_out, ld, dtype=torch.float32, device=x1.device)
+    stats = None
+    if want_stats:
+        stats = torch.empty(n, lib().ps_conv2d_stats_parts(m, f_out, ld), 2, dtype=torch.float64, device=x1.device)
+    check(lib().ps_conv2d_f16x2_f32(ptr(x1), c1, ptr(x2), c2, ptr(wimg), int(w_exp), ptr(bias), ptr(y), n, m, f_in,
+                                    t if t_in is None else t_in, t, ld, kf, kt, stride_f, dil_f, dil_t, pad_f, pad_t, f_out,
+                                    int(transposed), ACT_KINDS[act], ptr(slope), ptr(stats), stream_ptr(x1.device)),
+          "ps_conv2d_f16x2_f32")
+    return (y, stats) if want_stats else y
+
+
 def conv2d_stats(x1: torch.Tensor, x2: Optional[torch.Tensor], wt: torch.Tensor, bias: Optional[torch.Tensor], m: int, t: int,
                  f_out: int, kf: int, kt: int, stride_f: int, dil_f: int, dil_t: int, pad_f: int, pad_t: int, transposed: bool,
                  t_in: Optional[int] = None):

@@ -25,6 +25,7 @@ import os
 # 1 (default): Conv2d / ConvTranspose2d as ps_conv2d_f32 (implicit GEMM, taps gathered in the kernel);
 # 0: ps_unfold2d_f32 + ps_conv1x1_f32 + ps_activation_f32 (the path gLN-normalised layers always take)
 IMPLICIT_CONV = os.environ.get("PS_IMPLICIT_CONV", "1") == "1"
+F16X2_STRIDED = os.environ.get("PS_CONV2D_F16X2_STRIDED", "1") == "1"   # 0: stride > 1 transposed layers stay on the fp32 kernel (compacted taps)
 
 
 def _unet_shape(ctor, x, aux, params):
@@ -154,16 +155,16 @@ class Unet(PlanCache, nn.Module):
             w2, b = self._fold(seq[2], _f32(conv.weight, device).reshape(conv.out_channels, -1),
                                _f32(conv.bias, device))
             kind, slope = self._act(seq[3], device)
-            down.append(dict(wt=hip.pack_wt(w2), bias=b.contiguous(), M=conv.out_channels, act=kind, slope=slope,
-                             **self._gln(seq[2], b, device)))
+            down.append(dict(wt=hip.pack_wt(w2), w2=w2.contiguous(), bias=b.contiguous(), M=conv.out_channels, act=kind,
+                             slope=slope, **self._gln(seq[2], b, device)))
         for j, seq in enumerate(self.cnn_up):
             conv = seq[0]
             w = _f32(conv.weight, device)                                      # [Cin, Cout, kf, kt]
             w2 = w.permute(1, 0, 2, 3).reshape(w.shape[1], -1)
             w2, b = self._fold(seq[1] if len(seq) > 1 else None, w2, _f32(conv.bias, device))
             kind, slope = self._act(seq[2] if len(seq) > 2 else None, device)
-            up.append(dict(wt=hip.pack_wt(w2.contiguous()), bias=b.contiguous(), M=w.shape[1], act=kind, slope=slope,
-                           **self._gln(seq[1] if len(seq) > 1 else None, b, device)))
+            up.append(dict(wt=hip.pack_wt(w2.contiguous()), w2=w2.contiguous(), bias=b.contiguous(), M=w.shape[1], act=kind,
+                           slope=slope, **self._gln(seq[1] if len(seq) > 1 else None, b, device)))
         if self.skip_conv:
             for seq in self.skip_cnn:
                 kind, slope = self._act(seq[1], device)
@@ -185,6 +186,30 @@ class Unet(PlanCache, nn.Module):
         pad = float(f_out * (ld - t))
         return hip.norm_activation_(y, t, pro, lay["bias_sum"] * pad, lay["bias_sq"] * pad, lay["act"], lay["slope"])
 
+    def _conv(self, x, x2, lay: dict, t: int, f_out: int, kf: int, kt: int, sf: int, df: int, dt: int, pf: int, pt: int,
+              transposed: bool, t_in=None):
+        """One implicit-GEMM convolution of the stack with its epilogue (activation, or the statistics of a gLN that follows):
+        the fp16x2 kernel when the module's arithmetic is "fp16x2" and the layer suits it (K >= 32, more than 4 output
+        channels, no stride-2 transposed taps to compact), else the exact-fp32 kernels."""
+        gln = "gln" in lay
+        k = (x.shape[1] + (0 if x2 is None else x2.shape[1])) * kf * kt
+        if self.gemm_precision == "fp16x2" and k >= 32 and lay["M"] > 4 and (F16X2_STRIDED or not (transposed and sf > 1)):
+            if "f16x2" not in lay:
+                lay["f16x2"] = hip.pack_conv2d_f16x2(lay["w2"])
+            img, w_exp = lay["f16x2"]
+            if gln:
+                y, stats = hip.conv2d_f16x2(x, x2, img, w_exp, lay["bias"], lay["M"], t, f_out, kf, kt, sf, df, dt, pf, pt,
+                                            transposed, t_in=t_in, want_stats=True)
+                return self._gln_act(y, stats, lay, f_out, t)
+            return hip.conv2d_f16x2(x, x2, img, w_exp, lay["bias"], lay["M"], t, f_out, kf, kt, sf, df, dt, pf, pt, transposed,
+                                    lay["act"], lay["slope"], t_in=t_in)
+        if gln:
+            y, stats = hip.conv2d_stats(x, x2, lay["wt"], lay["bias"], lay["M"], t, f_out, kf, kt, sf, df, dt, pf, pt, transposed,
+                                        t_in=t_in)
+            return self._gln_act(y, stats, lay, f_out, t)
+        return hip.conv2d(x, x2, lay["wt"], lay["bias"], lay["M"], t, f_out, kf, kt, sf, df, dt, pf, pt, transposed, lay["act"],
+                          lay["slope"], t_in=t_in)
+
     def _gln_act(self, y: torch.Tensor, stats: torch.Tensor, lay: dict, f_out: int, t: int) -> torch.Tensor:
         """gLN + activation behind a convolution whose statistics cover the t valid frames only (no pad-column correction)."""
         gln = lay["gln"]
@@ -202,15 +227,10 @@ class Unet(PlanCache, nn.Module):
             f_in = x.shape[2]
             pf = kf // 2
             f_out = (f_in + 2 * pf - df * (kf - 1) - 1) // sf + 1
-            if "gln" not in lay and IMPLICIT_CONV and x.shape[1] * kf * kt <= 4096:
-                x = hip.conv2d(x, None, lay["wt"], lay["bias"], lay["M"], t, f_out, kf, kt, sf, df, dt, pf,
-                               kt - self.delay[i] - 1, False, lay["act"], lay["slope"])
-            elif IMPLICIT_CONV and x.shape[1] * kf * kt <= 4096:
-                # gLN behind the convolution: the implicit GEMM leaves the statistics of its output behind (round 3 built the
-                # tap matrix for these layers: 43 + 47 ms per forward of tse_unet_tcn_v0 at 32 x 4 s)
-                y, stats = hip.conv2d_stats(x, None, lay["wt"], lay["bias"], lay["M"], t, f_out, kf, kt, sf, df, dt, pf,
-                                            kt - self.delay[i] - 1, False)
-                x = self._gln_act(y, stats, lay, f_out, t)
+            if IMPLICIT_CONV and x.shape[1] * kf * kt <= 4096:
+                # (a gLN behind the convolution gets its statistics from the convolution's epilogue: round 3 built the tap
+                #  matrix for these layers, 43 + 47 ms per forward of tse_unet_tcn_v0 at 32 x 4 s)
+                x = self._conv(x, None, lay, t, f_out, kf, kt, sf, df, dt, pf, kt - self.delay[i] - 1, False)
             else:
                 taps = hip.unfold2d(x, None, t, f_out, kf, kt, sf, df, dt, pf, kt - self.delay[i] - 1, False)
                 x = self._gemm_act(taps, lay, f_out, x.shape[3], t)
@@ -245,9 +265,7 @@ class Unet(PlanCache, nn.Module):
                 if t + ext > ld:
                     raise NotImplementedError("U-Net on HIP: gLN decoder needs rows with room for the untrimmed frames")
                 if IMPLICIT_CONV and (x.shape[1] + (0 if x2 is None else x2.shape[1])) * kf * self.t_kernel <= 4096:
-                    y, stats = hip.conv2d_stats(x, x2, lay["wt"], lay["bias"], lay["M"], t + ext, f_out, kf, self.t_kernel, sf,
-                                                df, dt, pf, 0, True, t_in=t)
-                    x = self._gln_act(y, stats, lay, f_out, t + ext)
+                    x = self._conv(x, x2, lay, t + ext, f_out, kf, self.t_kernel, sf, df, dt, pf, 0, True, t_in=t)
                 else:
                     taps = hip.unfold2d(x, x2, t + ext, f_out, kf, self.t_kernel, sf, df, dt, pf, 0, True, t_in=t)
                     x = self._gemm_act(taps, lay, f_out, ld, t + ext)
@@ -255,8 +273,7 @@ class Unet(PlanCache, nn.Module):
                     x = hip.unfold2d(x, None, t, f_out, 1, 1, 1, 1, 1, 0, -ext, False, t_in=t + ext).view(
                         n, lay["M"], f_out, ld)
             elif IMPLICIT_CONV and (x.shape[1] + (0 if x2 is None else x2.shape[1])) * kf * self.t_kernel <= 4096:
-                x = hip.conv2d(x, x2, lay["wt"], lay["bias"], lay["M"], t, f_out, kf, self.t_kernel, sf, df, dt, pf,
-                               ext if transpose_delay else 0, True, lay["act"], lay["slope"])
+                x = self._conv(x, x2, lay, t, f_out, kf, self.t_kernel, sf, df, dt, pf, ext if transpose_delay else 0, True)
             else:
                 shift = ext if transpose_delay else 0
                 taps = hip.unfold2d(x, x2, t, f_out, kf, self.t_kernel, sf, df, dt, pf, shift, True)

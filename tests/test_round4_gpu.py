@@ -375,3 +375,48 @@ def test_lstm_h256_streamed_weights_kernel(H, dev, bi, n, s, k, shift, wscale, h
         got = hout[..., :t].cpu().transpose(1, 2).reshape(n * s, k, d * hid)
         e = (rel_max(got.numpy(), ref.numpy()), rel_max(back(hl).numpy(), hn.numpy()), rel_max(back(cl).numpy(), cn.numpy()))
         assert max(e) < tol, e
+
+
+@pytest.mark.parametrize("transposed,m,c1,c2,amp", [(False, 40, 20, 12, 1.0), (True, 100, 30, 34, 1.0), (True, 32, 16, 16, 1.0),
+                                                    (False, 64, 40, 0, 300.0), (True, 128, 64, 64, 1e-3)])
+def test_conv2d_f16x2_kernel(H, dev, transposed, m, c1, c2, amp):
+    """ps_conv2d_f16x2_f32 against float64 Conv2d / ConvTranspose2d (stride 1 in time, 2 / 1 in frequency), two sources, PReLU
+    epilogue, statistics for a gLN; activations of very different magnitudes (the kernel finds their range itself) -- and
+    against the fp32 implicit GEMM: fp32 class."""
+    import torch.nn.functional as F
+    n, f, t = 2, 11, 150
+    x1 = _rand4((n, c1, f, t), 651) * amp
+    x1[:, :, :, 40:44] *= 50.0            # a burst: the scale has to fall in the middle of some waves' K loops
+    x2 = _rand4((n, c2, f, t), 652) * amp if c2 else None
+    x = torch.cat([x1, x2], 1) if c2 else x1
+    kf, kt, sf = 3, 2, (1 if transposed else 2)
+    b, slope = _rand4((m,), 653) * amp, torch.tensor([0.2])
+    pad = lambda v: H.pad_rows(v.reshape(n, -1, t).to(dev)).view(n, v.shape[1], f, -1)  # noqa: E731
+    if not transposed:
+        w = _rand4((m, c1 + c2, kf, kt), 654, -0.3, 0.3)
+        ref = F.conv2d(F.pad(x.double(), (kt - 1, 0, kf // 2, kf // 2)), w.double(), b.double(), stride=(sf, 1))
+        w2, shift = w.reshape(m, -1), kt - 1
+    else:
+        w = _rand4((c1 + c2, m, kf, kt), 654, -0.3, 0.3)
+        op = sf - kf + 2 * (kf // 2)
+        ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=(sf, 1), padding=(kf // 2, 0),
+                                 output_padding=(op, 0))[..., (kt - 1):]
+        w2, shift = w.permute(1, 0, 2, 3).reshape(m, -1), kt - 1
+    pre = ref
+    ref = torch.where(ref >= 0, ref, 0.2 * ref)
+    img, w_exp = H.pack_conv2d_f16x2(w2.contiguous().to(dev))
+    args = (m, t, ref.shape[2], kf, kt, sf, 1, 1, kf // 2, shift, transposed)
+    y = H.conv2d_f16x2(pad(x1), None if x2 is None else pad(x2), img, w_exp, b.to(dev), *args, "prelu", slope.to(dev))
+    y32 = H.conv2d(pad(x1), None if x2 is None else pad(x2), H.pack_wt(w2.contiguous().to(dev)), b.to(dev), *args, "prelu",
+                   slope.to(dev))
+    yr, stats = H.conv2d_f16x2(pad(x1), None if x2 is None else pad(x2), img, w_exp, b.to(dev), *args, want_stats=True)
+    torch.cuda.synchronize()
+    e = rel_max(y[..., :t].cpu().numpy(), ref.numpy())
+    e32 = rel_max(y32[..., :t].cpu().numpy(), ref.numpy())
+    print("conv2d fp16x2", e, "fp32 kernel", e32)
+    assert e < 5e-6 and e < 4 * e32 + 1e-6
+    assert float(y[..., t:].abs().max()) == 0.0
+    assert rel_max(yr[..., :t].cpu().numpy(), pre.numpy()) < 5e-6
+    tot = stats.sum(dim=1).cpu()
+    assert torch.allclose(tot[:, 0], pre.sum(dim=(1, 2, 3)), rtol=1e-5, atol=1e-3 * float(pre.abs().max()))
+    assert torch.allclose(tot[:, 1], (pre ** 2).sum(dim=(1, 2, 3)), rtol=1e-5)
