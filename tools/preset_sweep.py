@@ -35,7 +35,7 @@ def main():
             spk = bool(c.get("speaker_net") or c.get("spk") or getattr(model, "embedding_free_tse", False))
             fn = (lambda: model.inference(noisy, enroll)) if spk else (lambda: model.inference(noisy))
             out = {"preset": name}
-            for prec in ("fp32", "fp16x2"):
+            for prec in os.environ.get("PS_PRECS", "fp32,fp16x2").split(","):
                 model.set_gemm_precision(prec)
                 torch.manual_seed(0)
                 for _ in range(2):

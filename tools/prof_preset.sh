@@ -9,7 +9,8 @@ python3 - "$name" <<'PY'
 import csv, glob, sys
 f = glob.glob(f"gpurun_out/prof_{sys.argv[1]}/*/*kernel_stats.csv")[0]
 rows = list(csv.DictReader(open(f)))
-fw = 10.0   # 2 arithmetics x (2 warm-up + 3 timed) forwards in the profiled process
+import os
+fw = 5.0 * len(os.environ.get("PS_PRECS", "fp32,fp16x2").split(","))   # per arithmetic: 2 warm-up + 3 timed forwards
 with open(f"gpurun_out/prof_{sys.argv[1]}_kernels.txt", "w") as o:
     for r in rows[:22]:
         line = (f'{r["Name"][:86]:86s} {float(r["Calls"])/fw:7.1f}/fwd {float(r["AverageNs"])/1e3:9.2f} us '
