@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 16
+#define PS_ABI_VERSION 17
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -351,6 +351,14 @@ typedef struct {
   int N, H, D, Q, q_stride, steps, step_stride, ldt, ldq, state_shift;
 } ps_lstm_args;
 int ps_lstm_f32(const ps_lstm_args* args, void* stream);
+/* The recurrences of nn.RNN (tanh) and nn.GRU (num_layers = 1) -- SingleRNN(rnn_type = "RNN" | "GRU"),
+ * /root/reference/puresound/nnet/lobe/rnn.py:19-35; no recipe builds them, the kernel is the plain one.  ps_lstm_args with
+ * G = H (RNN) or 3H (GRU: gates r, z, n) gate rows per direction in gx [N][D*G][ldt] and whh_t [D][H][G]; c0 / c_last must be
+ * NULL, state_shift 0.  gx = W_ih x + b_ih + b_hh, except the GRU's n gate whose hidden bias stays inside the reset product:
+ * bhn [D][H] (n = tanh(gx_n + r * (W_hn h + b_hn)), h' = (1 - z) n + z h). */
+#define PS_RNN_TANH 0
+#define PS_RNN_GRU 2
+int ps_rnn_f32(const ps_lstm_args* args, int kind, const float* bhn, void* stream);
 /* The same recurrence with the product W_hh h in the fp16x2 arithmetic of ps_conv1x1_f16x2_f32 (two fp16 terms per
  * operand, three MFMA products, fp32 accumulation on top of the fp32 pre-activations; error <= 2^-21 of sum |W||h| per
  * gate and step) where a kernel for it exists -- H = 64 with 20 consecutive 16-byte-aligned steps per sequence (the

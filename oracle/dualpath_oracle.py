@@ -78,6 +78,35 @@ def lstm(x: torch.Tensor, sd: SD, p: str, bidirectional: bool, states: Optional[
     return torch.cat(outs, -1), (torch.stack(hs), torch.stack(cs))
 
 
+def gru_rnn(x: torch.Tensor, sd: SD, p: str, bidirectional: bool, kind: str) -> torch.Tensor:
+    """nn.GRU / nn.RNN(I, H, num_layers=1, bidirectional, batch_first=True) as SingleRNN builds them for rnn_type "GRU" / "RNN"
+    (lobe/rnn.py:19-35 of mcw519/PureSound: getattr(nn, rnn_type), default tanh non-linearity): x [B,L,I] -> out [B,L,D*H].
+    GRU (gate order r, z, n):  r = sig(W_ir x + b_ir + W_hr h + b_hr),  z = sig(W_iz x + b_iz + W_hz h + b_hz),
+    n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),  h' = (1 - z) * n + z * h.      RNN:  h' = tanh(W_ih x + b_ih + W_hh h + b_hh)."""
+    dirs = ["", "_reverse"] if bidirectional else [""]
+    hid = sd[p + "weight_hh_l0"].shape[1]
+    outs = []
+    for d, suf in enumerate(dirs):
+        w_ih, w_hh = sd[f"{p}weight_ih_l0{suf}"], sd[f"{p}weight_hh_l0{suf}"]
+        b_ih, b_hh = sd[f"{p}bias_ih_l0{suf}"].to(x.dtype), sd[f"{p}bias_hh_l0{suf}"].to(x.dtype)
+        gx = linear(x, w_ih, b_ih)
+        h = torch.zeros(x.shape[0], hid, dtype=x.dtype)
+        out = torch.empty(x.shape[0], x.shape[1], hid, dtype=x.dtype)
+        steps = range(x.shape[1] - 1, -1, -1) if d == 1 else range(x.shape[1])
+        for t in steps:
+            gh = linear(h, w_hh, b_hh)
+            if kind == "GRU":
+                r = torch.sigmoid(gx[:, t, :hid] + gh[:, :hid])
+                z = torch.sigmoid(gx[:, t, hid:2 * hid] + gh[:, hid:2 * hid])
+                n = torch.tanh(gx[:, t, 2 * hid:] + r * gh[:, 2 * hid:])
+                h = (1 - z) * n + z * h
+            else:
+                h = torch.tanh(gx[:, t] + gh)
+            out[:, t] = h
+        outs.append(out)
+    return torch.cat(outs, -1)
+
+
 def l2_normalize(e: torch.Tensor) -> torch.Tensor:
     """F.normalize(e, p=2, dim=1)."""
     return e / e.norm(p=2, dim=1, keepdim=True).clamp_min(1e-12)

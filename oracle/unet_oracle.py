@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import separator_oracle as O
-from .dualpath_oracle import layer_norm, linear, lstm
+from .dualpath_oracle import gru_rnn, layer_norm, linear, lstm
 
 SD = Dict[str, torch.Tensor]
 
@@ -188,9 +188,12 @@ def unet_tcn(x: torch.Tensor, sd: SD, p: str, args: dict, dvec: Optional[torch.T
     return unet_up(y.reshape(n, c, f, t), skip, sd, p, args)
 
 
-def single_rnn(x: torch.Tensor, sd: SD, p: str, bidirectional: bool) -> torch.Tensor:
-    """SingleRNN("LSTM") (lobe/rnn.py:9-55): x [B, C, L] -> LSTM over L -> Linear -> [B, C, L]."""
-    y, _ = lstm(x.transpose(1, 2), sd, p + "rnn.", bidirectional)
+def single_rnn(x: torch.Tensor, sd: SD, p: str, bidirectional: bool, kind: str = "LSTM") -> torch.Tensor:
+    """SingleRNN(kind) (lobe/rnn.py:9-55): x [B, C, L] -> LSTM / GRU / RNN over L -> Linear -> [B, C, L]."""
+    if kind == "LSTM":
+        y, _ = lstm(x.transpose(1, 2), sd, p + "rnn.", bidirectional)
+    else:
+        y = gru_rnn(x.transpose(1, 2), sd, p + "rnn.", bidirectional, kind)
     return linear(y, sd[p + "proj.weight"], sd[p + "proj.bias"]).transpose(1, 2)
 
 

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PURESOUND_HIP_LIB: an experimental build of the same library (tools/build_variant.sh); kernel experiments only
 LIB_PATH = os.environ.get("PURESOUND_HIP_LIB") or os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -91,6 +91,7 @@ SIGNATURES = {
     "ps_row_stats_f64": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ps_attn_weights_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ps_lstm_f32": (C.c_int, [C.POINTER(LstmArgs), _vp]),
+    "ps_rnn_f32": (C.c_int, [C.POINTER(LstmArgs), C.c_int, _vp, _vp]),
     "ps_lstm_f16x2_f32": (C.c_int, [C.POINTER(LstmArgs), _vp]),
     "ps_lstm_fmajor_ok": (C.c_int, [C.POINTER(LstmArgs), C.c_int]),
     "ps_lstm_fmajor_f16x2_f32": (C.c_int, [C.POINTER(LstmArgs), C.c_int, _vp]),

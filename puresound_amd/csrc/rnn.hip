@@ -139,6 +139,69 @@ __global__ __launch_bounds__(WREG ? 256 : 1024) void lstm_kernel(LstmK k) {
   }
 }
 
+// ---- GRU / Elman RNN cells (SingleRNN(rnn_type="GRU" | "RNN"), lobe/rnn.py:19-35: no recipe builds them) -------------------
+// The structure of lstm_kernel<false>: LS sequences per workgroup, a thread per gate row that walks W_hh^T's column with h in
+// LDS, then a thread per (unit, sequence) for the cell.  gx holds W_ih x + b_ih (+ b_hh except for the GRU's n gate, whose
+// hidden bias sits inside the reset product: bhn [D][H]).  KIND 0: h' = tanh(gx + W_hh h); 2: GRU, gates r, z, n.
+template <int KIND>
+__global__ __launch_bounds__(1024) void rnn_kernel(LstmK k, const float* __restrict__ bhn) {
+  constexpr int NG = KIND == 2 ? 3 : 1;
+  extern __shared__ float smem[];
+  const ps_lstm_args& a = k.a;
+  const int H = a.H, G = NG * H;
+  f32x4* hbuf = reinterpret_cast<f32x4*>(smem);  // [H]  current h of the LS sequences
+  f32x4* abuf = hbuf + H;                          // [G]  W_hh h (+ gx, + b_hn)
+  f32x4* xbuf = abuf + G;                          // [H]  GRU: gx of the n gate
+  const int g = threadIdx.x;
+  const int q0 = blockIdx.x * LS, n = blockIdx.y, d = blockIdx.z;
+  const bool row = g < G;
+  const int DH = a.D * H;
+  const float* wt = a.whh_t + (size_t)d * H * G + g;
+  const int j = g % H, i = g / H;  // cell role: unit j of sequence i
+  const bool cell = g < H * LS && q0 + i < a.Q;
+  float h = 0.f;
+  if (cell && a.h0) h = a.h0[((size_t)n * DH + d * H + j) * a.ldq + q0 + i];
+  if (g < H * LS) reinterpret_cast<float*>(hbuf)[j * LS + i] = h;
+  const float* grow = a.gx + ((size_t)n * a.D * G + (size_t)d * G + g) * a.ldt;
+  float* hrow = a.hout + ((size_t)n * DH + d * H + j) * a.ldt;
+  const bool rev = d == 1;
+  const float bn = (KIND == 2 && row && g >= 2 * H && bhn) ? bhn[d * H + (g - 2 * H)] : 0.f;
+  __syncthreads();
+  for (int s = 0; s < a.steps; ++s) {
+    const int ts = rev ? a.steps - 1 - s : s;
+    if (row) {
+      f32x4 pre, acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < LS; ++e)
+        pre[e] = q0 + e < a.Q ? grow[(size_t)(q0 + e) * a.q_stride + (size_t)ts * a.step_stride] : 0.f;
+#pragma unroll 8
+      for (int kk = 0; kk < H; ++kk) acc += wt[(size_t)kk * G] * hbuf[kk];
+      if (KIND == 2 && g >= 2 * H) {
+        abuf[g] = acc + bn;
+        xbuf[g - 2 * H] = pre;
+      } else {
+        abuf[g] = acc + pre;
+      }
+    }
+    __syncthreads();
+    if (g < H * LS) {
+      const float* ab = reinterpret_cast<const float*>(abuf);
+      if constexpr (KIND == 2) {
+        const float r = sigmoidf_(ab[j * LS + i]);
+        const float z = sigmoidf_(ab[(H + j) * LS + i]);
+        const float nn = tanhf(reinterpret_cast<const float*>(xbuf)[j * LS + i] + r * ab[(2 * H + j) * LS + i]);
+        h = (1.f - z) * nn + z * h;
+      } else {
+        h = tanhf(ab[j * LS + i]);
+      }
+      reinterpret_cast<float*>(hbuf)[j * LS + i] = h;
+      if (cell) hrow[(size_t)(q0 + i) * a.q_stride + (size_t)ts * a.step_stride] = h;
+    }
+    __syncthreads();
+  }
+  if (cell && a.h_last) a.h_last[((size_t)n * DH + d * H + j) * a.ldq + q0 + i] = h;
+}
+
 // ---- MFMA recurrence for H = 64 / 128 ----------------------------------------------------------------------------
 // One workgroup owns 16 sequences (flat index b = n*Q + q, so a group may span two utterances) and H/16 waves; wave
 // w owns hidden units [16w, 16w+16) and ALL FOUR gates of them, so the cell update needs no exchange:
@@ -1199,6 +1262,42 @@ extern "C" int ps_lstm_fmajor_f16x2_f32(const ps_lstm_args* args, int ldm, void*
     return (int)e;
   }
   return 0;
+}
+
+extern "C" int ps_rnn_f32(const ps_lstm_args* args, int kind, const float* bhn, void* stream) {
+  if (!args || (kind != PS_RNN_TANH && kind != PS_RNN_GRU)) {
+    set_error("ps_rnn_f32: null args or unknown cell kind %d", kind);
+    return PS_E_INVALID;
+  }
+  const ps_lstm_args& a = *args;
+  const int ng = kind == PS_RNN_GRU ? 3 : 1;
+  if (!a.gx || !a.whh_t || !a.hout || a.c0 || a.c_last || a.N <= 0 || a.H <= 0 || a.D < 1 || a.D > 2 || a.Q <= 0 || a.steps <= 0 ||
+      a.q_stride < 0 || a.step_stride < 0 || a.ldt <= 0 || a.N > 65535 || a.state_shift != 0 || (kind == PS_RNN_GRU && !bhn)) {
+    set_error("ps_rnn_f32: bad argument (N=%d H=%d D=%d Q=%d steps=%d; no cell states, the GRU needs bhn)", a.N, a.H, a.D, a.Q, a.steps);
+    return PS_E_INVALID;
+  }
+  if (ng * a.H > 1024 || a.H * LS > 1024) {
+    set_error("ps_rnn_f32: hidden size %d is not supported (GRU: <= 256, RNN: <= 256)", a.H);
+    return PS_E_UNSUPPORTED;
+  }
+  if ((long long)(a.Q - 1) * a.q_stride + (long long)(a.steps - 1) * a.step_stride >= a.ldt ||
+      ((a.h0 || a.h_last) && a.ldq < a.Q)) {
+    set_error("ps_rnn_f32: a frame lies outside the row (ldt=%d) or ldq=%d < Q=%d", a.ldt, a.ldq, a.Q);
+    return PS_E_INVALID;
+  }
+  LstmK k{a};
+  const int rows = ng * a.H > a.H * LS ? ng * a.H : a.H * LS;
+  const int threads = (rows + 63) / 64 * 64;
+  const size_t lds = (size_t)(a.H + ng * a.H + a.H) * sizeof(f32x4);
+  dim3 grid((a.Q + LS - 1) / LS, a.N, a.D);
+  {
+    LaunchTimer timer("lstm", (hipStream_t)stream);
+    if (kind == PS_RNN_GRU)
+      hipLaunchKernelGGL((rnn_kernel<2>), grid, dim3(threads), lds, (hipStream_t)stream, k, bhn);
+    else
+      hipLaunchKernelGGL((rnn_kernel<0>), grid, dim3(threads), lds, (hipStream_t)stream, k, bhn);
+  }
+  return launch_status("ps_rnn_f32");
 }
 
 extern "C" int ps_lstm_f32(const ps_lstm_args* args, void* stream) { return lstm_launch(args, stream, false); }

@@ -430,6 +430,27 @@ def lstm(gx: torch.Tensor, whh_t: torch.Tensor, hidden: int, dirs: int, q: int, 
     return (hout, (h_last, c_last)) if h_last is not None else (hout, None)
 
 
+RNN_KINDS = {"RNN": 0, "GRU": 2}
+
+
+def rnn(gx: torch.Tensor, whh_t: torch.Tensor, kind: str, hidden: int, dirs: int, q: int, q_stride: int, steps: int,
+        step_stride: int, bhn: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ps_rnn_f32: the recurrence of nn.RNN (tanh) / nn.GRU over pre-activations gx padded [N, D*G, ldt] (G = H or 3H) ->
+    hout [N, D*H, ldt]; zero initial state."""
+    require_device(gx, "rnn")
+    n, rows, ldt = gx.shape
+    g = (3 if kind == "GRU" else 1) * hidden
+    if kind not in RNN_KINDS or rows != dirs * g or tuple(whh_t.shape) != (dirs, hidden, g):
+        raise RuntimeError("rnn: kind RNN / GRU, gx [N, D*G, ldt], whh_t [D, H, G]")
+    hout = torch.empty(n, dirs * hidden, ldt, dtype=torch.float32, device=gx.device)
+    a = LstmArgs()
+    a.gx, a.whh_t, a.hout = ptr(gx), ptr(whh_t), ptr(hout)
+    a.N, a.H, a.D, a.Q, a.q_stride, a.steps, a.step_stride = n, hidden, dirs, q, q_stride, steps, step_stride
+    a.ldt, a.ldq, a.state_shift = ldt, 0, 0
+    check(lib().ps_rnn_f32(C.byref(a), RNN_KINDS[kind], ptr(bhn), stream_ptr(gx.device)), "ps_rnn_f32")
+    return hout
+
+
 def _lstm_fmajor_args(gx_fm: torch.Tensor, whh_t: torch.Tensor, hout, hidden, dirs, q, q_stride, steps, step_stride):
     n, ldt, rows = gx_fm.shape
     a = LstmArgs()

@@ -97,6 +97,31 @@ def lstm_plan(lstm: nn.LSTM, device, gemm: str = "fp32") -> dict:
                 planes=_PLANES[gemm])
 
 
+def rnn_plan(rnn: nn.Module, device) -> dict:
+    """nn.GRU / nn.RNN(tanh; num_layers=1, batch_first=True) for ps_rnn_f32: input projection rows stacked over directions,
+    b_hh folded into the projection's bias except the GRU's n gate (its hidden bias sits inside the reset product: bhn)."""
+    kind = "GRU" if isinstance(rnn, nn.GRU) else "RNN"
+    if kind == "RNN" and getattr(rnn, "nonlinearity", "tanh") != "tanh":
+        raise NotImplementedError("nn.RNN on HIP: tanh cells (the reference's SingleRNN builds no other)")
+    if rnn.num_layers != 1 or not rnn.batch_first:
+        raise NotImplementedError("HIP recurrences: one layer, batch_first")
+    hid, ng = rnn.hidden_size, (3 if kind == "GRU" else 1)
+    wih, bias, whh, bhn = [], [], [], []
+    for suf in ([""] if not rnn.bidirectional else ["", "_reverse"]):
+        b_hh = _f32(getattr(rnn, "bias_hh_l0" + suf), device)
+        fold = b_hh.clone()
+        if kind == "GRU":
+            fold[2 * hid:] = 0.0
+            bhn.append(b_hh[2 * hid:].clone())
+        wih.append(_f32(getattr(rnn, "weight_ih_l0" + suf), device))
+        bias.append(_f32(getattr(rnn, "bias_ih_l0" + suf), device) + fold)
+        whh.append(_f32(getattr(rnn, "weight_hh_l0" + suf), device).t().contiguous())
+    rows = torch.cat(wih, 0).contiguous()
+    return dict(kind=kind, wih=hip.pack_wt(rows), rows=rows.shape[0], bias=torch.cat(bias).contiguous(),
+                whh_t=torch.stack(whh).contiguous(), bhn=torch.stack(bhn).contiguous() if bhn else None, H=hid,
+                D=2 if rnn.bidirectional else 1, I=rnn.input_size)
+
+
 def linear_plan(lin: nn.Module, device) -> dict:
     """nn.Linear or nn.Conv1d(k=1)."""
     w = lin.weight

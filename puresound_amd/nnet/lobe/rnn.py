@@ -1,4 +1,4 @@
-"""Recurrent lobes (mirror of puresound/nnet/lobe/rnn.py:9-55): SingleRNN holds an nn.LSTM and its projection under
+"""Recurrent lobes (mirror of puresound/nnet/lobe/rnn.py:9-55): SingleRNN holds an nn.LSTM (or nn.GRU / nn.RNN) and its projection under
 the reference's keys (`rnn.*`, `proj.*`).  The dual-path blocks of DPCRN / DPARN drive its LSTM through ps_lstm_f32
 with their own strided walks; as a layer of its own (the speaker net of tse_skim_v1_causal, egs/tse/model.py:487-495)
 it runs one sequence per utterance over the frame axis: input projection GEMM, ps_lstm_f32, output projection GEMM."""
@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from ... import hip
 from ...ops import op_module, same_shape
-from .._plans import PlanCache, linear_plan, lstm_plan
+from .._plans import PlanCache, linear_plan, lstm_plan, rnn_plan
 
 
 @op_module("single_rnn_fwd", same_shape)
@@ -26,10 +26,10 @@ class SingleRNN(PlanCache, nn.Module):
         self.proj = nn.Linear(hidden_size * self.num_direction, input_size)
 
     def _build(self, device):
-        if self.rnn_type != "LSTM":
-            raise NotImplementedError("SingleRNN on HIP: LSTM cells only (every recipe's setting)")
         if self.training and self.drop.p > 0:
             raise RuntimeError("SingleRNN: dropout is active; the HIP path is inference only -- call .eval()")
+        if self.rnn_type != "LSTM":   # GRU / RNN: the plain kernel (ps_rnn_f32): no recipe builds them
+            return dict(rnn=rnn_plan(self.rnn, device), proj=linear_plan(self.proj, device))
         return dict(rnn=lstm_plan(self.rnn, device, self.gemm_precision), proj=linear_plan(self.proj, device))
 
     def forward_padded(self, x: torch.Tensor, t: int) -> torch.Tensor:
@@ -37,6 +37,13 @@ class SingleRNN(PlanCache, nn.Module):
         p = self._plan_get(x.device, self._build)
         rnn, proj = p["rnn"], p["proj"]
         n, _, ldt = x.shape
+        if self.rnn_type != "LSTM":
+            gx, _ = hip.conv1x1(x, t, rnn["wih"], rnn["rows"], None, rnn["bias"],
+                                out=torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=x.device))
+            hseq = hip.rnn(gx, rnn["whh_t"], rnn["kind"], rnn["H"], rnn["D"], 1, ldt, t, 1, rnn["bhn"])
+            y, _ = hip.conv1x1(hseq, t, proj["wt"], proj["M"], None, proj["bias"],
+                               out=torch.empty(n, proj["M"], ldt, dtype=torch.float32, device=x.device))
+            return y
         if (rnn["planes"] == 2 and rnn["I"] >= 64 and rnn["H"] in (256, 192)
                 and hip.lstm_fmajor_h256_ok(n, ldt, rnn["D"], 1, ldt, t, 1)
                 and hip.conv1x1_f16x2_fmajor_ok(n, rnn["I"], rnn["rows"], t, ldt)):

@@ -339,6 +339,11 @@ CASES = {
                                      kernel_t=(2, 2, 2), kernel_f=(5, 3, 3), stride_t=(1, 1, 1), stride_f=(2, 2, 1),
                                      dilation_t=(1, 1, 1), dilation_f=(1, 1, 1), delay=(0, 0, 0), multi_output=3,
                                      rnn_hidden=10, nhead=1, dropout=0.0), B=2, T=19, seed=58),
+    # lobe/rnn.py:9-55 on its own: the three cell types the constructor accepts
+    "srnn_lstm_bi": dict(kind="single_rnn", args=("LSTM", 12, 20), kw=dict(bidirectional=True), B=3, T=37, seed=71),
+    "srnn_gru": dict(kind="single_rnn", args=("GRU", 12, 20), kw=dict(bidirectional=False), B=5, T=37, seed=72),
+    "srnn_gru_bi": dict(kind="single_rnn", args=("gru", 10, 64), kw=dict(bidirectional=True), B=2, T=50, seed=73),
+    "srnn_rnn_bi": dict(kind="single_rnn", args=("RNN", 12, 33), kw=dict(bidirectional=True), B=3, T=21, seed=74),
     "enc_free": dict(kind="encdec", enc=dict(kind="free", win=32, hop=16, C=20), B=3, L=500, seed=16),
     "enc_free_relu_ragged": dict(kind="encdec", enc=dict(kind="free", win=20, hop=6, C=9, relu=True),
                                  B=2, L=211, seed=17),
@@ -453,6 +458,8 @@ def build(ns, name):
         return build_encoder(ns, c["enc"])
     if c["kind"] in ("rnn", "lobe", "atten"):
         return getattr(ns, c["cls"])(*c["args"], **c["kw"])
+    if c["kind"] == "single_rnn":
+        return ns.SingleRNN(*c["args"], **c["kw"])
     if c["kind"] == "unet":
         return getattr(ns, c["cls"])(**c["kw"])
     if c["kind"] == "fbank":

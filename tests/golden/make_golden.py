@@ -186,6 +186,15 @@ def run_atten(name, c):
 
 
 @torch.no_grad()
+def run_single_rnn(name, c):
+    """SingleRNN on its own: x [B, C, T] -> proj(rnn(x)) (lobe/rnn.py:37-55)"""
+    model = cases.build(REF, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    x = _uniform(c["seed"], (c["B"], c["args"][1], c["T"]))
+    return {"x": x.numpy(), "y": model(x.clone()).numpy()}
+
+
+@torch.no_grad()
 def run_rnn(name, c):
     """DPRNN / SkiM at module level: x [B,C,T] (+ embedding vector or enrolment features)."""
     model = cases.build(REF, name).eval()
@@ -341,7 +350,7 @@ def main():
     dump_state_dict_keys()
     for name, c in cases.CASES.items():
         fn = {"wrap": run_wrap, "masker": run_masker, "encdec": run_encdec, "rnn": run_rnn,
-              "lobe": run_lobe, "atten": run_atten, "stream": run_stream, "unet": run_unet, "fbank": run_fbank, "loss": run_loss, "simo": run_simo, "func": run_func}[c["kind"]]
+              "lobe": run_lobe, "atten": run_atten, "single_rnn": run_single_rnn, "stream": run_stream, "unet": run_unet, "fbank": run_fbank, "loss": run_loss, "simo": run_simo, "func": run_func}[c["kind"]]
         if only and name not in only:
             continue
         out = fn(name, c)

@@ -342,3 +342,15 @@ def test_mha_self_atten_layer_matches_reference(golden_dir, name):
                                 kw["improved"], kw.get("bidirectional", False))
     assert y.shape == g["y"].shape
     assert rel_max(y.numpy(), g["y"]) < TOL
+
+
+@pytest.mark.parametrize("name", [n for n, c in cases.CASES.items() if c["kind"] == "single_rnn"])
+def test_single_rnn_matches_reference(golden_dir, name):
+    """SingleRNN on its own (lobe/rnn.py:9-55) with each cell type its constructor accepts: LSTM, GRU, RNN."""
+    from oracle import unet_oracle as UO
+    c = cases.CASES[name]
+    g = _load(golden_dir, name)
+    sd = {k: v.double() for k, v in det_state_dict(cases.build(PA.NS, name)).items()}
+    y = UO.single_rnn(torch.tensor(g["x"]).double(), sd, "", c["kw"]["bidirectional"], c["args"][0].upper())
+    assert y.shape == g["y"].shape
+    assert rel_max(y.numpy(), g["y"]) < TOL

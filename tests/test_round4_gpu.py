@@ -420,3 +420,16 @@ def test_conv2d_f16x2_kernel(H, dev, transposed, m, c1, c2, amp):
     tot = stats.sum(dim=1).cpu()
     assert torch.allclose(tot[:, 0], pre.sum(dim=(1, 2, 3)), rtol=1e-5, atol=1e-3 * float(pre.abs().max()))
     assert torch.allclose(tot[:, 1], (pre ** 2).sum(dim=(1, 2, 3)), rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", [n for n, c in cases.CASES.items() if c["kind"] == "single_rnn"])
+def test_single_rnn_cells_match_reference_golden(PA, dev, name):
+    """SingleRNN(rnn_type = LSTM | GRU | RNN) on its own against the reference's output (ps_rnn_f32 for the GRU / Elman cells)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    y = model(torch.tensor(g["x"]).to(dev))
+    assert y.shape == g["y"].shape
+    assert rel_max(y.cpu().numpy(), g["y"]) < 1e-4
