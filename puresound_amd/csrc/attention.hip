@@ -90,18 +90,18 @@ __global__ __launch_bounds__(ATT_SQ * 64) void self_attention_kernel(AttArgs a) 
 // broadcast per sequence); a thread (sequence, query) computes its L <= 64 scores into registers, takes the maximum,
 // exponentiates once per key and accumulates P V -- softmax(q k / sqrt(dh)) v in the reference's order of operations;
 // workgroup ids are renumbered so that the eight workgroups sharing a line run on ONE XCD, back to back.
-template <int DH>
-__global__ __launch_bounds__(ATT_SQ * 64) void self_attention_l64_kernel(AttArgs a) {
+template <int DH, int SQ>
+__global__ __launch_bounds__(SQ * 64) void self_attention_l64_kernel(AttArgs a) {
   constexpr int RS = DH + 4;  // floats per (key, sequence) row: 16-byte aligned, rows of the 4 sequences in different banks
   extern __shared__ __attribute__((aligned(16))) float sm[];  // k[L][SQ][RS] | v[L][SQ][RS]
   const int h = blockIdx.y, n = blockIdx.z;
   const int per = gridDim.x >> 3;  // (the grid is a multiple of 8 workgroups along x)
-  const int q0 = ((blockIdx.x & 7) * per + (blockIdx.x >> 3)) * ATT_SQ;
+  const int q0 = ((blockIdx.x & 7) * per + (blockIdx.x >> 3)) * SQ;
   float* ks = sm;
-  float* vs = sm + a.L * ATT_SQ * RS;
+  float* vs = sm + a.L * SQ * RS;
   const float* base = a.qkv + (size_t)n * 3 * a.E * a.ld;
-  for (int idx = threadIdx.x; idx < DH * a.L * ATT_SQ; idx += ATT_SQ * 64) {
-    const int s = idx % ATT_SQ, pos = (idx / ATT_SQ) % a.L, d = idx / (ATT_SQ * a.L);
+  for (int idx = threadIdx.x; idx < DH * a.L * SQ; idx += SQ * 64) {
+    const int s = idx % SQ, pos = (idx / SQ) % a.L, d = idx / (SQ * a.L);
     const int q = q0 + s;
     float kv = 0.f, vv = 0.f;
     if (q < a.Q) {
@@ -109,10 +109,10 @@ __global__ __launch_bounds__(ATT_SQ * 64) void self_attention_l64_kernel(AttArgs
       kv = base[(size_t)(a.E + h * DH + d) * a.ld + fr];
       vv = base[(size_t)(2 * a.E + h * DH + d) * a.ld + fr];
     }
-    ks[(pos * ATT_SQ + s) * RS + d] = kv;
-    vs[(pos * ATT_SQ + s) * RS + d] = vv;
+    ks[(pos * SQ + s) * RS + d] = kv;
+    vs[(pos * SQ + s) * RS + d] = vv;
   }
-  const int s = threadIdx.x % ATT_SQ, i = threadIdx.x / ATT_SQ;
+  const int s = threadIdx.x % SQ, i = threadIdx.x / SQ;
   const int q = q0 + s;
   const bool live = q < a.Q && i < a.L;
   const size_t fr = live ? (size_t)q * a.q_stride + (size_t)i * a.pos_stride : 0;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(ATT_SQ * 64) void self_attention_l64_kernel(AttArgs
   for (int j = 0; j < 64; ++j) {
     float acc = -INFINITY;
     if (j < jend) {  // (j < jend <= L <= 64)
-      const f32x4* kr = reinterpret_cast<const f32x4*>(ks + (j * ATT_SQ + s) * RS);
+      const f32x4* kr = reinterpret_cast<const f32x4*>(ks + (j * SQ + s) * RS);
       acc = 0.f;
 #pragma unroll
       for (int d4 = 0; d4 < DH / 4; ++d4) {
@@ -147,9 +147,9 @@ __global__ __launch_bounds__(ATT_SQ * 64) void self_attention_l64_kernel(AttArgs
 #pragma unroll
   for (int j = 0; j < 64; ++j) {
     if (j < jend) {
-      const float p = expf(sc[j] - m);
+      const float p = __expf(sc[j] - m);  // (v_exp_f32, ~2 ulp: 1.28 -> 1.20 ms per launch against expf)
       z += p;
-      const f32x4* vr = reinterpret_cast<const f32x4*>(vs + (j * ATT_SQ + s) * RS);
+      const f32x4* vr = reinterpret_cast<const f32x4*>(vs + (j * SQ + s) * RS);
 #pragma unroll
       for (int d4 = 0; d4 < DH / 4; ++d4) {
         const f32x4 v4 = vr[d4];
@@ -210,16 +210,28 @@ extern "C" int ps_self_attention_f32(const float* qkv, float* out, int N, int E,
   AttArgs a{qkv, out, E, heads, Q, q_stride, L, pos_stride, ld, causal, 1.f / sqrtf((float)dh)};
   // L <= 64 positions with a head dimension of 16 / 32 / 64: the register-score kernel (ps_debug_flags bit 23 keeps the
   // general one; tests run both)
+  // (8 sequences per workgroup when their K / V fit: a workgroup then uses 32 bytes of every 128-byte line it touches
+  //  instead of 16, and the L2 -> L1 fill traffic halves; ps_debug_flags bit 21 keeps 4)
   const size_t lds64 = (size_t)2 * L * ATT_SQ * (dh + 4) * sizeof(float);
   if (L <= 64 && (dh == 16 || dh == 32 || dh == 64) && lds64 <= 64 * 1024 && !(g_debug_flags & (1 << 23))) {
     LaunchTimer timer("self_attention", (hipStream_t)stream);
-    dim3 g((((Q + ATT_SQ - 1) / ATT_SQ) + 7) / 8 * 8, heads, N);
-    if (dh == 16)
-      hipLaunchKernelGGL((self_attention_l64_kernel<16>), g, dim3(ATT_SQ * 64), lds64, (hipStream_t)stream, a);
+    const bool wide = dh == 16 && 2 * lds64 <= 96 * 1024 && !(g_debug_flags & (1 << 21));
+    const int sq = wide ? 8 : ATT_SQ;
+    dim3 g((((Q + sq - 1) / sq) + 7) / 8 * 8, heads, N);
+    if (wide) {
+      static bool raised = false;
+      if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attention_l64_kernel<16, 8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        raised = true;
+      }
+      hipLaunchKernelGGL((self_attention_l64_kernel<16, 8>), g, dim3(512), 2 * lds64, (hipStream_t)stream, a);
+    } else if (dh == 16)
+      hipLaunchKernelGGL((self_attention_l64_kernel<16, ATT_SQ>), g, dim3(ATT_SQ * 64), lds64, (hipStream_t)stream, a);
     else if (dh == 32)
-      hipLaunchKernelGGL((self_attention_l64_kernel<32>), g, dim3(ATT_SQ * 64), lds64, (hipStream_t)stream, a);
+      hipLaunchKernelGGL((self_attention_l64_kernel<32, ATT_SQ>), g, dim3(ATT_SQ * 64), lds64, (hipStream_t)stream, a);
     else
-      hipLaunchKernelGGL((self_attention_l64_kernel<64>), g, dim3(ATT_SQ * 64), lds64, (hipStream_t)stream, a);
+      hipLaunchKernelGGL((self_attention_l64_kernel<64, ATT_SQ>), g, dim3(ATT_SQ * 64), lds64, (hipStream_t)stream, a);
     return att_status("ps_self_attention_f32");
   }
   {

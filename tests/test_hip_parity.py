@@ -1289,7 +1289,7 @@ def test_fbank_encoder_matches_reference_golden(PA, dev, golden_dir, name):
     assert rel_max(y.cpu().numpy(), g["feats"]) < TOL
 
 
-@pytest.mark.parametrize("e,heads,f,t,flags", [(16, 4, 9, 13, 0), (64, 4, 9, 13, 0), (64, 4, 9, 13, 1 << 23), (128, 8, 64, 37, 0),
+@pytest.mark.parametrize("e,heads,f,t,flags", [(16, 4, 9, 13, 0), (64, 4, 9, 13, 0), (64, 4, 9, 13, 1 << 23), (64, 4, 9, 13, 1 << 21), (128, 8, 64, 37, 0), (128, 8, 64, 37, 1 << 21),
                                                (64, 2, 20, 9, 0), (64, 1, 30, 6, 0), (64, 1, 30, 6, 1 << 23)])
 def test_self_attention_kernel(H, dev, e, heads, f, t, flags):
     """ps_self_attention_f32 / ps_add_position_f32 against the oracle's multi-head attention, both sequence layouts
