@@ -197,18 +197,20 @@ def single_rnn(x: torch.Tensor, sd: SD, p: str, bidirectional: bool, kind: str =
     return linear(y, sd[p + "proj.weight"], sd[p + "proj.bias"]).transpose(1, 2)
 
 
-def dprnn_block2d(x: torch.Tensor, sd: SD, p: str) -> torch.Tensor:
+def dprnn_block2d(x: torch.Tensor, sd: SD, p: str, intra_skip: bool = True, inter_skip: bool = True) -> torch.Tensor:
     """DPRNNblock2D.forward (dpcrn.py:34-81): bidirectional LSTM along frequency per frame, LayerNorm over channels,
-    skip; unidirectional LSTM along time per frequency bin, LayerNorm, skip."""
+    skip; unidirectional LSTM along time per frequency bin, LayerNorm, skip (each skip under its flag, dpcrn.py:62-63, 78-79)."""
     n, ch, c, t = x.shape
     y = x.transpose(1, -1).reshape(n * t, c, ch)                       # [N*T, C, CH]
     y = single_rnn(y.permute(0, 2, 1), sd, p + "intra_rnn.", True).permute(0, 2, 1)
     y = layer_norm(y, sd[p + "intra_norm.weight"], sd[p + "intra_norm.bias"])
-    x = x + y.reshape(n, t, c, ch).transpose(1, -1)
+    y = y.reshape(n, t, c, ch).transpose(1, -1)
+    x = x + y if intra_skip else y
     y = x.permute(0, 2, 3, 1).reshape(n * c, t, ch)                    # [N*C, T, CH]
     y = single_rnn(y.permute(0, 2, 1), sd, p + "inter_rnn.", False).permute(0, 2, 1)
     y = layer_norm(y, sd[p + "inter_norm.weight"], sd[p + "inter_norm.bias"])
-    return x + y.permute(0, 2, 1).reshape(n, c, ch, t).permute(0, 2, 1, 3)
+    y = y.permute(0, 2, 1).reshape(n, c, ch, t).permute(0, 2, 1, 3)
+    return x + y if inter_skip else y
 
 
 def dpcrn(x: torch.Tensor, sd: SD, p: str, args: dict) -> torch.Tensor:
@@ -272,20 +274,22 @@ def mha_self_atten_layer(x: torch.Tensor, sd: SD, p: str, heads: int, position_e
     return layer_norm(y + ff, sd[p + "norm2.weight"], sd[p + "norm2.bias"]).transpose(1, 2)
 
 
-def dparn_block2d(x: torch.Tensor, sd: SD, p: str, heads: int) -> torch.Tensor:
+def dparn_block2d(x: torch.Tensor, sd: SD, p: str, heads: int, intra_skip: bool = True, inter_skip: bool = True) -> torch.Tensor:
     """DPARNblock2D.forward (dparn.py:55-108): two self-attention layers along frequency per frame, Linear,
-    LayerNorm, skip; then the unidirectional LSTM along time of the DPCRN block."""
+    LayerNorm, skip; then the unidirectional LSTM along time of the DPCRN block (each skip under its flag)."""
     n, ch, c, t = x.shape
     y = x.transpose(1, -1).reshape(n * t, c, ch).permute(0, 2, 1)       # [N*T, CH, C]
     y = mha_self_atten_layer(y, sd, p + "intra_atten1.", heads, True)
     y = mha_self_atten_layer(y, sd, p + "intra_atten2.", heads, False)
     y = linear(y.permute(0, 2, 1), sd[p + "intra_fc.weight"], sd[p + "intra_fc.bias"])
     y = layer_norm(y, sd[p + "intra_norm.weight"], sd[p + "intra_norm.bias"])
-    x = x + y.reshape(n, t, c, ch).transpose(1, -1)
+    y = y.reshape(n, t, c, ch).transpose(1, -1)
+    x = x + y if intra_skip else y
     y = x.permute(0, 2, 3, 1).reshape(n * c, t, ch)
     y = single_rnn(y.permute(0, 2, 1), sd, p + "inter_rnn.", False).permute(0, 2, 1)
     y = layer_norm(y, sd[p + "inter_norm.weight"], sd[p + "inter_norm.bias"])
-    return x + y.permute(0, 2, 1).reshape(n, c, ch, t).permute(0, 2, 1, 3)
+    y = y.permute(0, 2, 1).reshape(n, c, ch, t).permute(0, 2, 1, 3)
+    return x + y if inter_skip else y
 
 
 def dparn(x: torch.Tensor, sd: SD, p: str, args: dict) -> torch.Tensor:

@@ -140,8 +140,9 @@ def layernorm_plan(ln: nn.Module, device) -> dict:
     return dict(gamma=_f32(ln.gamma, device), beta=_f32(ln.beta, device), eps=float(ln.eps))
 
 
-def _proj_norm(x, hseq, t, rnn, proj, norm, amax):
-    """x + LN(proj(h)) behind a recurrence (second half of lstm_path)."""
+def _proj_norm(x, hseq, t, rnn, proj, norm, amax, skip=True):
+    """x + LN(proj(h)) behind a recurrence (second half of lstm_path); skip=False: LN(proj(h)) alone."""
+    res = x if skip else None
     n, _, ldt = x.shape
     dev = x.device
     # the fused projection + LayerNorm kernel is the short-row kernel (16-frame workgroups): on long rows (the 2-D
@@ -150,11 +151,11 @@ def _proj_norm(x, hseq, t, rnn, proj, norm, amax):
         if amax is not None and rnn["planes"] == 2 and t >= 128:
             try:   # the row kernel hands the next GEMM its input range for free
                 y, _, amax[0] = hip.proj_layernorm(hseq, t, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"],
-                                                   norm["eps"], x, want_amax=True)
+                                                   norm["eps"], res, want_amax=True)
                 return y
             except RuntimeError:
                 amax[0] = None
-        y, _ = hip.proj_layernorm(hseq, t, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"], norm["eps"], x)
+        y, _ = hip.proj_layernorm(hseq, t, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"], norm["eps"], res)
         return y
     if (FUSE_GEMM_LN and rnn["planes"] == 2 and proj["M"] == 128 and proj["K"] % 32 == 0
             and hip.conv1x1_f16x2_ln_ok(n, proj["K"], 128, t)):
@@ -165,10 +166,10 @@ def _proj_norm(x, hseq, t, rnn, proj, norm, amax):
             proj["f16x2_ln"] = hip.pack_wt_f16x2(w256)
         wf, we = proj["f16x2_ln"]
         if amax is not None:   # the maxima of |y| ride along: the next recurrence's GEMM needs no pass of its own over y
-            y, amax[0] = hip.conv1x1_f16x2_ln(hseq, t, wf, we, 128, proj["bias"], norm["gamma"], norm["beta"], norm["eps"], x,
+            y, amax[0] = hip.conv1x1_f16x2_ln(hseq, t, wf, we, 128, proj["bias"], norm["gamma"], norm["beta"], norm["eps"], res,
                                               x_bound=1.0, want_amax=True)
             return y
-        return hip.conv1x1_f16x2_ln(hseq, t, wf, we, 128, proj["bias"], norm["gamma"], norm["beta"], norm["eps"], x, x_bound=1.0)
+        return hip.conv1x1_f16x2_ln(hseq, t, wf, we, 128, proj["bias"], norm["gamma"], norm["beta"], norm["eps"], res, x_bound=1.0)
     p = torch.empty(n, proj["M"], ldt, dtype=torch.float32, device=dev)
     if rnn["planes"] == 2 and proj["K"] >= 64:
         # the recurrence's arithmetic for its projection too: h is an LSTM output, |h| < 1 is its range
@@ -177,7 +178,7 @@ def _proj_norm(x, hseq, t, rnn, proj, norm, amax):
         hip.conv1x1_f16x2(hseq, t, proj["f16x2"][0], proj["f16x2"][1], proj["M"], None, proj["bias"], out=p, x_bound=1.0)
     else:
         hip.conv1x1(hseq, t, proj["wt"], proj["M"], None, proj["bias"], out=p)
-    return hip.chan_layernorm(p, t, norm["gamma"], norm["beta"], norm["eps"], res=x)
+    return hip.chan_layernorm(p, t, norm["gamma"], norm["beta"], norm["eps"], res=res)
 
 
 def _h_rows(rnn: dict, x: torch.Tensor, t: int, q: int, steps: int):
@@ -199,7 +200,7 @@ def _h_rows(rnn: dict, x: torch.Tensor, t: int, q: int, steps: int):
 
 def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int, q_stride: int, steps: int,
               step_stride: int, h0=None, c0=None, want_state: bool = False, state_shift: int = 0, state_out=None,
-              amax: Optional[list] = None):
+              amax: Optional[list] = None, skip: bool = True):
     """x + LN(proj(LSTM(x))) on padded [N,C,ldt] (dprnn.py:154-172, skim.py:215-227) -> (x', final states).
     `amax`: a one-element list carried from recurrence to recurrence in the fp16x2 arithmetic -- on entry the partial maxima
     of |x| per utterance (or None: measured here), on return those of x' (None when the kernel that made x' has none)."""
@@ -222,7 +223,7 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
                                              x_amax=x_amax if x_amax is not None else hip.absmax(x, t))
             hseq = hip.lstm_fmajor(gx_fm, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride,
                                    out=_h_rows(rnn, x, t, q, steps))
-            return _proj_norm(x, hseq, t, rnn, proj, norm, amax), None
+            return _proj_norm(x, hseq, t, rnn, proj, norm, amax, skip), None
         # H = 256 (SkiM's segment LSTMs): W_hh streamed from L2 in fragment order, states carried (ps_lstm_fmajor_h256_f16x2_f32)
         if (FMAJOR_LSTM and rnn["H"] in (256, 192) and hip.lstm_fmajor_h256_ok(n, ldt, rnn["D"], q, q_stride, steps, step_stride)
                 and hip.conv1x1_f16x2_fmajor_ok(n, rnn["I"], rnn["rows"], t, ldt)):
@@ -233,7 +234,7 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
             hseq, state = hip.lstm_fmajor_h256(gx_fm, rnn["whh_h256"][0], rnn["whh_h256"][1], rnn["D"], q, q_stride, steps,
                                                step_stride, h0, c0, want_state, state_shift, state_out,
                                                out=_h_rows(rnn, x, t, q, steps))
-            return _proj_norm(x, hseq, t, rnn, proj, norm, amax), state
+            return _proj_norm(x, hseq, t, rnn, proj, norm, amax, skip), state
         gx = torch.empty(n, rnn["rows"], ldt, dtype=torch.float32, device=dev)
         hip.conv1x1_f16x2(x, t, wf, we, rnn["rows"], None, rnn["bias"], out=gx,
                           x_amax=x_amax if x_amax is not None else hip.absmax(x, t))
@@ -248,4 +249,4 @@ def lstm_path(x: torch.Tensor, t: int, rnn: dict, proj: dict, norm: dict, q: int
         hip.conv1x1(x, t, rnn["wih"], rnn["rows"], None, rnn["bias"], out=gx)
     hseq, state = hip.lstm(gx, rnn["whh_t"], rnn["H"], rnn["D"], q, q_stride, steps, step_stride, h0, c0, want_state,
                            state_shift, state_out, f16x2=rnn["planes"] == 2, out=_h_rows(rnn, x, t, q, steps))
-    return _proj_norm(x, hseq, t, rnn, proj, norm, amax), state
+    return _proj_norm(x, hseq, t, rnn, proj, norm, amax, skip), state

@@ -35,7 +35,7 @@ class DPARNblock2D(PlanCache, nn.Module):
                     inter=(lstm_plan(self.inter_rnn.rnn, device, self.gemm_precision), linear_plan(self.inter_rnn.proj, device),
                            layernorm_plan(self.inter_norm, device)))
 
-    def forward_padded(self, x: torch.Tensor, t: int, amax=None) -> torch.Tensor:
+    def forward_padded(self, x: torch.Tensor, t: int, amax=None, intra_skip: bool = True, inter_skip: bool = True) -> torch.Tensor:
         """[N, CH, F, ld] -> [N, CH, F, ld].  amax: lstm_path's one-element list (fp16x2 arithmetic: the maxima of |x| travel
         from block to block)."""
         p = self._plan_get(x.device, self._build)
@@ -54,19 +54,18 @@ class DPARNblock2D(PlanCache, nn.Module):
                 w256[:ch] = p["fc"]["w_rows"]
                 p["fc"]["f16x2_ln"] = hip.pack_wt_f16x2(w256)
             wf, we = p["fc"]["f16x2_ln"]
-            y, amax[0] = hip.conv1x1_f16x2_ln(a, frames, wf, we, ch, p["fc"]["bias"], fn["gamma"], fn["beta"], fn["eps"], y,
-                                              x_bound=bound, want_amax=True)
+            y, amax[0] = hip.conv1x1_f16x2_ln(a, frames, wf, we, ch, p["fc"]["bias"], fn["gamma"], fn["beta"], fn["eps"],
+                                              y if intra_skip else None, x_bound=bound, want_amax=True)
         else:
-            y, _ = hip.proj_layernorm(a, frames, p["fc"]["wt"], p["fc"]["bias"], ch, fn["gamma"], fn["beta"], fn["eps"], y)
-        y, _ = lstm_path(y, frames, *p["inter"], q=f, q_stride=ld, steps=t, step_stride=1, amax=amax)
+            y, _ = hip.proj_layernorm(a, frames, p["fc"]["wt"], p["fc"]["bias"], ch, fn["gamma"], fn["beta"], fn["eps"],
+                                      y if intra_skip else None)
+        y, _ = lstm_path(y, frames, *p["inter"], q=f, q_stride=ld, steps=t, step_stride=1, amax=amax, skip=inter_skip)
         return y.view(n, ch, f, ld)
 
     def forward(self, x: torch.Tensor, intra_skip: bool = True, inter_skip: bool = True) -> torch.Tensor:
         hip.require_device(x, "DPARNblock2D.forward")
-        if not (intra_skip and inter_skip):
-            raise NotImplementedError("DPARNblock2D on HIP: both skip connections (the only mode DPARN uses)")
         n, ch, f, t = x.shape
-        y = self.forward_padded(hip.pad_rows(x.reshape(n, ch * f, t)).view(n, ch, f, -1), t)
+        y = self.forward_padded(hip.pad_rows(x.reshape(n, ch * f, t)).view(n, ch, f, -1), t, None, intra_skip, inter_skip)
         return hip.unpad_rows(y.reshape(n, ch * f, -1), t).view(n, ch, f, t)
 
 

@@ -34,7 +34,7 @@ class DPRNNblock2D(PlanCache, nn.Module):
                     inter=(lstm_plan(self.inter_rnn.rnn, device, self.gemm_precision), linear_plan(self.inter_rnn.proj, device),
                            layernorm_plan(self.inter_norm, device)))
 
-    def forward_padded(self, x: torch.Tensor, t: int, amax=None) -> torch.Tensor:
+    def forward_padded(self, x: torch.Tensor, t: int, amax=None, intra_skip: bool = True, inter_skip: bool = True) -> torch.Tensor:
         """[N, CH, F, ld] -> [N, CH, F, ld].  amax: the one-element list of lstm_path (fp16x2 arithmetic: the maxima of |x|
         travel from recurrence to recurrence and from block to block instead of being measured before every GEMM)."""
         p = self._plan_get(x.device, self._build)
@@ -42,16 +42,14 @@ class DPRNNblock2D(PlanCache, nn.Module):
         y = x.view(n, ch, f * ld)
         frames = (f - 1) * ld + t                      # frames of the flattened (f, t) axis that hold data
         amax = [None] if amax is None else amax
-        y, _ = lstm_path(y, frames, *p["intra"], q=t, q_stride=1, steps=f, step_stride=ld, amax=amax)
-        y, _ = lstm_path(y, frames, *p["inter"], q=f, q_stride=ld, steps=t, step_stride=1, amax=amax)
+        y, _ = lstm_path(y, frames, *p["intra"], q=t, q_stride=1, steps=f, step_stride=ld, amax=amax, skip=intra_skip)
+        y, _ = lstm_path(y, frames, *p["inter"], q=f, q_stride=ld, steps=t, step_stride=1, amax=amax, skip=inter_skip)
         return y.view(n, ch, f, ld)
 
     def forward(self, x: torch.Tensor, intra_skip: bool = True, inter_skip: bool = True) -> torch.Tensor:
         hip.require_device(x, "DPRNNblock2D.forward")
-        if not (intra_skip and inter_skip):
-            raise NotImplementedError("DPRNNblock2D on HIP: both skip connections (the only mode DPCRN uses)")
         n, ch, f, t = x.shape
-        y = self.forward_padded(hip.pad_rows(x.reshape(n, ch * f, t)).view(n, ch, f, -1), t)
+        y = self.forward_padded(hip.pad_rows(x.reshape(n, ch * f, t)).view(n, ch, f, -1), t, None, intra_skip, inter_skip)
         return hip.unpad_rows(y.reshape(n, ch * f, -1), t).view(n, ch, f, t)
 
 

@@ -433,3 +433,23 @@ def test_single_rnn_cells_match_reference_golden(PA, dev, name):
     y = model(torch.tensor(g["x"]).to(dev))
     assert y.shape == g["y"].shape
     assert rel_max(y.cpu().numpy(), g["y"]) < 1e-4
+
+
+@pytest.mark.parametrize("intra_skip,inter_skip", [(True, True), (False, True), (True, False), (False, False)])
+@pytest.mark.parametrize("kind", ["dpcrn", "dparn"])
+def test_dual_path_blocks_with_skip_flags(PA, dev, kind, intra_skip, inter_skip):
+    """DPRNNblock2D / DPARNblock2D.forward(x, intra_skip, inter_skip) (dpcrn.py:34-81, dparn.py:55-108) against the oracle's
+    restatement with the same flags (the oracle itself is pinned by the golden cases with both skips on)."""
+    from oracle import unet_oracle as UO
+    n, ch, f, t = 2, 16, 9, 21
+    blk = (PA.NS.DPRNNblock2D(input_size=ch, hidden_size=12) if kind == "dpcrn"
+           else PA.NS.DPARNblock2D(input_size=ch, hidden_size=12, nhead=2)).eval()
+    sd = det_state_dict(blk)
+    blk.load_state_dict(sd)
+    blk.to(dev)
+    x = _rand4((n, ch, f, t), 711)
+    sdd = {k: v.double() for k, v in sd.items()}
+    ref = (UO.dprnn_block2d(x.double(), sdd, "", intra_skip, inter_skip) if kind == "dpcrn"
+           else UO.dparn_block2d(x.double(), sdd, "", 2, intra_skip, inter_skip))
+    y = blk(x.to(dev), intra_skip, inter_skip)
+    assert rel_max(y.cpu().numpy(), ref.numpy()) < 1e-4
