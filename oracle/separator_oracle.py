@@ -234,7 +234,7 @@ def create_fourier_tables(n_fft: int):
 # ---------------------------------------------------------------------------
 # Conv-TasNet blocks
 # ---------------------------------------------------------------------------
-def ds_conv(x: torch.Tensor, sd: SD, p: str, kernel: int, dilation: int, causal: bool, norm: str) -> torch.Tensor:
+def ds_conv(x: torch.Tensor, sd: SD, p: str, kernel: int, dilation: int, causal: bool, norm: str, stride: int = 1) -> torch.Tensor:
     """DepthwiseSeparableConv1d.forward (lobe/cnn.py:84-106); the hid_channels transform (in_conv.*) and the skip
     connection (skip_conv.*) are taken when their parameters are in the state dict, as the module builds them."""
     padding = (kernel - 1) * dilation if causal else ((kernel - 1) // 2) * dilation
@@ -243,6 +243,8 @@ def ds_conv(x: torch.Tensor, sd: SD, p: str, kernel: int, dilation: int, causal:
         x = conv1x1(x, sd[p + "in_conv.0.weight"], sd[p + "in_conv.0.bias"])
         x = prelu(apply_norm(x, sd, p + "in_conv.1.", norm), sd[p + "in_conv.2.weight"])
     y = dilated_conv(x, sd[p + "depthwise.0.weight"], sd[p + "depthwise.0.bias"], dilation, padding)
+    if stride != 1:  # Conv1d(stride=s) = every s-th frame of the stride-1 result (cnn.py:62-71)
+        y = y[..., ::stride]
     y = prelu(apply_norm(y, sd, p + "depthwise.1.", norm), sd[p + "depthwise.2.weight"])
     y = conv1x1(y, sd[p + "pointwise.0.weight"], sd[p + "pointwise.0.bias"])
     y = prelu(apply_norm(y, sd, p + "pointwise.1.", norm), sd[p + "pointwise.2.weight"])

@@ -49,8 +49,12 @@ class DepthwiseSeparableConv1d(nn.Module):
         """x [N, C, T] -> [N, out_channels, T] (cnn.py:84-106): [in_conv] -> depthwise -> pointwise (each conv + norm +
         PReLU) [+ skip_conv(x)].  Causal: the reference pads both sides and cuts the tail, i.e. left padding only."""
         hip.require_device(x, "DepthwiseSeparableConv1d.forward")
-        if self.stride != 1:
-            raise NotImplementedError("DepthwiseSeparableConv1d on HIP: stride 1 only (every recipe's setting)")
+        if self.stride != 1 and self.causal:
+            raise NotImplementedError("DepthwiseSeparableConv1d on HIP: stride != 1 with causal=True (no recipe strides at all)")
+        if self.stride != 1 and self.skip:
+            # the reference adds skip_conv(x) of length T to a result of length ~T / stride: torch's broadcasting error
+            raise RuntimeError("The size of tensor a must match the size of tensor b at non-singleton dimension 2 "
+                               "(DepthwiseSeparableConv1d: skip=True needs stride=1)")
         if not self.causal and self.kernel % 2 == 0:
             raise RuntimeError("DepthwiseSeparableConv1d: an even kernel with symmetric padding changes the length")
         with torch.no_grad():
@@ -91,7 +95,15 @@ class DepthwiseSeparableConv1d(nn.Module):
                 a, pro = settle(y, st, nk, slope, h)
             conv, nk, slope = parts(self.depthwise)
             y, st = hip.dwconv(a, t, conv.weight.detach().to(**f32).contiguous(), conv.bias.detach().to(**f32).contiguous(),
-                               self.dilation, self.padding, pro, nk[0] == PS_NORM_GLOBAL)
+                               self.dilation, self.padding, pro, nk[0] == PS_NORM_GLOBAL and self.stride == 1)
+            if self.stride != 1:
+                # Conv1d(stride=s) is every s-th frame of the stride-1 result (cnn.py:62-71): the stride-1 kernel, a strided
+                # copy (no recipe takes this path), the norm's statistics over the frames that remain
+                lf = t + 2 * self.padding - self.dilation * (self.kernel - 1)      # stride-1 output length
+                y = hip.pad_rows(y[..., :lf][..., ::self.stride].contiguous())
+                t = (lf + self.stride - 1) // self.stride
+                ldt = y.shape[-1]
+                st = hip.row_stats(y, t) if nk[0] == PS_NORM_GLOBAL else None
             a, pro = settle(y, st, nk, slope, h)
             conv, nk, slope = parts(self.pointwise)
             m = conv.out_channels

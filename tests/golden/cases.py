@@ -253,6 +253,10 @@ CASES = {
                           B=3, T=50, seed=63, bn_stats=True),
     "dsc_causal_cln": dict(kind="lobe", cls="DepthwiseSeparableConv1d", args=(10, 14),
                            kw=dict(norm_cls="cLN", kernel=2, dilation=1, skip=True, causal=True), B=2, T=33, seed=64),
+    "dsc_stride2_gln": dict(kind="lobe", cls="DepthwiseSeparableConv1d", args=(12, 20),
+                            kw=dict(hid_channels=18, norm_cls="gLN", kernel=3, dilation=2, stride=2), B=2, T=71, seed=65),
+    "dsc_stride3_cln": dict(kind="lobe", cls="DepthwiseSeparableConv1d", args=(10, 14),
+                            kw=dict(norm_cls="cLN", kernel=5, dilation=1, stride=3), B=2, T=50, seed=66),
     # ---- recurrent maskers, module level: T mod K in {0, 1, K-1}, causal / bidirectional, FiLM / Gate
     # conditioning, embedding-free TSE (embed = enrolment features), overlapped segments
     "dprnn_causal_r0": dict(kind="rnn", cls="DPRNN", args=(16, 8, 16), kw=dict(n_blocks=2, seg_size=5, causal=True),

@@ -129,7 +129,7 @@ def test_depthwise_separable_lobe_oracle_matches_reference(golden_dir, name):
     sd = {k: v.double() for k, v in det_state_dict(cases.build(PA.NS, name)).items()}
     kw = c["kw"]
     y = O.ds_conv(torch.tensor(g["x"]).double(), sd, "", kw.get("kernel", 3), kw.get("dilation", 1),
-                  kw.get("causal", False), kw["norm_cls"])
+                  kw.get("causal", False), kw["norm_cls"], kw.get("stride", 1))
     assert y.shape == g["y"].shape
     assert rel_max(y.numpy(), g["y"]) < TOL
 
