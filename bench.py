@@ -259,7 +259,7 @@ def main():
         "config": {"workload": "egs/ns Conv-TasNet, learned-conv encoder (32/16/512), R=3 X=8 H=256, "
                                "batch=32x4 s fp32 per GPU (BASELINE configs[1])",
                    "global_batch": total_b, "samples_per_utt": L, "parallelism": f"dp{world}",
-                   "hip_streams_per_gpu": int(getattr(model, "hip_streams", 2)),
+                   "hip_streams_per_gpu": int(getattr(model, "hip_streams", 1)),
                    "shards": "ragged (balanced contiguous split of 32*N-1 utterances)" if ragged else "equal",
                    "x_realtime": value / SR},
         # what the collective layer actually saw (the driver's scaling run checks it against --gpus)
@@ -278,7 +278,7 @@ def main():
         # sub-batch stream overlap is switched off for this pass: with two launches sharing the chip an
         # event pair would time the overlap, not the kernel.
         t = (L - 32) // 16 + 1
-        streams_kept = getattr(model, "hip_streams", 2)
+        streams_kept = getattr(model, "hip_streams", 1)
         model.hip_streams = 1
         model.inference(noisy)
         torch.cuda.synchronize(dev)

@@ -284,13 +284,15 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             # get_mask + apply_tf_masks + _get_waveform + _wav_output_constrain, base_nn.py:716-721
             return self.encoder.decode_padded(feats, t, mask, mask_act, out_mode, out)
 
-        # Utterances are independent, so a batch is split over `hip_streams` HIP streams: the tail of one
-        # half's kernels (and its HBM-bound depthwise/encoder/decoder launches) overlaps the other half's
-        # MFMA-bound GEMMs.  Results are bit-identical to the single-stream run.
+        # Utterances are independent, so a batch CAN be split over `hip_streams` HIP streams (the tail of one half's kernels
+        # overlapping the other half's GEMMs; results bit-identical to the single-stream run).  Default 1 since round 4: with
+        # the fp16x2 arithmetic nothing is left for a second lane to hide, and halving the batch costs -- config 3 14.2 ms
+        # against 12.5, config 4 3.2 against 2.1 (its recurrences fall off the 16-sequence kernels), the benchmark's step
+        # nothing; every benchmark of rounds 2-3 already set 1 by hand.  model.hip_streams = 2 restores the two lanes.
         n = noisy.shape[0]
         # (below 16 utterances a launch no longer fills the chip and halving it costs more than the overlap returns:
         #  tools/batch_sweep.py)
-        lanes = min(int(getattr(self, "hip_streams", 2)), n // 8) if n >= 16 else 1
+        lanes = min(int(getattr(self, "hip_streams", 1)), n // 8) if n >= 16 else 1
         if isinstance(self.masker, SkiM) and self.masker.causal:
             # the reference's causal Mem-LSTM hand-over leaks the last segment state of utterance n-1 into
             # utterance n (skim.py:102-109): keep the batch in one piece so the result stays identical to it

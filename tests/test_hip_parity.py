@@ -1047,9 +1047,11 @@ def test_full_size_properties_of_the_other_baseline_configs(PA, dev, name, gemm)
     assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0
     for i in (0, 15, 16, 31):
         single = model.inference(noisy[i:i + 1].to(dev), None if enroll is None else enroll[i:i + 1].to(dev))
-        if gemm == "fp32":
+        if gemm == "fp32" and not name.startswith("cfg4"):
             assert torch.equal(single[0], out[i]), i
         else:
+            # split GEMMs: fp32 rounding; DPRNN: the recurrence kernel depends on how many sequences a launch has (16 per
+            # workgroup for a full batch, 4 for one utterance): the same sums in another order
             assert float((single[0] - out[i]).abs().max()) <= 1e-5, i
     ref = O.inference(noisy[5:6], sd, cases.oracle_cfg(name), None if enroll is None else enroll[5:6])
     assert rel_max(out[5:6].cpu().numpy(), ref.numpy()) < TOL
