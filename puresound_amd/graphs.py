@@ -61,6 +61,14 @@ class GraphedInference:
         such as load_state_dict or optimizer steps are noticed by themselves)."""
         self._graphs.clear()
         self._tensors = None
+        self._stoch = None
+
+    def _stochastic(self) -> bool:
+        if getattr(self, "_stoch", None) is None:
+            from .nnet.lobe.trivial import SpecAugment
+            self._stoch = any(isinstance(m, SpecAugment) and (m.freq_mask > 0 or m.time_mask > 0)
+                              for m in self.model.modules())
+        return self._stoch
 
     def _signature(self):
         # per call, so it has to be cheap: the version counters of the tensors found at the first call (a walk over the
@@ -76,6 +84,10 @@ class GraphedInference:
     def __call__(self, noisy: torch.Tensor, enroll: Optional[torch.Tensor] = None) -> torch.Tensor:
         hip.require_device(noisy, "GraphedInference")
         dev = noisy.device
+        if self._stochastic():
+            # SpecAugment draws its mask positions on the host at every call (the reference's layer masks in eval mode too,
+            # lobe/trivial.py:7-58): a captured graph would replay ONE draw for ever.  Such a model runs eagerly.
+            return self.model.inference(noisy) if enroll is None else self.model.inference(noisy, enroll)
         sig = self._signature()
         if sig != self._sig:
             self._graphs.clear()

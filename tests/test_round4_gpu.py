@@ -453,3 +453,25 @@ def test_dual_path_blocks_with_skip_flags(PA, dev, kind, intra_skip, inter_skip)
            else UO.dparn_block2d(x.double(), sdd, "", 2, intra_skip, inter_skip))
     y = blk(x.to(dev), intra_skip, inter_skip)
     assert rel_max(y.cpu().numpy(), ref.numpy()) < 1e-4
+
+
+def test_graphed_inference_does_not_freeze_specaugment(PA, dev):
+    """tse_skim_v2_causal masks its speaker features at random in eval mode (as the reference's SpecAugment does): a captured
+    hipGraph would replay one draw for ever, so GraphedInference runs such a model eagerly -- same seed, same result as
+    model.inference; a model without stochastic layers still replays a graph, bit for bit the eager forward."""
+    from puresound_amd.graphs import GraphedInference
+    g = torch.Generator().manual_seed(9)
+    noisy = ((torch.rand(2, 16000, generator=g) * 2 - 1) * 0.5).to(dev)
+    enroll = ((torch.rand(2, 16000, generator=g) * 2 - 1) * 0.5).to(dev)
+    for name, graphs in (("tse_skim_v2_short", 0), ("tse_skim_causal_short", 1)):
+        model = cases.build(PA.NS, name).eval()
+        model.load_state_dict(det_state_dict(model))
+        model.to(dev)
+        fast = GraphedInference(model)
+        for seed in (0, 1):
+            torch.manual_seed(seed)
+            ref = model.inference(noisy, enroll)
+            torch.manual_seed(seed)
+            out = fast(noisy, enroll)
+            assert torch.equal(out, ref), (name, seed)
+        assert len(fast._graphs) == graphs, name
