@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 17
+#define PS_ABI_VERSION 18
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -105,6 +105,18 @@ size_t ps_free_decode_workspace_bytes(int N, int T, int win, int hop);
 int ps_free_decode_ws_f32(const float* feats, const float* mask, int mask_act, const float* w, float* out, int N, int C,
                           int T, int ldt, int win, int hop, int out_mode, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* The decoder with the signal score's moments as its epilogue (_align_waveform, base_nn.py:398-412, then
+ * SDRLoss.forward / si_snr, loss/sdr.py:104-183, 263-299 -- all algebra on five moments, see ps_wave_moments_f64 below).
+ * Writes `out` as ps_free_decode_ws_f32 does and, per utterance, P = ps_free_decode_moments_parts(...) slots of
+ * (sum a, sum b, sum a^2, sum b^2, sum ab) in fp64 into partials [N][P][5], a = the estimate after the output constraint,
+ * b = the aligned reference: ref [N][ldr] holds ref_len samples per row; shorter than the (T-1) hop + win output samples it
+ * counts as left-padded with zeros, longer it is cut (the reference's rule).  The caller adds the P slots up in order
+ * (deterministic: one writer per slot).  ps_free_decode_moments_parts = 0 where only the two-launch form exists
+ * (anything but win = 32, hop = 16, T >= 64, C % 16 == 0): ps_free_decode_moments_f32 then returns PS_E_UNSUPPORTED. */
+int ps_free_decode_moments_parts(int N, int C, int T, int ldt, int win, int hop);
+int ps_free_decode_moments_f32(const float* feats, const float* mask, int mask_act, const float* w, float* out, int N,
+                               int C, int T, int ldt, int win, int hop, int out_mode, const float* ref, int ldr,
+                               int ref_len, double* partials, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Conv-STFT encoder / iSTFT decoder (ConvSTFT.forward / .inverse, lobe/encoder.py:358-456; extend_fbins,

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PURESOUND_HIP_LIB: an experimental build of the same library (tools/build_variant.sh); kernel experiments only
 LIB_PATH = os.environ.get("PURESOUND_HIP_LIB") or os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -71,6 +71,9 @@ SIGNATURES = {
     "ps_free_decode_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp] + [C.c_int] * 7 + [_vp]),
     "ps_free_decode_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "ps_free_decode_ws_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp] + [C.c_int] * 7 + [_vp, C.c_size_t, _vp]),
+    "ps_free_decode_moments_parts": (C.c_int, [C.c_int] * 6),
+    "ps_free_decode_moments_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp] + [C.c_int] * 7 + [_vp, C.c_int, C.c_int, _vp,
+                                              _vp, C.c_size_t, _vp]),
     "ps_frame_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_complex_mask_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [_vp]),
     "ps_polar_mask_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 3 + [_vp]),

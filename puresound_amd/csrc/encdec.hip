@@ -254,10 +254,28 @@ __global__ __launch_bounds__(256) void free_encode_mfma_kernel(const float* __re
 #endif
 constexpr int DM_UC = PS_DM_UC;  // k pairs whose loads are in flight together per wave
 
+// Signal scores in the decoder's epilogue (SDRLoss / si_snr of loss/sdr.py:104-299 after _align_waveform,
+// base_nn.py:398-412): with MOM the kernels also leave the five moments of (estimate, aligned reference) -- sum a, sum b,
+// sum a^2, sum b^2, sum ab in fp64 -- of the samples they complete, one slot per tile (main kernel) and per workgroup (fixup
+// kernel), written by one lane each: no atomics, the caller adds a row's slots up in order.  A reference shorter than the
+// estimate counts as left-padded with zeros ("align from last"), a longer one is cut.
+struct DecodeScore {
+  const float* ref;  // [N][ldr]
+  double* parts;     // [N][nparts][5]
+  int ldr, ref_len, nparts;
+};
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <bool MOM>
 __global__ __launch_bounds__(256) void free_decode_mfma_kernel(const float* __restrict__ feats, const float* __restrict__ mask,
                                                                int mask_mode, const float* __restrict__ w,
                                                                float* __restrict__ out, float* __restrict__ tails, int C,
-                                                               int T, int ldt, int ntiles, int out_mode) {
+                                                               int T, int ldt, int ntiles, int out_mode, DecodeScore sc) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lr = lane & 31, lh = lane >> 5;
@@ -316,19 +334,61 @@ __global__ __launch_bounds__(256) void free_decode_mfma_kernel(const float* __re
     *reinterpret_cast<f32x4*>(dst) = f32x4{acc[8], acc[9], acc[10], acc[11]};
     *reinterpret_cast<f32x4*>(dst + 8) = f32x4{acc[12], acc[13], acc[14], acc[15]};
   }
+  if constexpr (MOM) {
+    double m[5] = {0., 0., 0., 0., 0.};
+    if (t <= T && final_here) {  // the samples this lane completed (a tile's first 16 belong to the fixup kernel)
+      const int pad = Lout > sc.ref_len ? Lout - sc.ref_len : 0;
+      const float* rr = sc.ref + (size_t)n * sc.ldr;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int sidx = 16 * t + 4 * lh + (r & 3) + 8 * (r >> 2);
+        const double a = (double)o[r], b = sidx >= pad ? (double)rr[sidx - pad] : 0.;
+        m[0] += a, m[1] += b, m[2] += a * a, m[3] += b * b, m[4] += a * b;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) m[k] = wave_sum_f64(m[k]);
+    if (lane == 0) {
+      double* dst = sc.parts + ((size_t)n * sc.nparts + tile) * 5;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) dst[k] = m[k];
+    }
+  }
 }
 
+// MOM: grid (ceil(16 (ntiles - 1) / 256), N) so that a workgroup's moments belong to one utterance; slot ntiles + blockIdx.x
+template <bool MOM>
 __global__ __launch_bounds__(256) void free_decode_fixup_kernel(float* __restrict__ out, const float* __restrict__ tails,
-                                                                int T, int ntiles, int N, int out_mode) {
+                                                                int T, int ntiles, int N, int out_mode, DecodeScore sc) {
   const int idx = blockIdx.x * 256 + threadIdx.x;  // (n, tile >= 1, j < 16)
   const int j = idx & 15, rest = idx >> 4;
-  const int tile = rest % (ntiles - 1) + 1, n = rest / (ntiles - 1);
-  if (n >= N) return;
+  const int tile = MOM ? rest + 1 : rest % (ntiles - 1) + 1, n = MOM ? (int)blockIdx.y : rest / (ntiles - 1);
   const int Lout = (T - 1) * 16 + 32;
   const size_t sidx = (size_t)16 * 32 * tile + j;
-  if ((int)sidx >= Lout) return;
-  float* o = out + (size_t)n * Lout + sidx;
-  *o = out_constrain(*o + tails[((size_t)n * ntiles + tile - 1) * 16 + j], out_mode);
+  const bool live = n < N && tile < ntiles && (int)sidx < Lout;
+  if (!MOM && !live) return;
+  float a = 0.f;
+  if (live) {
+    float* o = out + (size_t)n * Lout + sidx;
+    a = out_constrain(*o + tails[((size_t)n * ntiles + tile - 1) * 16 + j], out_mode);
+    *o = a;
+  }
+  if constexpr (MOM) {
+    __shared__ double red[4][5];
+    const int pad = Lout > sc.ref_len ? Lout - sc.ref_len : 0;
+    const double ad = (double)a, b = live && (int)sidx >= pad ? (double)sc.ref[(size_t)n * sc.ldr + sidx - pad] : 0.;
+    double m[5] = {ad, b, ad * ad, b * b, ad * b};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) m[k] = wave_sum_f64(m[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) red[threadIdx.x >> 6][k] = m[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5)
+      sc.parts[((size_t)n * sc.nparts + ntiles + blockIdx.x) * 5 + threadIdx.x] =
+          ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  }
 }
 
 // Run-time (win, hop) fallback: one thread per output sample.
@@ -623,12 +683,52 @@ extern "C" int ps_free_decode_ws_f32(const float* feats, const float* mask, int 
   hipStream_t s = (hipStream_t)stream;
   LaunchTimer timer("free_decode", s);
   const int ntiles = T / 32 + 1;
-  hipLaunchKernelGGL(free_decode_mfma_kernel, dim3((ntiles + 3) / 4, N), dim3(256), 0, s, feats, mask, mask_act, w, out,
-                     (float*)workspace, C, T, ldt, ntiles, out_mode);
+  hipLaunchKernelGGL(free_decode_mfma_kernel<false>, dim3((ntiles + 3) / 4, N), dim3(256), 0, s, feats, mask, mask_act, w,
+                     out, (float*)workspace, C, T, ldt, ntiles, out_mode, ps::DecodeScore{});
   const long long fix = (long long)N * (ntiles - 1) * 16;
-  hipLaunchKernelGGL(free_decode_fixup_kernel, dim3((unsigned)((fix + 255) / 256)), dim3(256), 0, s, out,
-                     (const float*)workspace, T, ntiles, N, out_mode);
+  hipLaunchKernelGGL(free_decode_fixup_kernel<false>, dim3((unsigned)((fix + 255) / 256)), dim3(256), 0, s, out,
+                     (const float*)workspace, T, ntiles, N, out_mode, ps::DecodeScore{});
   return check_launch("ps_free_decode_ws_f32");
+}
+
+extern "C" int ps_free_decode_moments_parts(int N, int C, int T, int ldt, int win, int hop) {
+  if (N <= 0 || N > 65535 || C <= 0 || T < 64 || ldt < T || win != 32 || hop != 16 || C % (2 * ps::DM_UC) ||
+      (long long)C * ldt * 4 >= (1ll << 31))
+    return 0;
+  const int ntiles = T / 32 + 1;
+  return ntiles + ((ntiles - 1) * 16 + 255) / 256;
+}
+
+extern "C" int ps_free_decode_moments_f32(const float* feats, const float* mask, int mask_act, const float* w, float* out,
+                                          int N, int C, int T, int ldt, int win, int hop, int out_mode, const float* ref,
+                                          int ldr, int ref_len, double* partials, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  const int nparts = ps_free_decode_moments_parts(N, C, T, ldt, win, hop);
+  if (nparts == 0) {
+    set_error("ps_free_decode_moments_f32: shape outside the fused kernel (N=%d C=%d T=%d ldt=%d win=%d hop=%d): decode, "
+              "then ps_wave_moments_f64", N, C, T, ldt, win, hop);
+    return PS_E_UNSUPPORTED;
+  }
+  if (!feats || !w || !out || !ref || !partials || !workspace || ref_len <= 0 || ldr < ref_len ||
+      workspace_bytes < ps_free_decode_workspace_bytes(N, T, win, hop) || ((uintptr_t)out & 15) ||
+      ((uintptr_t)workspace & 15)) {
+    set_error("ps_free_decode_moments_f32: null / unaligned pointer, short workspace or bad reference row (ref_len=%d "
+              "ldr=%d)", ref_len, ldr);
+    return PS_E_INVALID;
+  }
+  if (mask_act < PS_ACT_LINEAR || mask_act > PS_ACT_SIGMOID || out_mode < PS_OUT_CLAMP || out_mode > PS_OUT_NONE) {
+    set_error("ps_free_decode_moments_f32: unknown mask_act=%d or out_mode=%d", mask_act, out_mode);
+    return PS_E_INVALID;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  LaunchTimer timer("free_decode_moments", s);
+  const int ntiles = T / 32 + 1;
+  const ps::DecodeScore sc{ref, partials, ldr, ref_len, nparts};
+  hipLaunchKernelGGL(free_decode_mfma_kernel<true>, dim3((ntiles + 3) / 4, N), dim3(256), 0, s, feats, mask, mask_act, w,
+                     out, (float*)workspace, C, T, ldt, ntiles, out_mode, sc);
+  hipLaunchKernelGGL(free_decode_fixup_kernel<true>, dim3(((ntiles - 1) * 16 + 255) / 256, N), dim3(256), 0, s, out,
+                     (const float*)workspace, T, ntiles, N, out_mode, sc);
+  return check_launch("ps_free_decode_moments_f32");
 }
 
 extern "C" int ps_overlap_average_f32(const float* tail, int ld_tail, const float* cur, float* out, int B, int win,

@@ -92,6 +92,50 @@ def free_decode(feats: torch.Tensor, t: int, w: torch.Tensor, hop: int, mask: Op
     return out
 
 
+def align_reference(ref: torch.Tensor, length: int) -> torch.Tensor:
+    """_align_waveform's rule for the reference (base_nn.py:398-412): shorter than the estimate it is left-padded with
+    zeros, longer it is cut."""
+    have = ref.shape[-1]
+    if have < length:
+        return torch.nn.functional.pad(ref, (length - have, 0))
+    return ref[..., :length]
+
+
+def free_decode_moments(feats: torch.Tensor, t: int, w: torch.Tensor, hop: int, ref: torch.Tensor,
+                        mask: Optional[torch.Tensor] = None, mask_act: str = "linear", out_mode: str = "none",
+                        out: Optional[torch.Tensor] = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """free_decode + the moments [N, 5] (fp64: sum a, sum b, sum a^2, sum b^2, sum ab over the (T-1)*hop+win output
+    samples) of the estimate a and the reference b = ref [N, L_ref] aligned by the reference's rule (align_reference).
+    One pass: the moments are the decoder's epilogue (ps_free_decode_moments_f32) where that kernel exists, otherwise
+    the decoder followed by ps_wave_moments_f64."""
+    require_device(feats, "free_decode_moments")
+    require_device(ref, "free_decode_moments")
+    require_weight(w, feats, "free_decode_moments")
+    n, c, ldt = feats.shape
+    win = w.shape[-1]
+    lout = (t - 1) * hop + win
+    if ref.dim() != 2 or ref.shape[0] != n or ref.dtype != torch.float32 or ref.shape[1] < 1:
+        raise RuntimeError("free_decode_moments: `ref` must be an fp32 [N, L_ref] tensor")
+    parts = lib().ps_free_decode_moments_parts(n, c, t, ldt, win, hop)
+    if parts == 0:
+        out = free_decode(feats, t, w, hop, mask, mask_act, out_mode, out)
+        return out, wave_moments(out, align_reference(ref, lout))
+    if out is None:
+        out = torch.empty(n, lout, dtype=torch.float32, device=feats.device)
+    elif tuple(out.shape) != (n, lout) or not out.is_contiguous():
+        raise RuntimeError("free_decode_moments: `out` must be a contiguous [N, (T-1)*hop+win] tensor")
+    if ref.stride(1) != 1:
+        ref = ref.contiguous()
+    ws_bytes = lib().ps_free_decode_workspace_bytes(n, t, win, hop)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=feats.device)
+    part = torch.empty(n, parts, 5, dtype=torch.float64, device=feats.device)
+    check(lib().ps_free_decode_moments_f32(ptr(feats), ptr(mask), _abi.PS_ACT[mask_act], ptr(w), ptr(out), n, c, t, ldt,
+                                           win, hop, _abi.PS_OUT[out_mode], ptr(ref), ref.stride(0), ref.shape[1],
+                                           ptr(part), ptr(ws), ws_bytes, stream_ptr(feats.device)),
+          "ps_free_decode_moments_f32")
+    return out, part.sum(dim=1)
+
+
 def frame(wav: torch.Tensor, win: int, hop: int) -> tuple[torch.Tensor, int]:
     """wav [N,L] -> (frames padded [N,win,ldt], T): frames[n][k][t] = wav[n][t*hop+k]."""
     require_device(wav, "frame")

@@ -227,6 +227,30 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         if noisy.device.type == "cpu":  # BASELINE configs[0] / the recipes' --backend cpu: stock ATen (nnet/cpu_path.py)
             from . import cpu_path
             return cpu_path.wrapper_inference(self, noisy, enroll)
+        return self._inference(noisy, enroll, None)
+
+    @torch.no_grad()
+    def inference_scored(self, noisy: torch.Tensor, ref_clean: torch.Tensor, enroll: Optional[torch.Tensor] = None,
+                         loss_func: Optional[nn.Module] = None, inactive_labels: Optional[torch.Tensor] = None):
+        """inference() and the signal score of its result against ref_clean [N, L_ref] in one go -> (enhanced [N, L_out],
+        score).  Not a method of the reference: it is what its evaluation loops do after inference (`_align_waveform`,
+        base_nn.py:398-412, then SDRLoss / si_snr, loss/sdr.py:104-299), with the score's five moments gathered by the
+        decoder kernel while it writes the waveform instead of by further passes over it.  loss_func: an
+        SDRLoss (default self.loss_func_wav, else SDRLoss.init_mode("sisnr")); the score is its forward value."""
+        from .loss.sdr import SDRLoss
+        loss = loss_func if loss_func is not None else getattr(self, "loss_func_wav", None)
+        if loss is None:
+            loss = SDRLoss.init_mode("sisnr")
+        if not isinstance(loss, SDRLoss) or loss.source_aggregated:
+            raise NotImplementedError("inference_scored: an SDRLoss on [N, L] signals (not a source-aggregated mode)")
+        hip.require_device(ref_clean, "SoTaskWrapModule.inference_scored")
+        if ref_clean.dim() != 2 or ref_clean.shape[0] != noisy.shape[0]:
+            raise RuntimeError("inference_scored: ref_clean must be [N, L_ref] with the batch of `noisy`")
+        enh, moments = self._inference(noisy, enroll, ref_clean.float())
+        return enh, loss.from_moments(moments, enh.shape[-1], inactive_labels)
+
+    def _inference(self, noisy: torch.Tensor, enroll: Optional[torch.Tensor], ref: Optional[torch.Tensor]):
+        """The HIP path of inference(); with `ref` also the moments [N, 5] of (estimate, aligned ref)."""
         hip.require_device(noisy, "SoTaskWrapModule.inference")
         mask_act = self.check_mask_constraint(self.mask_constraint)
         pairing = self.check_mask_pairing(self.mask_type, self.f_type)
@@ -267,10 +291,13 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             feats, t = enc.encode_padded(noisy.contiguous(), self.drop_first_bin)
             mask = self.masker.forward_padded(feats, t, dvec)
             enh = hip.complex_mask(feats, mask, mask_act) if pairing == "complex" else hip.real_mask(feats, mask, mask_act)
-            return enc.decode_padded(enh, t, self.drop_first_bin, out_mode)
+            wav = enc.decode_padded(enh, t, self.drop_first_bin, out_mode)
+            if ref is None:
+                return wav
+            return wav, hip.wave_moments(wav, hip.align_reference(ref, wav.shape[-1]))  # (the iSTFT has no epilogue form)
 
         def run(part: torch.Tensor, lane: int, out: Optional[torch.Tensor],
-                part_enroll: Optional[torch.Tensor] = None) -> torch.Tensor:
+                part_enroll: Optional[torch.Tensor] = None, part_ref: Optional[torch.Tensor] = None):
             dvec, kw = None, {}
             if part_enroll is not None and self.embedding_free_tse:    # base_nn.py:706-707: the masker gets
                 dvec, te = self.encoder.encode_padded(part_enroll, need)  # the enrolment FEATURES
@@ -282,6 +309,8 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
                 kw["x_amax"] = self.encoder.feature_bound(part)        # the features' range without a pass over them
             mask = self.masker.forward_padded(feats, t, dvec, lane=lane, **kw)  # base_nn.py:709-714
             # get_mask + apply_tf_masks + _get_waveform + _wav_output_constrain, base_nn.py:716-721
+            if part_ref is not None:
+                return self.encoder.decode_scored_padded(feats, t, part_ref, mask, mask_act, out_mode, out)
             return self.encoder.decode_padded(feats, t, mask, mask_act, out_mode, out)
 
         # Utterances are independent, so a batch CAN be split over `hip_streams` HIP streams (the tail of one half's kernels
@@ -300,13 +329,14 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         if enroll is not None and enroll.shape[0] != n:
             raise RuntimeError("inference: noisy and enroll must have the same batch size")
         if lanes <= 1:
-            return run(noisy.contiguous(), 0, None, None if enroll is None else enroll.contiguous())
+            return run(noisy.contiguous(), 0, None, None if enroll is None else enroll.contiguous(), ref)
         noisy = noisy.contiguous()
         enroll = None if enroll is None else enroll.contiguous()
         dev = noisy.device
         win, hop = self.encoder.win_length, self.encoder.hop_length
         t_frames = (noisy.shape[1] - win) // hop + 1
         out = torch.empty(n, (t_frames - 1) * hop + win, dtype=torch.float32, device=dev)
+        moments = None if ref is None else torch.empty(n, 5, dtype=torch.float64, device=dev)
         cur = torch.cuda.current_stream(dev)
         pool = _side_streams(dev, lanes)
         bounds = [n * i // lanes for i in range(lanes + 1)]
@@ -322,11 +352,14 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             if first and i > 0:
                 s.wait_stream(pool[i - 1])
             with torch.cuda.stream(s):
-                run(noisy[bounds[i]:bounds[i + 1]], i, out[bounds[i]:bounds[i + 1]],
-                    None if enroll is None else enroll[bounds[i]:bounds[i + 1]])
+                got = run(noisy[bounds[i]:bounds[i + 1]], i, out[bounds[i]:bounds[i + 1]],
+                          None if enroll is None else enroll[bounds[i]:bounds[i + 1]],
+                          None if ref is None else ref[bounds[i]:bounds[i + 1]])
+                if ref is not None:
+                    moments[bounds[i]:bounds[i + 1]] = got[1]
         for s in pool:
             cur.wait_stream(s)
-        return out
+        return out if ref is None else (out, moments)
 
     def _prepare_plans(self, dev: torch.device) -> None:
         """Build / re-validate every kernel-side plan of the masker and the speaker branch on the current stream."""
@@ -343,8 +376,8 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
                 m._plan_get(dev, m._build)
 
     def _align_waveform(self, enh_wav: torch.Tensor, ref_wav: torch.Tensor):
-        """base_nn.py:398-412: a shorter reference is left-padded with zeros, a longer one cuts the estimate."""
-        return _align_waveform(enh_wav, ref_wav)
+        """base_nn.py:398-412: a shorter reference is left-padded with zeros ("align from last"), a longer one is cut."""
+        return enh_wav, hip.align_reference(ref_wav, enh_wav.shape[-1])
 
     # -- speaker branch (base_nn.py:697-705, 724-738) ---------------------------------------------------
     def _speaker_embedding_from_feats(self, x: torch.Tensor, t: int, x_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -477,13 +510,15 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
 
 
 
-def _align_waveform(enh_wav: torch.Tensor, ref_wav: torch.Tensor):
+def _align_waveform_simo(enh_wav: torch.Tensor, ref_wav: torch.Tensor):
+    """base_nn.py:874-888, the multi-output wrapper's variant: a shorter reference is left-padded with zeros; for a longer
+    one the reference slices the ESTIMATE to the reference's length -- a no-op, so the lengths stay different and its loss
+    fails on them.  Mirrored as is (the single-output wrapper's variant, :398-412, cuts the reference instead)."""
     enh_l, ref_l = enh_wav.shape[-1], ref_wav.shape[-1]
-    if enh_l != ref_l:
-        if ref_l < enh_l:
-            ref_wav = torch.nn.functional.pad(ref_wav, (enh_l - ref_l, 0))  # align from last
-        else:
-            enh_wav = enh_wav[..., :ref_l]                                  # align from begin
+    if ref_l < enh_l:
+        ref_wav = torch.nn.functional.pad(ref_wav, (enh_l - ref_l, 0))
+    elif ref_l > enh_l:
+        enh_wav = enh_wav[..., :ref_l]
     return enh_wav, ref_wav
 
 
@@ -510,11 +545,16 @@ class SiMoTaskWrapModule(EncDecMaskerBaseModel):
             print(f"Total params: {self.overall_parameters}")
 
     def _align_waveform(self, enh_wav: torch.Tensor, ref_wav: torch.Tensor):
-        return _align_waveform(enh_wav, ref_wav)
+        return _align_waveform_simo(enh_wav, ref_wav)
 
     @torch.no_grad()
     def inference(self, noisy: torch.Tensor) -> torch.Tensor:
         """noisy [N, L] -> separated waveforms [N, M, L_out] (base_nn.py:922-939)."""
+        return self._inference(noisy, None)
+
+    def _inference(self, noisy: torch.Tensor, ref: Optional[torch.Tensor]):
+        """inference(); with ref [N, M, L_ref] also the moments [N*M, 5] of (estimate, aligned ref) per (utterance, source),
+        gathered by the decoder launch where the encoder is the learned filterbank."""
         hip.require_device(noisy, "SiMoTaskWrapModule.inference")
         mask_act = self.check_mask_constraint(self.mask_constraint)
         pairing = self.check_mask_pairing(self.mask_type, self.f_type)
@@ -553,9 +593,24 @@ class SiMoTaskWrapModule(EncDecMaskerBaseModel):
             else:
                 enh = hip.real_mask(feats_rep, mask_pad, mask_act)
             wav = enc.decode_padded(enh, t, self.drop_first_bin, out_mode)
+        elif ref is not None:
+            if ref.dim() != 3 or tuple(ref.shape[:2]) != (batch, chout):
+                raise RuntimeError(f"SiMo: ref_clean must be [N, M, L] = [{batch}, {chout}, L], got {tuple(ref.shape)}")
+            hip.require_device(ref, "SiMoTaskWrapModule.forward")
+            lout = (t - 1) * self.encoder.hop_length + self.encoder.win_length
+            if ref.shape[-1] > lout:  # base_nn.py:885-887 leaves the lengths different and the loss fails on them
+                raise RuntimeError(f"The size of tensor a ({lout}) must match the size of tensor b ({ref.shape[-1]}) at "
+                                   f"non-singleton dimension 1 (SiMo _align_waveform does not cut a longer reference)")
+            wav, moments = self.encoder.decode_scored_padded(
+                feats_rep, t, ref.float().reshape(batch * chout, -1), mask_pad, mask_act, out_mode)
+            return wav.reshape(batch, chout, -1), moments
         else:
             wav = self.encoder.decode_padded(feats_rep, t, mask_pad, mask_act, out_mode)
-        return wav.reshape(batch, chout, -1)
+        wav = wav.reshape(batch, chout, -1)
+        if ref is None:
+            return wav
+        enh, aligned = _align_waveform_simo(wav, ref.float())
+        return wav, hip.wave_moments(enh.reshape(batch * chout, -1), aligned.reshape(batch * chout, -1))
 
     @torch.no_grad()
     def forward(self, noisy: torch.Tensor, ref_clean: torch.Tensor,
@@ -563,8 +618,13 @@ class SiMoTaskWrapModule(EncDecMaskerBaseModel):
         """base_nn.py:899-920 without autograd: separated estimate -> align -> loss_func_wav([N*M, L], [N*M, L])."""
         if self.loss_func_wav is None:
             raise RuntimeError("SiMoTaskWrapModule.forward needs loss_func_wav")
+        labels = None if inactive_labels is None else inactive_labels.reshape(-1)
+        from .loss.sdr import SDRLoss
+        if isinstance(self.loss_func_wav, SDRLoss) and not self.loss_func_wav.source_aggregated:
+            # the score is algebra on five moments per row: the decoder launch leaves them behind (SURVEY 8(f)-4)
+            enh, moments = self._inference(noisy, ref_clean)
+            return self.loss_func_wav.from_moments(moments, enh.shape[-1], labels)
         enh = self.inference(noisy)
         batch, chout = enh.shape[:2]
         enh, ref_clean = self._align_waveform(enh, ref_clean)
-        labels = None if inactive_labels is None else inactive_labels.reshape(-1)
         return self.loss_func_wav(enh.reshape(batch * chout, -1), ref_clean.reshape(batch * chout, -1), labels)

@@ -69,6 +69,13 @@ class FreeEncDec(nn.Module):
         return hip.free_decode(feats_pad, t, self.decoder.weight.detach(), self.hop_length, mask_pad, mask_act,
                                out_mode, out)
 
+    def decode_scored_padded(self, feats_pad: torch.Tensor, t: int, ref: torch.Tensor,
+                             mask_pad: Optional[torch.Tensor] = None, mask_act: str = "linear", out_mode: str = "none",
+                             out: Optional[torch.Tensor] = None):
+        """decode_padded + the moments [N, 5] of (estimate, ref aligned as base_nn.py:398-412) from the same launch."""
+        return hip.free_decode_moments(feats_pad, t, self.decoder.weight.detach(), self.hop_length, ref, mask_pad,
+                                       mask_act, out_mode, out)
+
     # -- reference API -------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """[N,L] -> [N,C,T] (encoder.py:71-83)."""

@@ -16,16 +16,26 @@ import torch.nn as nn
 from ... import hip
 
 
-def _inner(s1: torch.Tensor, s2: torch.Tensor, zero_mean: bool):
-    """[..., L] x 2 -> fp64 (<a,a>, <b,b>, <a,b>) of shape [..., 1] (optionally of the zero-mean signals)."""
+def _moments(s1: torch.Tensor, s2: torch.Tensor) -> torch.Tensor:
+    """[..., L] x 2 -> fp64 moments [..., 5] = (S_a, S_b, S_aa, S_bb, S_ab)."""
     lead, length = s1.shape[:-1], s1.shape[-1]
-    m = hip.wave_moments(s1.reshape(-1, length), s2.reshape(-1, length))
-    sa, sb, saa, sbb, sab = (m[:, i].reshape(*lead, 1) for i in range(5))
+    return hip.wave_moments(s1.reshape(-1, length), s2.reshape(-1, length)).reshape(*lead, 5)
+
+
+def _inner_of(m: torch.Tensor, length: int, zero_mean: bool):
+    """moments [..., 5] over `length` samples -> fp64 (<a,a>, <b,b>, <a,b>) of shape [..., 1] (optionally of the
+    zero-mean signals)."""
+    sa, sb, saa, sbb, sab = (m[..., i:i + 1] for i in range(5))
     if zero_mean:
         saa = saa - sa * sa / length
         sbb = sbb - sb * sb / length
         sab = sab - sa * sb / length
     return saa, sbb, sab
+
+
+def _inner(s1: torch.Tensor, s2: torch.Tensor, zero_mean: bool):
+    """[..., L] x 2 -> fp64 (<a,a>, <b,b>, <a,b>) of shape [..., 1] (optionally of the zero-mean signals)."""
+    return _inner_of(_moments(s1, s2), s1.shape[-1], zero_mean)
 
 
 def l2_norm(s1: torch.Tensor, s2: torch.Tensor) -> torch.Tensor:
@@ -35,7 +45,13 @@ def l2_norm(s1: torch.Tensor, s2: torch.Tensor) -> torch.Tensor:
 
 def si_snr(s1: torch.Tensor, s2: torch.Tensor, eps: float = 1e-8, reduction: bool = True) -> torch.Tensor:
     """Single-source SI-SNR in dB (sdr.py:263-299)."""
-    aa, bb, ab = _inner(s1, s2, True)
+    return si_snr_from_moments(_moments(s1, s2), s1.shape[-1], eps, reduction)
+
+
+def si_snr_from_moments(m: torch.Tensor, length: int, eps: float = 1e-8, reduction: bool = True) -> torch.Tensor:
+    """si_snr of signals given by their moments [..., 5] over `length` samples (hip.wave_moments, or the decoder's
+    epilogue: hip.free_decode_moments)."""
+    aa, bb, ab = _inner_of(m, length, True)
     alpha = ab / (bb + eps)
     target = alpha * alpha * bb
     noise = (aa - 2 * alpha * ab + alpha * alpha * bb).clamp_min(0.0)
@@ -45,7 +61,11 @@ def si_snr(s1: torch.Tensor, s2: torch.Tensor, eps: float = 1e-8, reduction: boo
 
 def inactive_sdr_loss(s1: torch.Tensor, s2: torch.Tensor, reduction: bool = True) -> torch.Tensor:
     """10 log10(|s1|^2 + 0.01 |s2|^2 + 1e-8) on the zero-mean signals (sdr.py:302-322)."""
-    aa, bb, _ = _inner(s1, s2, True)
+    return _inactive_from_moments(_moments(s1, s2), s1.shape[-1], reduction)
+
+
+def _inactive_from_moments(m: torch.Tensor, length: int, reduction: bool = True) -> torch.Tensor:
+    aa, bb, _ = _inner_of(m, length, True)
     val = (10 * torch.log10(aa + 0.01 * bb + 1e-8)).float()
     return torch.mean(val) if reduction else val
 
@@ -89,14 +109,21 @@ class SDRLoss(nn.Module):
     def forward(self, s1: torch.Tensor, s2: torch.Tensor, inactive_labels: Optional[torch.Tensor] = None) -> torch.Tensor:
         self.check_input_shape(s1)
         self.check_input_shape(s2)
+        return self.from_moments(_moments(s1, s2), s1.shape[-1], inactive_labels)
+
+    @torch.no_grad()
+    def from_moments(self, m: torch.Tensor, length: int, inactive_labels: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """forward() on signals given by their moments: m [N, 5] (or [N, M, 5] for the source-aggregated modes) over
+        `length` samples, e.g. from the decoder's epilogue (hip.free_decode_moments).  Rows are independent, so the
+        reference's split into active / inactive rows (sdr.py:123-136) is a split of the rows of m."""
         inactive_loss = None
         if inactive_labels is not None and bool((inactive_labels == True).any()):  # noqa: E712  (sdr.py:123-136)
             active_idx = torch.where(inactive_labels == False)[0]  # noqa: E712
             inactive_idx = torch.where(inactive_labels == True)[0]  # noqa: E712
-            inactive_loss = inactive_sdr_loss(s1[inactive_idx], s2[inactive_idx], reduction=False)
-            s1, s2 = s1[active_idx], s2[active_idx]
-        if s1.shape[0] > 0:
-            aa, bb, ab = _inner(s1, s2, self.zero_mean)
+            inactive_loss = _inactive_from_moments(m[inactive_idx], length, reduction=False)
+            m = m[active_idx]
+        if m.shape[0] > 0:
+            aa, bb, ab = _inner_of(m, length, self.zero_mean)
             alpha = ab / (bb + self.eps) if self.scaled else torch.ones_like(ab)
             target = alpha * alpha * bb                                  # |s_target|^2
             if not self.scale_dependent:
@@ -114,7 +141,7 @@ class SDRLoss(nn.Module):
                 snr = 10 * torch.log10(target.sum(dim=-1) / (noise.sum(dim=-1) + self.eps) + self.eps)
             snr = (-snr).float()
         else:
-            snr = torch.zeros(0, 1, dtype=torch.float32, device=s1.device)
+            snr = torch.zeros(0, 1, dtype=torch.float32, device=m.device)
         if self.threshold is not None:
             keep = snr[snr > self.threshold]
             if keep.nelement() > 0:

@@ -220,3 +220,22 @@ def test_wrapper_level_gemm_precision_switch():
     tcn.set_gemm_precision("bf16x3")
     assert all(m.gemm_precision == "bf16x3" for root in (tcn.masker, tcn.speaker_net) for m in root.modules()
                if hasattr(m, "gemm_precision"))
+
+
+def test_align_rules_of_the_two_wrappers():
+    """base_nn.py:398-412 (single output: a longer reference is cut) and :874-888 (multi output: the estimate is sliced
+    to the longer reference's length, i.e. nothing happens); both left-pad a shorter reference."""
+    import torch
+    from puresound_amd import hip
+    from puresound_amd.nnet.base_nn import _align_waveform_simo
+    from oracle import loss_oracle as LO
+    enh, short, long_ = torch.arange(10.).reshape(1, 10), torch.ones(1, 7), torch.ones(1, 13)
+    assert hip.align_reference(short, 10).tolist() == [[0., 0., 0.] + [1.] * 7]
+    assert hip.align_reference(long_, 10).shape == (1, 10)
+    for ref in (short, long_, enh):
+        e, r = LO.align_waveform_single(enh, ref)
+        assert torch.equal(r, hip.align_reference(ref, 10)) and e is enh
+        e2, r2 = _align_waveform_simo(enh, ref)
+        e3, r3 = LO.align_waveform(enh, ref)
+        assert torch.equal(e2, e3) and torch.equal(r2, r3)
+    assert _align_waveform_simo(enh, long_)[1].shape == (1, 13)

@@ -475,3 +475,111 @@ def test_graphed_inference_does_not_freeze_specaugment(PA, dev):
             out = fast(noisy, enroll)
             assert torch.equal(out, ref), (name, seed)
         assert len(fast._graphs) == graphs, name
+
+
+# ------------------------------------------------------------------------------------------------
+# the signal score's moments as the decoder's epilogue (ps_free_decode_moments_f32)
+# ------------------------------------------------------------------------------------------------
+def _aligned(ref, length):
+    """_align_waveform's rule for the reference (base_nn.py:398-412) in numpy."""
+    have = ref.shape[-1]
+    if have < length:
+        return np.concatenate([np.zeros(ref.shape[:-1] + (length - have,), ref.dtype), ref], -1)
+    return ref[..., :length]
+
+
+def _moments_np(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return np.stack([a.sum(-1), b.sum(-1), (a * a).sum(-1), (b * b).sum(-1), (a * b).sum(-1)], -1)
+
+
+@pytest.mark.parametrize("n,c,t,dref,mask_act,out_mode", [
+    (3, 64, 200, 0, "relu", "none"), (3, 64, 200, -37, "sigmoid", "sigmoid"), (2, 32, 1031, 50, "linear", "linear"),
+    (5, 512, 3999, -16, "relu", "none"), (2, 16, 64, -1000, "linear", "none"), (2, 24, 200, -5, "relu", "none"),
+    (2, 64, 40, 3, "relu", "none")])
+def test_decoder_leaves_the_score_moments_behind(H, dev, n, c, t, dref, mask_act, out_mode):
+    """The waveform is bit-identical to ps_free_decode_ws_f32's; the moments equal an fp64 numpy pass over that waveform and
+    the reference aligned by base_nn.py:398-412 (shorter: left-padded, longer: cut).  The last two shapes (C % 16 != 0, T <
+    64) are outside the fused kernel: the wrapper then decodes and calls ps_wave_moments_f64."""
+    from puresound_amd import _abi
+    win, hop = 32, 16
+    lout = (t - 1) * hop + win
+    feats, mask = H.pad_rows(_rand((n, c, t), 801).to(dev)), H.pad_rows(_rand((n, c, t), 802).to(dev))
+    w = _rand((c, 1, win), 803, -0.2, 0.2).to(dev)
+    wide = _rand((n, lout + dref + 9), 804).to(dev)
+    ref = wide[:, 5:5 + lout + dref]  # rows of a wider buffer (ldr > ref_len)
+    fused = _abi.lib().ps_free_decode_moments_parts(n, c, t, feats.shape[-1], win, hop) > 0
+    assert fused == (c % 16 == 0 and t >= 64)
+    want = H.free_decode(feats, t, w, hop, mask, mask_act, out_mode)
+    out, m = H.free_decode_moments(feats, t, w, hop, ref, mask, mask_act, out_mode)
+    assert torch.equal(out, want)
+    ref_m = _moments_np(want.cpu().numpy(), _aligned(ref.cpu().numpy(), lout))
+    np.testing.assert_allclose(m.cpu().numpy(), ref_m, rtol=1e-11, atol=1e-9)
+    if fused:  # the same call again: one writer per slot, so bit-identical moments
+        _, m2 = H.free_decode_moments(feats, t, w, hop, ref, mask, mask_act, out_mode)
+        assert torch.equal(m, m2)
+        with pytest.raises(RuntimeError):
+            H.free_decode_moments(feats, t, w, hop, ref[:1], mask, mask_act, out_mode)
+
+
+@pytest.mark.parametrize("name,dref,lanes", [("cfg2_short", -100, 1), ("cfg2_short", 64, 1), ("cfg3_short", 0, 1),
+                                             ("cfg2_short", -100, 2)])
+def test_inference_scored_equals_inference_then_the_oracle_score(PA, dev, name, dref, lanes):
+    """wrapper.inference_scored = inference() followed by _align_waveform + SDRLoss (oracle/loss_oracle.py restating
+    loss/sdr.py:104-183), for a shorter / equal / longer reference, with inactive rows, and over two HIP stream lanes."""
+    from oracle import loss_oracle as LO
+    from puresound_amd.nnet.loss.sdr import SDRLoss
+    c = cases.CASES[name]
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    b = 16 if lanes > 1 else c["B"]
+    model.hip_streams = lanes
+    noisy = det_wave(c["seed"], b, c["L"]).to(dev)
+    enroll = det_wave(c["seed"] + 1, b, c["L_enroll"]).to(dev) if "L_enroll" in c else None
+    want = model.inference(noisy, enroll)
+    clean = (0.7 * want.cpu() + 0.05 * det_wave(c["seed"] + 2, b, want.shape[-1]))
+    clean = clean[:, :want.shape[-1] + dref] if dref <= 0 else torch.nn.functional.pad(clean, (0, dref))
+    labels = torch.zeros(b, dtype=torch.bool)
+    labels[-1] = True
+    for mode in ("sisnr", "sdsdr", "tsdr"):
+        enh, score = model.inference_scored(noisy, clean.to(dev), enroll, SDRLoss.init_mode(mode, reduction=False),
+                                            labels.to(dev))
+        assert torch.equal(enh, want)
+        e, r = LO.align_waveform_single(want.cpu(), clean)
+        ref_score = LO.sdr_loss(e, r, reduction=False, inactive_labels=labels, **LO.mode_flags(mode))
+        np.testing.assert_allclose(score.cpu().numpy(), ref_score.numpy(), atol=2e-3, rtol=0)
+    # default loss: the wrapper's loss_func_wav, else SI-SNR with the mean reduction
+    _, score = model.inference_scored(noisy, clean.to(dev), enroll)
+    e, r = LO.align_waveform_single(want.cpu(), clean)
+    np.testing.assert_allclose(float(score), float(LO.sdr_loss(e, r, reduction=True, **LO.mode_flags("sisnr"))), atol=2e-3)
+
+
+def test_simo_forward_scores_from_the_decoder_launch(PA, dev):
+    """SiMoTaskWrapModule.forward on the learned filterbank (win 32, hop 16): the loss comes from the decoder's moments;
+    equal to inference() + the oracle's align + SDRLoss; a longer reference fails as in the reference (base_nn.py:885-887)."""
+    from oracle import loss_oracle as LO
+    c = cases.CASES["simo_free"]
+    enc = cases.build_encoder(PA.NS, dict(kind="free", win=32, hop=16, C=32))
+    masker = cases.build_simo_masker(PA.NS, dict(c, enc=dict(kind="free", win=32, hop=16, C=32),
+                                                 masker=dict(c["masker"], input_dim=32)))
+    model = PA.NS.SiMoTaskWrapModule(encoder=enc, masker=masker, verbose=False,
+                                     loss_func_wav=PA.NS.SDRLoss.init_mode("sisnr", reduction=False), **c["wrap"]).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    b, heads, length = 3, c["heads"], 3000
+    noisy = det_wave(91, b, length).to(dev)
+    wav = model.inference(noisy)
+    assert wav.shape == (b, heads, (length - 32) // 16 * 16 + 32)
+    from puresound_amd import _abi
+    assert _abi.lib().ps_free_decode_moments_parts(b * heads, 32, (length - 32) // 16 + 1, 256, 32, 16) > 0
+    ref_clean = (0.5 * wav.cpu() + 0.1 * det_wave(92, b * heads, wav.shape[-1]).reshape(wav.shape))[..., :-40]
+    labels = torch.zeros(b, heads, dtype=torch.bool)
+    labels[1, 0] = True
+    got = model(noisy, ref_clean.to(dev), labels.to(dev)).cpu().numpy()
+    e, r = LO.align_waveform(wav.cpu(), ref_clean)
+    want = LO.sdr_loss(e.reshape(b * heads, -1), r.reshape(b * heads, -1), reduction=False,
+                       inactive_labels=labels.reshape(-1), **LO.mode_flags("sisnr"))
+    np.testing.assert_allclose(got, want.numpy(), atol=2e-3, rtol=0)
+    with pytest.raises(RuntimeError, match="must match the size"):
+        model(noisy, torch.nn.functional.pad(ref_clean, (0, 100)).to(dev), labels.to(dev))
