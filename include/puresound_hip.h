@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 18
+#define PS_ABI_VERSION 19
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -428,6 +428,44 @@ int ps_lstm_gates_cell_f32(const float* xh, const float* wt_units, const float* 
 int ps_proj_layernorm_f32(const float* x, const float* wt, const float* bias, const float* gamma, const float* beta,
                           float eps, const float* res, float* y, const float* gamma2, const float* beta2, float eps2,
                           float* y2, float* x_copy, int res_inside, int N, int K, int M, int T, int ldt, void* stream);
+/* The same three operators for SEVERAL independent one-utterance problems of one shape in ONE launch each (blockIdx.y =
+ * the problem): the streaming harness runs the (hop, block) cells of a chunk as a wavefront (cell (h, i) needs (h, i-1) and
+ * (h-1, i) only), and the cells of an anti-diagonal differ in nothing but their pointers -- block i's weights and state, the
+ * hop's rows.  `cells` is a HOST array of ncells <= PS_MAX_CELLS entries, copied into the kernel arguments; fields as the
+ * arguments of the same name above with N = 1; results are bit-identical to ncells separate calls. */
+#define PS_MAX_CELLS 8
+typedef struct ps_film_cell {
+  const float* x;
+  const float* wt_pairs;
+  const float* res_pairs; /* may be NULL */
+  float* y;
+} ps_film_cell;
+typedef struct ps_gates_cell {
+  const float* xh;
+  const float* wt_units;
+  const float* bias_units; /* may be NULL */
+  float* c;
+  float* h;
+} ps_gates_cell;
+typedef struct ps_projln_cell {
+  const float* x;
+  const float* wt;
+  const float* bias; /* may be NULL */
+  const float* gamma;
+  const float* beta;
+  const float* res; /* may be NULL */
+  float* y;
+  const float* gamma2; /* with y2 */
+  const float* beta2;
+  float* y2;     /* may be NULL */
+  float* x_copy; /* may be NULL */
+  float eps, eps2;
+} ps_projln_cell;
+int ps_film_conv_cells_f32(const ps_film_cell* cells, int ncells, int C, int T, int ldt, void* stream);
+int ps_lstm_gates_cell_cells_f32(const ps_gates_cell* cells, int ncells, int K, int H, int T, int ldt, int ld_state,
+                                 void* stream);
+int ps_proj_layernorm_cells_f32(const ps_projln_cell* cells, int ncells, int res_inside, int K, int M, int T, int ldt,
+                                void* stream);
 /* The same on long rows with the partial maxima of |y| as a by-product: y_amax [N][ps_proj_layernorm_amax_parts(T)] is what
  * a following ps_conv1x1_f16x2_f32 takes as x_amax (the LSTM input projections of DPRNN / SkiM in the fp16x2 arithmetic).
  * Only the row kernel produces them (T >= 128, y2 == x_copy == NULL); otherwise PS_E_UNSUPPORTED. */

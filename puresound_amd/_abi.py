@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PURESOUND_HIP_LIB: an experimental build of the same library (tools/build_variant.sh); kernel experiments only
 LIB_PATH = os.environ.get("PURESOUND_HIP_LIB") or os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -32,6 +32,22 @@ class Prologue(C.Structure):
 
 class F16x2Range(C.Structure):
     _fields_ = [("w_exp", C.c_int), ("x_bound", C.c_float), ("x_amax", _vp), ("x_amax_parts", C.c_int), ("y_amax", _vp)]
+
+
+PS_MAX_CELLS = 8
+
+
+class FilmCell(C.Structure):
+    _fields_ = [(k, _vp) for k in ("x", "wt_pairs", "res_pairs", "y")]
+
+
+class GatesCell(C.Structure):
+    _fields_ = [(k, _vp) for k in ("xh", "wt_units", "bias_units", "c", "h")]
+
+
+class ProjLnCell(C.Structure):
+    _fields_ = [(k, _vp) for k in ("x", "wt", "bias", "gamma", "beta", "res", "y", "gamma2", "beta2", "y2", "x_copy")] + [
+        ("eps", C.c_float), ("eps2", C.c_float)]
 
 
 class LstmArgs(C.Structure):
@@ -108,6 +124,9 @@ SIGNATURES = {
     "ps_lstm_gates_cell_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp] + [C.c_int] * 6 + [_vp]),
     "ps_proj_layernorm_f32": (C.c_int, [_vp] * 5 + [C.c_float, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp] + [C.c_int] * 6
                               + [_vp]),
+    "ps_film_conv_cells_f32": (C.c_int, [C.POINTER(FilmCell)] + [C.c_int] * 4 + [_vp]),
+    "ps_lstm_gates_cell_cells_f32": (C.c_int, [C.POINTER(GatesCell)] + [C.c_int] * 6 + [_vp]),
+    "ps_proj_layernorm_cells_f32": (C.c_int, [C.POINTER(ProjLnCell)] + [C.c_int] * 6 + [_vp]),
     "ps_proj_layernorm_amax_parts": (C.c_int, [C.c_int]),
     "ps_proj_layernorm_amax_f32": (C.c_int, [_vp] * 5 + [C.c_float, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp] + [C.c_int] * 6
                                    + [_vp, _vp]),

@@ -109,12 +109,12 @@ struct FusedArgs {
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
 template <int NCB, int EPI>  // EPI 1 = FiLM, 2 = LSTM cell
-__global__ __launch_bounds__(256) void conv1x1_small_fused_kernel(FusedArgs fa) {
+__device__ __forceinline__ void small_fused_body(const FusedArgs& fa, const int n) {
   const SmallArgs& a = fa.g;
   __shared__ f32x4 part[4][NCB][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.x * 16, n = blockIdx.y;
+  const int m0 = blockIdx.x * 16;
   const int t0 = blockIdx.z * (NCB * 16);
   const int m = m0 + r;
   const float* wp = a.wt + ((size_t)(m >> 8) * a.Kp) * 256 + (m & 255);
@@ -197,6 +197,23 @@ __global__ __launch_bounds__(256) void conv1x1_small_fused_kernel(FusedArgs fa) 
   }
 }
 
+template <int NCB, int EPI>
+__global__ __launch_bounds__(256) void conv1x1_small_fused_kernel(FusedArgs fa) {
+  small_fused_body<NCB, EPI>(fa, blockIdx.y);
+}
+
+// Several independent one-utterance launches of the kernel above as ONE launch (the streaming wavefront: the (hop, block)
+// cells of an anti-diagonal share nothing but their shapes): blockIdx.y picks the cell's arguments.
+constexpr int MAX_CELLS = PS_MAX_CELLS;
+struct FusedCells {
+  FusedArgs c[MAX_CELLS];
+};
+
+template <int NCB, int EPI>
+__global__ __launch_bounds__(256) void conv1x1_small_fused_cells_kernel(FusedCells m) {
+  small_fused_body<NCB, EPI>(m.c[blockIdx.y], 0);
+}
+
 // Projection + LayerNorm + residual (+ the NEXT block's input LayerNorm) of the streaming step: a workgroup owns ALL M
 // output channels of 16 frames (waves split the channel blocks, each walks the whole K), the [M][16] tile meets in
 // LDS and every frame is normalised over its M channels there:
@@ -225,15 +242,15 @@ constexpr int PLN_MAXM = 256;
 // NRB: row blocks of 16 output channels: 8 (M <= 128) or 16 (M <= 256).  NW: waves that split K (4, or 8 for the short
 // rows of the streaming step, where the kernel is one latency chain on a handful of CUs: twice the loads in flight,
 // half the trips and half the MFMAs per wave).
-template <int NRB, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void proj_layernorm_kernel(ProjLnArgs a) {
+template <int NRB, int NW>
+__device__ __forceinline__ void proj_layernorm_body(const ProjLnArgs& a, const int n) {
   constexpr int NT = 64 * NW, CP = NT / 16;  // threads; channel parts of the LayerNorm phase
   __shared__ f32x4 part[NW][NRB][64];
   __shared__ float tile[NRB * 16][17];
   __shared__ float red[CP][17];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 15, kq = lane >> 4;
-  const int t0 = blockIdx.x * 16, n = blockIdx.y;
+  const int t0 = blockIdx.x * 16;
   const float* xp = a.x + (size_t)n * a.K * a.ldt + t0 + r;
   // the four waves split K; every wave accumulates all row blocks of its K share
   f32x4 acc[NRB];
@@ -323,6 +340,20 @@ __global__ __launch_bounds__(64 * NW) void proj_layernorm_kernel(ProjLnArgs a) {
       for (int m = cp; m < a.M; m += CP)
         a.y2[((size_t)n * a.M + m) * a.ldt + t] = (tile[m][f] - mean) * rstd * a.gamma2[m] + a.beta2[m];
   }
+}
+
+template <int NRB, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void proj_layernorm_kernel(ProjLnArgs a) {
+  proj_layernorm_body<NRB, NW>(a, blockIdx.y);
+}
+
+struct ProjLnCells {  // (see FusedCells)
+  ProjLnArgs c[MAX_CELLS];
+};
+
+template <int NRB, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void proj_layernorm_cells_kernel(ProjLnCells m) {
+  proj_layernorm_body<NRB, NW>(m.c[blockIdx.y], 0);
 }
 
 // The same operator on LONG rows (the offline DPRNN / SkiM / DPCRN paths: every frame of a 32 x 4 s batch goes through
@@ -743,6 +774,102 @@ extern "C" int ps_lstm_gates_cell_f32(const float* xh, const float* wt_units, co
   fa.ld_state = ld_state;
   fused_launch("lstm_gates_cell", 2, fa, N, (hipStream_t)stream);
   return small_status("ps_lstm_gates_cell_f32");
+}
+
+// ---- the cells of a streaming anti-diagonal as one launch each (N = 1 per cell, shapes shared) -------------------------
+static int fused_cells_launch(const char* who, int epi, const FusedCells& fc, int ncells, hipStream_t stream) {
+  const SmallArgs& a = fc.c[0].g;
+  const int ncb = a.T <= 16 ? 1 : a.T <= 32 ? 2 : 4;
+  dim3 grid((a.M + 15) / 16, ncells, (a.T + ncb * 16 - 1) / (ncb * 16));
+  LaunchTimer timer(who, stream);
+#define PS_FUSED(NCB)                                                                                    \
+  if (epi == 1)                                                                                          \
+    hipLaunchKernelGGL((conv1x1_small_fused_cells_kernel<NCB, 1>), grid, dim3(256), 0, stream, fc);      \
+  else                                                                                                   \
+    hipLaunchKernelGGL((conv1x1_small_fused_cells_kernel<NCB, 2>), grid, dim3(256), 0, stream, fc);
+  if (ncb == 1) {
+    PS_FUSED(1)
+  } else if (ncb == 2) {
+    PS_FUSED(2)
+  } else {
+    PS_FUSED(4)
+  }
+#undef PS_FUSED
+  return small_status(who);
+}
+
+extern "C" int ps_film_conv_cells_f32(const ps_film_cell* cells, int ncells, int C, int T, int ldt, void* stream) {
+  if (!cells || ncells <= 0 || ncells > PS_MAX_CELLS || C <= 0 || C % 2 || T <= 0 || ldt < T) {
+    set_error("ps_film_conv_cells_f32: bad argument (ncells=%d of at most %d, C=%d T=%d ldt=%d; C must be even)", ncells,
+              PS_MAX_CELLS, C, T, ldt);
+    return PS_E_INVALID;
+  }
+  FusedCells fc{};
+  for (int i = 0; i < ncells; ++i) {
+    if (!cells[i].x || !cells[i].wt_pairs || !cells[i].y) {
+      set_error("ps_film_conv_cells_f32: cell %d has a null pointer", i);
+      return PS_E_INVALID;
+    }
+    SmallArgs& g = fc.c[i].g;
+    g.x = cells[i].x, g.wt = cells[i].wt_pairs, g.y = cells[i].y, g.res = cells[i].res_pairs;
+    g.K = C, g.Kp = (C + 15) / 16 * 16, g.M = 2 * C, g.T = T, g.ldt = ldt;
+  }
+  return fused_cells_launch("ps_film_conv_cells_f32", 1, fc, ncells, (hipStream_t)stream);
+}
+
+extern "C" int ps_lstm_gates_cell_cells_f32(const ps_gates_cell* cells, int ncells, int K, int H, int T, int ldt,
+                                            int ld_state, void* stream) {
+  if (!cells || ncells <= 0 || ncells > PS_MAX_CELLS || K <= 0 || H <= 0 || T <= 0 || ldt < T || ld_state < T) {
+    set_error("ps_lstm_gates_cell_cells_f32: bad argument (ncells=%d of at most %d, K=%d H=%d T=%d)", ncells, PS_MAX_CELLS,
+              K, H, T);
+    return PS_E_INVALID;
+  }
+  FusedCells fc{};
+  for (int i = 0; i < ncells; ++i) {
+    if (!cells[i].xh || !cells[i].wt_units || !cells[i].c || !cells[i].h) {
+      set_error("ps_lstm_gates_cell_cells_f32: cell %d has a null pointer", i);
+      return PS_E_INVALID;
+    }
+    FusedArgs& fa = fc.c[i];
+    fa.g.x = cells[i].xh, fa.g.wt = cells[i].wt_units, fa.g.bias = cells[i].bias_units;
+    fa.g.K = K, fa.g.Kp = (K + 15) / 16 * 16, fa.g.M = 4 * H, fa.g.T = T, fa.g.ldt = ldt;
+    fa.c_state = cells[i].c, fa.h_out = cells[i].h, fa.ld_state = ld_state;
+  }
+  return fused_cells_launch("ps_lstm_gates_cell_cells_f32", 2, fc, ncells, (hipStream_t)stream);
+}
+
+extern "C" int ps_proj_layernorm_cells_f32(const ps_projln_cell* cells, int ncells, int res_inside, int K, int M, int T,
+                                           int ldt, void* stream) {
+  if (!cells || ncells <= 0 || ncells > PS_MAX_CELLS || K <= 0 || M <= 0 || T <= 0 || ldt < T) {
+    set_error("ps_proj_layernorm_cells_f32: bad argument (ncells=%d of at most %d, K=%d M=%d T=%d)", ncells, PS_MAX_CELLS,
+              K, M, T);
+    return PS_E_INVALID;
+  }
+  if (M > PLN_MAXM) {
+    set_error("ps_proj_layernorm_cells_f32: M=%d > %d output channels", M, PLN_MAXM);
+    return PS_E_UNSUPPORTED;
+  }
+  ProjLnCells pc{};
+  for (int i = 0; i < ncells; ++i) {
+    const ps_projln_cell& c = cells[i];
+    if (!c.x || !c.wt || !c.gamma || !c.beta || !c.y || (c.y2 && (!c.gamma2 || !c.beta2))) {
+      set_error("ps_proj_layernorm_cells_f32: cell %d has a null pointer", i);
+      return PS_E_INVALID;
+    }
+    pc.c[i] = ProjLnArgs{c.x, c.wt, c.bias, c.gamma, c.beta, c.res, c.y, c.gamma2, c.beta2, c.y2, c.x_copy, res_inside,
+                         c.eps, c.eps2, K, (K + 15) / 16 * 16, M, T, ldt, 1, nullptr};
+  }
+  hipStream_t s = (hipStream_t)stream;
+  LaunchTimer timer("proj_layernorm", s);
+  const dim3 grid((T + 15) / 16, ncells);
+  // (the same choice as ps_proj_layernorm_f32 makes for one cell: results stay bit-identical to the per-cell launches)
+  if (M <= 128 && (long long)((T + 15) / 16) <= 64)
+    hipLaunchKernelGGL((proj_layernorm_cells_kernel<8, 8>), grid, dim3(512), 0, s, pc);
+  else if (M <= 128)
+    hipLaunchKernelGGL((proj_layernorm_cells_kernel<8>), grid, dim3(256), 0, s, pc);
+  else
+    hipLaunchKernelGGL((proj_layernorm_cells_kernel<16>), grid, dim3(256), 0, s, pc);
+  return small_status("ps_proj_layernorm_cells_f32");
 }
 
 extern "C" int ps_proj_layernorm_amax_parts(int T) { return T > 0 ? 4 * ((T + 127) / 128) : 0; }

@@ -719,6 +719,56 @@ def proj_layernorm(x: torch.Tensor, t: int, wt: torch.Tensor, bias: Optional[tor
     return y, y2
 
 
+# ---- the cells of a streaming anti-diagonal: the three operators above for several one-utterance problems per launch ----
+MAX_CELLS = _abi.PS_MAX_CELLS
+
+
+def film_conv_cells(cells: list, t: int) -> None:
+    """cells: [(xn [1,C,ld], wt_pairs, res_pairs | None, out [1,C,ld]), ...] -> one ps_film_conv_cells_f32 launch."""
+    x0 = cells[0][0]
+    require_device(x0, "film_conv_cells")
+    _, c, ldt = x0.shape
+    arr = (_abi.FilmCell * len(cells))()
+    for a, (x, wt, res, y) in zip(arr, cells):
+        if tuple(x.shape) != (1, c, ldt) or tuple(y.shape) != (1, c, ldt) or x.stride(1) != ldt or y.stride(1) != ldt:
+            raise RuntimeError("film_conv_cells: every cell is a [1, C, ld] row block of one shape")
+        a.x, a.wt_pairs, a.res_pairs, a.y = ptr(x), ptr(wt), ptr(res), ptr(y)
+    check(lib().ps_film_conv_cells_f32(arr, len(cells), c, t, ldt, stream_ptr(x0.device)), "ps_film_conv_cells_f32")
+
+
+def lstm_gates_cell_cells(cells: list, t: int, hidden: int) -> None:
+    """cells: [(xh [1,K,ld], wt_units, bias_units, c [1,H,ld'], h [1,H,ld']), ...] -> one launch (c in place, h' out)."""
+    xh0, c0 = cells[0][0], cells[0][3]
+    require_device(xh0, "lstm_gates_cell_cells")
+    _, k, ldt = xh0.shape
+    arr = (_abi.GatesCell * len(cells))()
+    for a, (xh, wt, bias, c, h) in zip(arr, cells):
+        if tuple(xh.shape) != (1, k, ldt) or c.stride(1) != c0.stride(1) or h.stride(1) != c0.stride(1):
+            raise RuntimeError("lstm_gates_cell_cells: every cell has the same [1, K, ld] block and state row stride")
+        a.xh, a.wt_units, a.bias_units, a.c, a.h = ptr(xh), ptr(wt), ptr(bias), ptr(c), ptr(h)
+    check(lib().ps_lstm_gates_cell_cells_f32(arr, len(cells), k, hidden, t, ldt, c0.stride(1), stream_ptr(xh0.device)),
+          "ps_lstm_gates_cell_cells_f32")
+
+
+def proj_layernorm_cells(cells: list, t: int, m: int) -> None:
+    """cells: [dict(x, wt, bias, gamma, beta, eps, res, y, norm2 = (gamma2, beta2, eps2) | None, y2, x_copy), ...] -> one
+    launch: y = res + LN(W x + b) (+ y2 = LN2(y), + x_copy = x) per cell."""
+    x0 = cells[0]["x"]
+    require_device(x0, "proj_layernorm_cells")
+    _, k, ldt = x0.shape
+    arr = (_abi.ProjLnCell * len(cells))()
+    for a, c in zip(arr, cells):
+        if tuple(c["x"].shape) != (1, k, ldt) or tuple(c["y"].shape) != (1, m, ldt) or not c["y"].is_contiguous():
+            raise RuntimeError("proj_layernorm_cells: every cell maps a [1, K, ld] block to a contiguous [1, M, ld] block")
+        g2, b2, e2 = c["norm2"] if c.get("norm2") is not None else (None, None, 0.0)
+        a.x, a.wt, a.bias, a.gamma, a.beta = ptr(c["x"]), ptr(c["wt"]), ptr(c.get("bias")), ptr(c["gamma"]), ptr(c["beta"])
+        a.res, a.y, a.gamma2, a.beta2 = ptr(c.get("res")), ptr(c["y"]), ptr(g2), ptr(b2)
+        a.y2, a.x_copy = ptr(c.get("y2") if g2 is not None else None), ptr(c.get("x_copy"))
+        a.eps, a.eps2 = float(c["eps"]), float(e2)
+    check(lib().ps_proj_layernorm_cells_f32(arr, len(cells), 0, k, m, t, ldt, stream_ptr(x0.device)),
+          "ps_proj_layernorm_cells_f32")
+
+
 def overlap_average(prev: torch.Tensor, cur: torch.Tensor, overlap: int) -> torch.Tensor:
     """Streaming harness OLA: returns the new [B, win] block whose first `overlap` samples are the average of the
     tail of `prev` [B, L] and the head of `cur` [B, win]."""

@@ -184,7 +184,9 @@ class DemoTseNet(nn.Module):
         # averaging overlap-add of all hops, the new tail and the new window queue: one launch
         hip.stream_overlap(frames, self._wins, self._tail, self._blocks, self.queue, h)
 
-    _wavefront = True  # chunk body: (hop, block) cells as a wavefront over parallel graph branches (False: hop after hop)
+    _wavefront = True  # chunk body: (hop, block) cells as a wavefront (False: hop after hop)
+    _batched_cells = True  # an anti-diagonal's cells as one launch per kernel (False: one graph branch per block, round 3)
+    _wf_y = None
 
     def _wavefront_run(self, feats: torch.Tensor, x_ln: torch.Tensor, h0: int, h1: int) -> None:
         """Hops [h0, h1) of the chunk through all blocks as a wavefront: the cells (hop d - i, block i) of anti-diagonal d run
@@ -192,6 +194,23 @@ class DemoTseNet(nn.Module):
         m = self.masker
         nb = m.n_blocks
         dev = feats.device
+        if self._batched_cells and nb <= hip.MAX_CELLS:
+            # the cells of an anti-diagonal differ in their pointers only: ONE launch per kernel and diagonal
+            # (ps_*_cells_f32), so the chunk is a linear chain of 3 (hops + blocks - 1) launches on one stream -- no fork,
+            # no join, no idle side streams
+            if nb > 1 and (self._wf_y is None or len(self._wf_y) != nb - 1
+                           or self._wf_y[0][0][0].shape != feats[0:1].shape):
+                mk = lambda: torch.empty_like(feats[0:1])  # noqa: E731
+                self._wf_y = [[(mk(), mk()) for _ in range(2)] for _ in range(nb - 1)]   # [block][hop parity] -> (y, y2)
+            for d in range(h0, h1 + nb - 1):
+                cells = []
+                for i in range(nb):
+                    h = d - i
+                    if h0 <= h < h1:
+                        cur = (feats[h:h + 1], x_ln[h:h + 1]) if i == 0 else self._wf_y[i - 1][h & 1]
+                        cells.append((i, cur[0], cur[1], self._cores[h:h + 1], None if i == nb - 1 else self._wf_y[i][h & 1]))
+                m._cells(cells)
+            return
         main = torch.cuda.current_stream(dev)
         if getattr(self, "_wf_streams", None) is None or len(self._wf_streams) != nb:
             self._wf_streams = [torch.cuda.Stream(dev) for _ in range(nb)]

@@ -242,6 +242,37 @@ class StreamingSkiM(SkiM):
         hip.proj_layernorm(h_new, b, proj["wt"], proj["bias"], proj["M"], norm["gamma"], norm["beta"], norm["eps"], x_rows,
                            norm2, x_copy=h_rows, out=last, out2=None if norm2 is None else y_bufs[1])
 
+    def _cells(self, cells: list) -> None:
+        """Several _cell calls of DIFFERENT blocks -- [(i, cur, cur_ln, core_out, y_bufs), ...], the cells of one
+        anti-diagonal of the wavefront -- as three launches in all (ps_*_cells_f32: blockIdx.y picks the cell) instead of
+        three per cell on parallel streams.  Bit-identical to the per-cell launches (same kernels, same launch shapes)."""
+        if len(cells) == 1:
+            return self._cell(*cells[0])
+        b = self.streams
+        c_in, hid = self.input_size, self.hidden_size
+        film, gates, proj_cells = [], [], []
+        m_out = None
+        for i, cur, cur_ln, core_out, y_bufs in cells:
+            rnn, proj, norm = self.seg_lstm[i].step_plan(cur_ln.device)
+            xh = self._xh[i]
+            x_rows, h_rows = xh[:, :c_in, :], xh[:, c_in:, :]
+            fusion = self.seg_input_fusion[i]
+            film.append((cur_ln, fusion._plan_get(cur_ln.device, fusion._build)["wt_pairs"], fusion._per_frame_pairs, x_rows))
+            gates.append((xh, rnn["w_units"], rnn["bias_units"], self._seg_c[i], self._h_new[i]))
+            norm2 = None
+            if i + 1 < self.n_blocks:
+                nxt = self.seg_input_fusion[i + 1]
+                ln = nxt._plan_get(cur_ln.device, nxt._build)["norm"]
+                norm2 = (ln["gamma"], ln["beta"], ln["eps"])
+            last = core_out if i == self.n_blocks - 1 else y_bufs[0]
+            proj_cells.append(dict(x=self._h_new[i], wt=proj["wt"], bias=proj["bias"], gamma=norm["gamma"], beta=norm["beta"],
+                                   eps=norm["eps"], res=x_rows, y=last, norm2=norm2,
+                                   y2=None if norm2 is None else y_bufs[1], x_copy=h_rows))
+            m_out = proj["M"]
+        hip.film_conv_cells(film, b)
+        hip.lstm_gates_cell_cells(gates, b, hid)
+        hip.proj_layernorm_cells(proj_cells, b, m_out)
+
     def _frame_body(self, out: Optional[torch.Tensor] = None, x_ln: Optional[torch.Tensor] = None,
                     core_out: Optional[torch.Tensor] = None):
         """One frame of every stream through all blocks; reads _x_in / _embed_static, updates the seg states in

@@ -583,3 +583,77 @@ def test_simo_forward_scores_from_the_decoder_launch(PA, dev):
     np.testing.assert_allclose(got, want.numpy(), atol=2e-3, rtol=0)
     with pytest.raises(RuntimeError, match="must match the size"):
         model(noisy, torch.nn.functional.pad(ref_clean, (0, 100)).to(dev), labels.to(dev))
+
+
+# ------------------------------------------------------------------------------------------------
+# streaming wavefront: the cells of an anti-diagonal as one launch per kernel (ps_*_cells_f32)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("t", [4, 37, 64])
+def test_cells_launches_equal_separate_launches(H, dev, t):
+    """ps_film_conv_cells_f32 / ps_lstm_gates_cell_cells_f32 / ps_proj_layernorm_cells_f32 on three cells with different
+    weights, inputs and states: bit-identical to three separate ps_film_conv_f32 / ... launches."""
+    c, hid, ncell = 12, 8, 3
+    dv = lambda shape, seed, lo=-1.0, hi=1.0: _rand(shape, seed, lo, hi).to(dev)  # noqa: E731
+    # FiLM
+    xs = [H.pad_rows(dv((1, c, t), 900 + i)) for i in range(ncell)]
+    wts = [H.pack_wt(dv((2 * c, c), 910 + i, -0.3, 0.3)) for i in range(ncell)]
+    ress = [H.pad_rows(dv((1, 2 * c, t), 920 + i)) if i != 1 else None for i in range(ncell)]
+    want = [H.film_conv(xs[i], t, wts[i], ress[i]) for i in range(ncell)]
+    outs = [torch.zeros_like(xs[0]) for _ in range(ncell)]
+    H.film_conv_cells([(xs[i], wts[i], ress[i], outs[i]) for i in range(ncell)], t)
+    for a, b in zip(outs, want):
+        assert torch.equal(a[..., :t], b[..., :t])
+    # gates + cell
+    xhs = [H.pad_rows(dv((1, c + hid, t), 930 + i)) for i in range(ncell)]
+    ws = [H.pack_wt(dv((4 * hid, c + hid), 940 + i, -0.3, 0.3)) for i in range(ncell)]
+    bs = [dv((4 * hid,), 950 + i) for i in range(ncell)]
+    c0 = [H.pad_rows(dv((1, hid, t), 960 + i)) for i in range(ncell)]
+    c_ref, h_ref = [x.clone() for x in c0], [torch.zeros_like(x) for x in c0]
+    for i in range(ncell):
+        H.lstm_gates_cell(xhs[i], t, ws[i], bs[i], c_ref[i], h_ref[i], hid)
+    c_got, h_got = [x.clone() for x in c0], [torch.zeros_like(x) for x in c0]
+    H.lstm_gates_cell_cells([(xhs[i], ws[i], bs[i], c_got[i], h_got[i]) for i in range(ncell)], t, hid)
+    for i in range(ncell):
+        assert torch.equal(c_got[i][..., :t], c_ref[i][..., :t]) and torch.equal(h_got[i][..., :t], h_ref[i][..., :t])
+    # projection + LayerNorm + residual; the last cell without the second norm (the last block of the wavefront)
+    for m, k in ((12, 8), (128, 256), (200, 20)):
+        hx = [H.pad_rows(dv((1, k, t), 970 + i)) for i in range(ncell)]
+        res = [H.pad_rows(dv((1, m, t), 980 + i)) for i in range(ncell)]
+        wp = [H.pack_wt(dv((m, k), 990 + i, -0.3, 0.3)) for i in range(ncell)]
+        vec = [[dv((m,), 1000 + 10 * i + j, 0.5, 1.5) for j in range(5)] for i in range(ncell)]
+        cells, refs = [], []
+        for i in range(ncell):
+            bp, g1, b1, g2, b2 = vec[i]
+            norm2 = (g2, b2, 1e-5) if i + 1 < ncell else None
+            cp = torch.zeros_like(hx[i])
+            refs.append(H.proj_layernorm(hx[i], t, wp[i], bp, m, g1, b1, 1e-5, res[i], norm2, x_copy=cp) + (cp,))
+            cells.append(dict(x=hx[i], wt=wp[i], bias=bp, gamma=g1, beta=b1, eps=1e-5, res=res[i], norm2=norm2,
+                              y=torch.zeros_like(res[i]), y2=torch.zeros_like(res[i]), x_copy=torch.zeros_like(hx[i])))
+        H.proj_layernorm_cells(cells, t, m)
+        for cell, (y, y2, cp) in zip(cells, refs):
+            assert torch.equal(cell["y"][..., :t], y[..., :t]) and torch.equal(cell["x_copy"][..., :t], cp[..., :t])
+            if y2 is not None:
+                assert torch.equal(cell["y2"][..., :t], y2[..., :t])
+    with pytest.raises(RuntimeError, match="ncells"):
+        H.film_conv_cells([(xs[0], wts[0], None, outs[0])] * 9, t)
+
+
+def test_wavefront_in_one_launch_per_diagonal_equals_one_branch_per_block(dev):
+    """A chunk's wavefront with the cells of an anti-diagonal in one launch per kernel (round 4: a linear chain of launches) and
+    with one graph branch per block (round 3): the same bits, across a Mem-LSTM update."""
+    from puresound_amd.streaming.demo import DemoTseNet
+    net = DemoTseNet().eval()
+    net.load_state_dict(det_state_dict(net))
+    net.to(dev)
+    b, n_chunks = 6, 10
+    wav = det_wave(521, b, 320 * n_chunks).to(dev)
+    emb = torch.rand(b, 192, generator=torch.Generator().manual_seed(522)).to(dev)
+    outs = []
+    for batched in (True, False):
+        net._batched_cells = batched
+        net.init_streams(b, use_graph=True)
+        pre = None
+        for i in range(n_chunks):
+            pre = net.streaming_inference_chunk(wav[:, i * 320:(i + 1) * 320], emb, pre)
+        outs.append(pre.clone())
+    assert torch.equal(outs[0], outs[1])
