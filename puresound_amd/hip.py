@@ -65,8 +65,11 @@ def free_encode(wav: torch.Tensor, w: torch.Tensor, hop: int, relu: bool = False
     t = (length - win) // hop + 1
     need = min_frames(t) if callable(min_frames) else (min_frames or 0)
     ldt = padded_frames(max(t, need))
-    # frames beyond T: zero when a consumer asked for them (segment padding), otherwise never read as data
-    feats = (torch.zeros if need > t else torch.empty)(n, c, ldt, dtype=torch.float32, device=wav.device)
+    # frames beyond T: zero when a consumer asked for them (segment padding: only those columns are cleared, the kernel
+    # writes [0, T) and nothing else), otherwise never read as data
+    feats = torch.empty(n, c, ldt, dtype=torch.float32, device=wav.device)
+    if need > t:
+        feats[..., t:].zero_()
     check(lib().ps_free_encode_f32(ptr(wav), ptr(w), ptr(feats), n, length, c, win, hop, t, ldt, int(relu),
                                    stream_ptr(wav.device)), "ps_free_encode_f32")
     return feats, t

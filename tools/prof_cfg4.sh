@@ -2,7 +2,7 @@
 # kernel-trace totals of BASELINE config 4 (DPRNN, 32 x 4 s) with the masker in the fp16x2 arithmetic (GPU box): tools/prof_cfg4.sh
 root=$(pwd); cd /tmp && export TMPDIR=/tmp && cd "$root"
 out=gpurun_out/prof_cfg4; rm -rf $out
-PS_PRECS=fp16x2 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 tools/preset_sweep.py cfg4_short > gpurun_out/prof_cfg4.log 2>&1
+PS_PRECS=${PS_PRECS:-fp16x2} rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 tools/preset_sweep.py cfg4_short > gpurun_out/prof_cfg4.log 2>&1
 grep "^{" gpurun_out/prof_cfg4.log
 python3 - <<'PY'
 import csv, glob
