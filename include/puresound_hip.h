@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 19
+#define PS_ABI_VERSION 20
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -554,6 +554,13 @@ int ps_conv1x1_bf16_io(const void* x, int x_bf16, const void* wt_planes, void* y
                        const float* res, double* ostats, void* stream);
 int ps_dwconv_io(const void* x, int x_bf16, const float* w, const float* b, void* y, int y_bf16, int N, int H, int T,
                  int ldt, int P, int dilation, int left, const ps_prologue* pro, double* ostats, void* stream);
+/* The depthwise convolution leaving the partial maxima of |y| over the valid frames behind instead of the statistics:
+ * y_amax [N][ps_dwconv_stats_parts(H, T)] -- the input range of a following ps_conv1x1_f16x2_f32 whose prologue is a
+ * per-channel affine map (an eval BatchNorm) rather than a global norm (ps_f16x2_range.amax_mul / amax_add).  fp32 rows,
+ * P = 3 and 2 * dilation <= 256 (ps_dwconv_amax_ok = 1); otherwise PS_E_UNSUPPORTED: ps_dwconv_f32, then ps_absmax_f32. */
+int ps_dwconv_amax_ok(int P, int dilation, int left);
+int ps_dwconv_amax_f32(const float* x, const float* w, const float* b, float* y, int N, int H, int T, int ldt, int P,
+                       int dilation, int left, const ps_prologue* pro, float* y_amax, void* stream);
 
 
 /* ps_conv1x1_f32's contract in the "fp16x2" arithmetic: every operand as two fp16 terms (22 significant bits), three
@@ -570,6 +577,9 @@ int ps_dwconv_io(const void* x, int x_bf16, const float* w, const float* b, void
  *                launch before, or ps_absmax_f32): per utterance, max |x| goes to [2^14, 2^15);
  *                else 2^-2 behind a normalising prologue and 2^-4 otherwise (|values| beyond 2.6e5 / 1e6 overflow to
  *                inf / NaN in y; small inputs lose relative precision: absolute resolution 2^-23 / 2^-21).
+ *                With amax_mul > 0 the maxima are those of the producer's output BEFORE the prologue f (a per-channel
+ *                affine map -- an eval BatchNorm -- and a PReLU): the range of f(x) is taken as amax_mul * max|x| + amax_add
+ *                (max |scale| and max |shift| of the map, times max(1, |slope|)); 0 = the maxima as they are.
  *   y_amax       optional, [N][ps_conv1x1_stats_parts(M, T)]: partial maxima of |y| over the valid frames. */
 typedef struct ps_f16x2_range {
   int w_exp;
@@ -577,6 +587,7 @@ typedef struct ps_f16x2_range {
   const float* x_amax;
   int x_amax_parts;
   float* y_amax;
+  float amax_mul, amax_add;
 } ps_f16x2_range;
 int ps_conv1x1_f16x2_f32(const float* x, const void* wt_planes, const ps_f16x2_range* rng, float* y, int N, int K, int M,
                          int T, int ldt, const ps_prologue* pro, const float* bias, const float* bias_n,

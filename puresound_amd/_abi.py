@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PURESOUND_HIP_LIB: an experimental build of the same library (tools/build_variant.sh); kernel experiments only
 LIB_PATH = os.environ.get("PURESOUND_HIP_LIB") or os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -31,7 +31,8 @@ class Prologue(C.Structure):
 
 
 class F16x2Range(C.Structure):
-    _fields_ = [("w_exp", C.c_int), ("x_bound", C.c_float), ("x_amax", _vp), ("x_amax_parts", C.c_int), ("y_amax", _vp)]
+    _fields_ = [("w_exp", C.c_int), ("x_bound", C.c_float), ("x_amax", _vp), ("x_amax_parts", C.c_int), ("y_amax", _vp),
+                ("amax_mul", C.c_float), ("amax_add", C.c_float)]
 
 
 PS_MAX_CELLS = 8
@@ -100,6 +101,8 @@ SIGNATURES = {
     "ps_conv1x1_bf16_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 6 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
     "ps_dwconv_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp]),
     "ps_dwconv_io": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 8 + [C.POINTER(Prologue), _vp, _vp]),
+    "ps_dwconv_amax_ok": (C.c_int, [C.c_int] * 3),
+    "ps_dwconv_amax_f32": (C.c_int, [_vp] * 4 + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp]),
     "ps_conv1x1_bf16_io": (C.c_int, [_vp, C.c_int, _vp, _vp] + [C.c_int] * 7 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
     "ps_conv1x1_f16x2_f32": (C.c_int, [_vp, _vp, C.POINTER(F16x2Range), _vp] + [C.c_int] * 5 + [C.POINTER(Prologue), _vp, _vp, _vp, _vp, _vp]),
     "ps_absmax_parts": (C.c_int, []),

@@ -209,6 +209,12 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
   // hidden_bf16 (with gemm_planes = 1): y1, y2, y3 -- which never leave this workspace -- are bf16 rows; the block's
   // input and output (the residual stream) stay fp32
   const int hb = (b.hidden_bf16 && b.gemm_planes == 1) ? 1 : 0;
+  // gemm_planes = 2 behind a folded BatchNorm (bN1d blocks: no bound on the normalised values exists): the producers leave
+  // the maxima of |y2| / |y3| behind -- in the statistics slots such a norm has no use for -- and the consumer maps them
+  // through the norm's largest scale and shift
+  float* const a2 = (b.gemm_planes == 2 && b.dw_norm == PS_NORM_AFFINE) ? reinterpret_cast<float*>(w.s2) : nullptr;
+  float* const a3 = (b.gemm_planes == 2 && b.pw_norm == PS_NORM_AFFINE) ? reinterpret_cast<float*>(w.s3) : nullptr;
+  int a2_parts = 0;
   // `which` = 0 / 1 / 2: in_conv, pointwise, out_conv (gemm_planes = 2: each has its own range descriptor)
   auto gemm = [&](int which, const float* x, int xb, const float* wt, const void* wb, float* y, int yb, int K, int M,
                   const ps_prologue* pro, const float* bias, const float* bn, const float* res, double* st) {
@@ -216,15 +222,26 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
     if (b.gemm_planes == 2) {
       ps_f16x2_range rng{};
       rng.w_exp = b.w_exp[which];
+      const float gmax = which == 1 ? b.dw_gmax : b.pw_gmax, bmax = which == 1 ? b.dw_bmax : b.pw_bmax;
+      const float* measured = which == 1 ? a2 : a3;  // maxima of the producer's output in front of a folded BatchNorm
       if (which == 0) {
         rng.x_amax = x_amax;
         rng.x_amax_parts = x_amax_parts;
+      } else if (measured && gmax > 0.f) {
+        // behind a per-channel affine map: |scale_c v + shift_c| <= max|scale| max|v| + max|shift| (times max(1, |slope|),
+        // folded into gmax / bmax by the planner)
+        rng.x_amax = measured;
+        rng.x_amax_parts = which == 1 ? a2_parts : gemm_parts_h;
+        rng.amax_mul = gmax;
+        rng.amax_add = bmax;
+      } else if (measured) {
+        rng.x_bound = bmax > 0.f ? bmax : 1.f;  // (scale = 0: the map is the constant shift)
       } else {
         // behind a global norm |z| <= sqrt(count - 1), so |gamma z + beta| <= max|gamma| sqrt(count) + max|beta|
-        const float gmax = which == 1 ? b.dw_gmax : b.pw_gmax, bmax = which == 1 ? b.dw_bmax : b.pw_bmax;
         rng.x_bound = gmax * (float)sqrt(count) + bmax;
         if (!(rng.x_bound > 0.f)) rng.x_bound = 1.f;  // (gamma = beta = 0: every value is 0)
       }
+      if (which == 1) rng.y_amax = a3;
       if (which == 2) rng.y_amax = y_amax;
       return ps_conv1x1_f16x2_f32(x, wb, &rng, y, N, K, M, T, ldt, pro, bias, bn, res, st, stream);
     }
@@ -250,9 +267,11 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
     }
     return ps_conv1x1_bf16_io(x, xb, wb, y, yb, N, K, M, T, ldt, b.gemm_planes, pro, bias, bn, res, st, stream);
   };
-  if (b.gemm_planes == 2 && (b.dw_norm != PS_NORM_GLOBAL || b.pw_norm != PS_NORM_GLOBAL || !x_amax)) {
-    set_error("ps_conv_tasnet_f32: gemm_planes=2 (fp16x2) needs global norms in front of the pointwise and output convs "
-              "(their bound on the normalised values is what scales the activations into fp16's range)");
+  auto ranged = [](int norm) { return norm == PS_NORM_GLOBAL || norm == PS_NORM_AFFINE; };
+  if (b.gemm_planes == 2 && (!ranged(b.dw_norm) || !ranged(b.pw_norm) || !x_amax)) {
+    set_error("ps_conv_tasnet_f32: gemm_planes=2 (fp16x2) needs a global norm (a bound on the normalised values) or a "
+              "per-channel affine norm (the producer's measured maxima) in front of the pointwise and output convs, and the "
+              "range of the block's input");
     return PS_E_UNSUPPORTED;
   }
   if (b.gemm_planes != 0 && (!b.in_wb || !b.pw_wb || !b.out_wb)) {
@@ -280,8 +299,21 @@ static int run_block(const ps_tcn_block& b, const float* x_in, float* x_out, con
   p1.beta = b.in_beta;
   p1.slope = b.in_slope;
   const int left = b.causal ? (b.P - 1) * b.dilation : ((b.P - 1) / 2) * b.dilation;
-  rc = ps_dwconv_io(w.y1, hb, b.dw_w, b.dw_b, w.y2, hb, N, b.H, T, ldt, b.P, b.dilation, left, &p1,
-                    b.dw_norm == PS_NORM_GLOBAL ? w.s2 : nullptr, stream);
+  if (a2 && ps_dwconv_amax_ok(b.P, b.dilation, left)) {
+    rc = ps_dwconv_amax_f32(w.y1, b.dw_w, b.dw_b, w.y2, N, b.H, T, ldt, b.P, b.dilation, left, &p1, a2, stream);
+    a2_parts = dw_parts;
+  } else {
+    rc = ps_dwconv_io(w.y1, hb, b.dw_w, b.dw_b, w.y2, hb, N, b.H, T, ldt, b.P, b.dilation, left, &p1,
+                      b.dw_norm == PS_NORM_GLOBAL ? w.s2 : nullptr, stream);
+    if (!rc && a2) {  // (a shape outside the kernel that measures while it writes: one more pass over y2)
+      if ((size_t)ps_absmax_parts() * sizeof(float) > (size_t)w.parts * 2 * sizeof(double)) {
+        set_error("ps_conv_tasnet_f32: no room for the maxima of the depthwise output (T=%d)", T);
+        return PS_E_UNSUPPORTED;
+      }
+      rc = ps_absmax_f32(w.y2, a2, N, b.H, T, ldt, stream);
+      a2_parts = ps_absmax_parts();
+    }
+  }
   if (rc) return rc;
 
   // 3) pointwise: prologue = depthwise norm + PReLU; stats of y3

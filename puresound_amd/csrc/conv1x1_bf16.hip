@@ -94,6 +94,9 @@ struct BfArgs {
   const float* x_amax;
   int x_amax_parts;
   float* y_amax;
+  // the maxima are those of a producer whose output reaches the GEMM through a per-channel affine map + PReLU (a folded
+  // BatchNorm prologue): the range of f(x) is bounded by amax_mul * max |x| + amax_add (amax_mul = 0: the maxima as they are)
+  float amax_mul, amax_add;
 };
 
 // PLANES = 2: the scale pair of utterance n (every lane of the calling wave gets the same values)
@@ -104,6 +107,7 @@ __device__ __forceinline__ void f16_scales(const BfArgs& a, int n, int lane, flo
     const float* src = a.x_amax + (size_t)n * a.x_amax_parts;
     for (int i = lane; i < a.x_amax_parts; i += 64) m = fmaxf(m, src[i]);
     m = wave_max(m);
+    if (a.amax_mul > 0.f) m = m * a.amax_mul + a.amax_add;
     // max |x| in [2^e, 2^(e+1)) goes to [2^14, 2^15) (fp16 holds up to 65504); an all-zero utterance keeps 1
     int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255) - 127;
     e = e < -100 ? -100 : (e > 100 ? 100 : e);
@@ -1754,6 +1758,8 @@ extern "C" int ps_conv1x1_f16x2_ln_f32(const float* x, const void* wt_planes, co
   a.winv = ldexpf(1.f, -rng->w_exp);
   a.x_amax = rng->x_bound > 0.f ? nullptr : rng->x_amax;
   a.x_amax_parts = rng->x_amax_parts;
+  a.amax_mul = rng->amax_mul > 0.f ? rng->amax_mul : 0.f;
+  a.amax_add = rng->amax_add > 0.f ? rng->amax_add : 0.f;
   a.y_amax = rng->y_amax;  // [N][ps_conv1x1_stats_parts(256, T)] partial maxima of |y| (the next GEMM's input range) or NULL
   int Gr = 0;
   if (!rb_ok(a, N, &Gr)) {
@@ -1916,6 +1922,8 @@ static int split_gemm(const void* x_any, int x_bf16, const void* wt_planes, cons
       a.x_amax = rng->x_bound > 0.f ? nullptr : rng->x_amax;
       a.x_amax_parts = rng->x_amax_parts;
       a.y_amax = rng->y_amax;
+      a.amax_mul = rng->amax_mul > 0.f ? rng->amax_mul : 0.f;
+      a.amax_add = rng->amax_add > 0.f ? rng->amax_add : 0.f;
       if (fmajor) {
         int Gr = 0;
         a.fm_ld = fm_ld;

@@ -33,6 +33,7 @@ struct DwArgs {
   double* ostats;
   ps_prologue pro;
   int H, T, ldt, P, dilation, left;
+  float* amax;  // wave kernel, AMAX build: [N][ps_dwconv_stats_parts] partial maxima of |y|
 };
 
 // P > 0: compile-time tap count; P == 0: run-time taps.  ALIGNED: every tap offset is a multiple of 4 frames.
@@ -236,7 +237,9 @@ constexpr int DWW_NV = 5;                     // 16-byte pieces per lane: 4 + ha
 
 // B16: the rows of x AND y are bf16 in HBM (round 4: the hidden maps of a block whose activation rows are all bf16); the
 // LDS strip and the arithmetic stay fp32, a piece is 8 bytes per lane instead of 16.
-template <bool ALIGNED, bool B16 = false>
+// AMAX: instead of the (sum, sumsq) partials the workgroup leaves the maximum of |y| over its valid frames in a.amax (same
+// slots): what a following fp16x2 GEMM needs when the norm between them is a folded BatchNorm, not a global norm.
+template <bool ALIGNED, bool B16 = false, bool AMAX = false>
 __global__ __launch_bounds__(256, 8) void dwconv_wave_kernel(DwArgs a) {
   __shared__ __attribute__((aligned(16))) float strip[4][DWW_SEG];
   double* const red = reinterpret_cast<double*>(&strip[0][0]);  // the two reductions run before / after the strips are in use
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256, 8) void dwconv_wave_kernel(DwArgs a) {
   }
   const NormScalars ns = load_norm_scalars(a.pro, n, red);  // (the only workgroup barriers before the final reduction)
   __syncthreads();                                          // (red is strip 0: every thread has read its totals)
-  float fsum = 0.f, fsq = 0.f;
+  [[maybe_unused]] float fsum = 0.f, fsq = 0.f, famax = 0.f;
   auto process_row = [&](auto r_c, auto q_c) {
     constexpr int r = decltype(r_c)::value, q = decltype(q_c)::value;
     const int h = h0 + wave + 4 * r;
@@ -326,7 +329,10 @@ __global__ __launch_bounds__(256, 8) void dwconv_wave_kernel(DwArgs a) {
           f32x4 out;
 #pragma unroll
           for (int e = 0; e < 4; ++e) out[e] = ((bia[r] + w0[r] * s0[e]) + w1[r] * s1[e]) + w2[r] * s2[e];
-          if (t + 3 < a.T) {
+          if constexpr (AMAX) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) famax = fmaxf(famax, t + e < a.T ? fabsf(out[e]) : 0.f);
+          } else if (t + 3 < a.T) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               fsum += out[e];
@@ -361,7 +367,18 @@ __global__ __launch_bounds__(256, 8) void dwconv_wave_kernel(DwArgs a) {
   process_row(std::integral_constant<int, 2>{}, q0{});
   load_row(3, q0{});
   process_row(std::integral_constant<int, 3>{}, q0{});
-  if (a.ostats) {
+  if constexpr (AMAX) {
+    if (a.amax) {
+      famax = wave_max(famax);
+      __syncthreads();  // (every wave is done with its strip)
+      float* const mx = &strip[0][0];
+      if (lane == 0) mx[wave] = famax;
+      __syncthreads();
+      if (tid == 0)
+        a.amax[(size_t)n * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
+            fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+    }
+  } else if (a.ostats) {
     double s = fsum, q = fsq;
     __syncthreads();  // (every wave is done with its strip)
     block_sum2(s, q, red);
@@ -387,9 +404,33 @@ extern "C" int ps_dwconv_f32(const float* x, const float* w, const float* b, flo
   return ps_dwconv_io(x, 0, w, b, y, 0, N, H, T, ldt, P, dilation, left, pro, ostats, stream);
 }
 
+static int dwconv_any(const void* x_any, int x_bf16, const float* w, const float* b, void* y_any, int y_bf16, int N, int H, int T,
+                      int ldt, int P, int dilation, int left, const ps_prologue* pro, double* ostats, float* amax, void* stream);
+
 extern "C" int ps_dwconv_io(const void* x_any, int x_bf16, const float* w, const float* b, void* y_any, int y_bf16, int N,
                             int H, int T, int ldt, int P, int dilation, int left, const ps_prologue* pro, double* ostats,
                             void* stream) {
+  return dwconv_any(x_any, x_bf16, w, b, y_any, y_bf16, N, H, T, ldt, P, dilation, left, pro, ostats, nullptr, stream);
+}
+
+extern "C" int ps_dwconv_amax_ok(int P, int dilation, int left) {
+  return P == 3 && dilation > 0 && left >= 0 && left <= 2 * dilation && 2 * dilation <= 256 &&
+         ps::DW_FRAMES / 4 + ((left + 3) / 4 * 4 + 2 * dilation - left + 3) / 4 <= 64 * ps::DWW_NV;
+}
+
+extern "C" int ps_dwconv_amax_f32(const float* x, const float* w, const float* b, float* y, int N, int H, int T, int ldt, int P,
+                                  int dilation, int left, const ps_prologue* pro, float* y_amax, void* stream) {
+  using namespace ps;
+  if (!y_amax || !ps_dwconv_amax_ok(P, dilation, left)) {
+    set_error("ps_dwconv_amax_f32: the maxima are an output of the wave-private kernel only (P = 3, 2 * dilation <= 256; "
+              "ps_dwconv_amax_ok); got P=%d dilation=%d left=%d", P, dilation, left);
+    return PS_E_UNSUPPORTED;
+  }
+  return dwconv_any(x, 0, w, b, y, 0, N, H, T, ldt, P, dilation, left, pro, nullptr, y_amax, stream);
+}
+
+static int dwconv_any(const void* x_any, int x_bf16, const float* w, const float* b, void* y_any, int y_bf16, int N, int H, int T,
+                      int ldt, int P, int dilation, int left, const ps_prologue* pro, double* ostats, float* amax, void* stream) {
   using namespace ps;
   const float* x = (const float*)x_any;
   float* y = (float*)y_any;
@@ -416,6 +457,7 @@ extern "C" int ps_dwconv_io(const void* x_any, int x_bf16, const float* w, const
   a.b = b;
   a.y = y;
   a.ostats = ostats;
+  a.amax = amax;
   if (pro) {
     a.pro = *pro;
     if (a.pro.norm != PS_NORM_NONE && (!a.pro.gamma || !a.pro.beta)) {
@@ -447,7 +489,10 @@ extern "C" int ps_dwconv_io(const void* x_any, int x_bf16, const float* w, const
     const bool small = (P - 1) * dilation + 8 <= DW_SMALLHALO;
     const bool wave_ok = P == 3 && 2 * dilation <= 256 &&
                          DW_FRAMES / 4 + ((left + 3) / 4 * 4 + 2 * dilation - left + 3) / 4 <= 64 * DWW_NV && !(g_debug_flags & 1);
-    if (x_bf16 && y_bf16 && wave_ok) {  // (bit 0 keeps the workgroup-synchronised kernel: tests run both)
+    if (amax) {  // (ps_dwconv_amax_f32: fp32 rows, the wave-private kernel's shapes)
+      if (aligned) hipLaunchKernelGGL((dwconv_wave_kernel<true, false, true>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dwconv_wave_kernel<false, false, true>), grid, dim3(256), 0, st, a);
+    } else if (x_bf16 && y_bf16 && wave_ok) {  // (bit 0 keeps the workgroup-synchronised kernel: tests run both)
       if (aligned) hipLaunchKernelGGL((dwconv_wave_kernel<true, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((dwconv_wave_kernel<false, true>), grid, dim3(256), 0, st, a);
     } else if (x_bf16 || y_bf16) {

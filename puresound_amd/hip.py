@@ -271,10 +271,13 @@ def conv1x1_f16x2(x: torch.Tensor, t: int, wt_planes: torch.Tensor, w_exp: int, 
                   pro: Optional[Prologue] = None, bias: Optional[torch.Tensor] = None,
                   bias_n: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                   want_stats: bool = False, out: Optional[torch.Tensor] = None, x_bound: float = 0.0,
-                  x_amax: Optional[torch.Tensor] = None, want_amax: bool = False):
+                  x_amax: Optional[torch.Tensor] = None, want_amax: bool = False,
+                  amax_map: Optional[tuple] = None):
     """ps_conv1x1_f32's contract in the fp16x2 arithmetic (ps_conv1x1_f16x2_f32; weights from pack_wt_f16x2).
     x_bound / x_amax: how the activations are brought into fp16's range (see include/puresound_hip.h); x_amax is an
-    [N, parts] tensor of partial maxima (absmax(), or the y_amax of the producing launch).  Returns (y, stats, y_amax)."""
+    [N, parts] tensor of partial maxima (absmax(), or the y_amax of the producing launch); amax_map = (mul, add): the
+    maxima are those of x in front of an affine prologue whose output is bounded by mul * max|x| + add.
+    Returns (y, stats, y_amax)."""
     require_device(x, "conv1x1_f16x2")
     n, k, ldt = x.shape
     y = out if out is not None else torch.empty(n, m, ldt, dtype=torch.float32, device=x.device)
@@ -289,6 +292,8 @@ def conv1x1_f16x2(x: torch.Tensor, t: int, wt_planes: torch.Tensor, w_exp: int, 
         if x_amax.dim() != 2 or x_amax.shape[0] != n or not x_amax.is_contiguous():
             raise ValueError(f"conv1x1_f16x2: x_amax must be a contiguous [N={n}, parts] tensor, got {tuple(x_amax.shape)}")
     rng = F16x2Range(int(w_exp), float(x_bound), ptr(x_amax), x_amax.shape[1] if x_amax is not None else 0, ptr(amax))
+    if amax_map is not None:
+        rng.amax_mul, rng.amax_add = float(amax_map[0]), float(amax_map[1])
     check(lib().ps_conv1x1_f16x2_f32(ptr(x), ptr(wt_planes), C.byref(rng), ptr(y), n, k, m, t, ldt,
                                      C.byref(pro) if pro is not None else None, ptr(bias), ptr(bias_n), ptr(res),
                                      ptr(stats), stream_ptr(x.device)), "ps_conv1x1_f16x2_f32")
@@ -384,12 +389,19 @@ def conv1x1_bf16(x: torch.Tensor, t: int, wt_planes: torch.Tensor, m: int, pro: 
 
 def dwconv(x: torch.Tensor, t: int, w: torch.Tensor, b: Optional[torch.Tensor], dilation: int, left: int,
            pro: Optional[Prologue] = None, want_stats: bool = False,
-           out_dtype: Optional[torch.dtype] = None) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """x padded [N,H,ldt] (fp32 or bf16 rows), w [H,1,P] -> y padded [N,H,ldt] (+ partial stats)."""
+           out_dtype: Optional[torch.dtype] = None, want_amax: bool = False) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """x padded [N,H,ldt] (fp32 or bf16 rows), w [H,1,P] -> y padded [N,H,ldt] (+ partial stats; with want_amax the
+    partial maxima of |y| [N, parts] instead: ps_dwconv_amax_f32, fp32 rows, P = 3, 2 * dilation <= 256)."""
     require_device(x, "dwconv", allow_bf16=True)
     n, h, ldt = x.shape
     p = w.shape[-1]
     y = torch.zeros(n, h, ldt, dtype=out_dtype or x.dtype, device=x.device)
+    if want_amax:
+        amax = torch.empty(n, lib().ps_dwconv_stats_parts(h, t), dtype=torch.float32, device=x.device)
+        check(lib().ps_dwconv_amax_f32(ptr(x), ptr(w), ptr(b), ptr(y), n, h, t, ldt, p, dilation, left,
+                                       C.byref(pro) if pro is not None else None, ptr(amax), stream_ptr(x.device)),
+              "ps_dwconv_amax_f32")
+        return y, amax
     stats = None
     if want_stats:
         parts = lib().ps_dwconv_stats_parts(h, t)

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from .. import hip
 from ..ops import op_module, same_shape
-from .._abi import PS_NORM_GLOBAL, TcnBlock, ptr
+from .._abi import PS_NORM_AFFINE, PS_NORM_GLOBAL, TcnBlock, ptr
 from .lobe.cnn import DepthwiseSeparableConv1d
 from .lobe.norm import ChanLN, GlobLN, get_norm, norm_plan
 
@@ -95,10 +95,12 @@ class TCN(_PlanCache, nn.Module):
         if max(self.in_channels, self.hid_channels) > 512:
             return 0  # ps_conv1x1_bf16_f32 keeps prologue tables for up to 512 input channels: wider blocks run fp32
         if planes == 2:
-            # fp16x2 scales the activations of the pointwise / output convs by a bound on the normalised values: only a
-            # global norm (gLN, gGN) gives one.  Folded BatchNorm / cLN blocks take the three-plane bf16 split.
+            # fp16x2 scales the activations of the pointwise / output convs into fp16's range: behind a global norm (gLN,
+            # gGN) by a bound on the normalised values, behind an eval BatchNorm (bN1d: a per-channel affine map) by the
+            # maxima the producing kernel measured, mapped through the largest scale and shift.  cLN blocks (run stage by
+            # stage) take the three-plane bf16 split.
             dsc = self.dconv[0]
-            if not all(isinstance(m, (GlobLN, nn.GroupNorm)) for m in (dsc.depthwise[1], dsc.pointwise[1])):
+            if not all(isinstance(m, (GlobLN, nn.GroupNorm, nn.BatchNorm1d)) for m in (dsc.depthwise[1], dsc.pointwise[1])):
                 return 3
             if isinstance(self.in_conv[1], ChanLN):
                 return 3
@@ -151,7 +153,7 @@ class TCN(_PlanCache, nn.Module):
         b.hidden_bf16 = int(hb)
         rows_bf16 = bool(hb and self.stream_bf16)
         if planes == 2:
-            assert fused and kinds["dw"] == PS_NORM_GLOBAL and kinds["pw"] == PS_NORM_GLOBAL
+            assert fused and kinds["dw"] in (PS_NORM_GLOBAL, PS_NORM_AFFINE) and kinds["pw"] in (PS_NORM_GLOBAL, PS_NORM_AFFINE)
             for i, (key, wsrc) in enumerate((("in_wb", w_in[:, :c, 0]),
                                              ("pw_wb", dsc.pointwise[0].weight.detach().to(**f32)),
                                              ("out_wb", self.out_conv.weight.detach().to(**f32)))):

@@ -40,15 +40,18 @@ def test_weight_packer_two_fp16_planes_reconstruct_the_weight():
         H.pack_wt_f16x2(torch.full((2, 2), float("inf")))
 
 
-def test_fp16x2_blocks_fall_back_to_bf16x3_without_global_norms():
+def test_fp16x2_blocks_need_a_range_for_their_normalised_values():
     import puresound_amd.nnet.conv_tasnet as CT
     assert CT.GEMM_PLANES["fp16x2"] == 2
+    blk = CT.TCN(16, 8, 3, 1, causal=True, tcn_norm="cLN", dconv_norm="cLN").eval()
+    blk.gemm_precision = "fp16x2"
+    assert blk.gemm_planes_for_plan() == 3  # per-frame norms, run stage by stage -> the three-plane bf16 split
     blk = CT.TCN(16, 8, 3, 1, causal=True, tcn_norm="bN1d", dconv_norm="bN1d").eval()
     blk.gemm_precision = "fp16x2"
-    assert blk.gemm_planes_for_plan() == 3  # no bound on the normalised values -> the three-plane bf16 split
+    assert blk.gemm_planes_for_plan() == 2  # folded BatchNorm: the producers' measured maxima through its scale / shift
     blk = CT.TCN(16, 8, 3, 1).eval()
     blk.gemm_precision = "fp16x2"
-    assert blk.gemm_planes_for_plan() == 2
+    assert blk.gemm_planes_for_plan() == 2  # global norms: a bound on the normalised values
 
 
 # ---- device ------------------------------------------------------------------------------------------------------------

@@ -657,3 +657,96 @@ def test_wavefront_in_one_launch_per_diagonal_equals_one_branch_per_block(dev):
             pre = net.streaming_inference_chunk(wav[:, i * 320:(i + 1) * 320], emb, pre)
         outs.append(pre.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------------------
+# fp16x2 behind a folded BatchNorm (bN1d blocks): measured maxima mapped through the norm's scale / shift
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,h,t,dil,left", [(3, 40, 3000, 1, 2), (2, 512, 3999, 8, 16), (2, 64, 1500, 128, 256),
+                                            (2, 33, 700, 2, 2)])
+def test_dwconv_leaves_the_maxima_of_its_output(H, dev, n, h, t, dil, left):
+    """ps_dwconv_amax_f32: the same rows as ps_dwconv_f32 and partial maxima whose maximum is max |y| over the valid frames (affine prologue + PReLU in front, as inside a bN1d block)."""
+    from puresound_amd import _abi
+    x = H.pad_rows(_rand((n, h, t), 1101).to(dev) * 3)
+    w, b = _rand((h, 1, 3), 1102).to(dev), _rand((h,), 1103).to(dev)
+    keep = (_rand((h,), 1104, 0.2, 2.0).to(dev), _rand((h,), 1105).to(dev), torch.tensor([0.3], device=dev))
+    pro = H.make_prologue(_abi.PS_NORM_AFFINE, True, None, 0.0, 0.0, *keep)
+    want, _ = H.dwconv(x, t, w, b, dil, left, pro)
+    got, amax = H.dwconv(x, t, w, b, dil, left, pro, want_amax=True)
+    # (another build of the same kernel: the compiler contracts the tap sum into FMAs differently, one rounding apart)
+    assert rel_max(got[..., :t].cpu().numpy(), want[..., :t].cpu().numpy()) < 1e-6
+    assert amax.shape == (n, _abi.lib().ps_dwconv_stats_parts(h, t))
+    assert torch.equal(amax.max(1).values, got[..., :t].abs().amax((1, 2)))
+    with pytest.raises(RuntimeError, match="wave-private"):
+        H.dwconv(x, t, _rand((h, 1, 5), 1106).to(dev), b, 1, 2, pro, want_amax=True)
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-3, 2e3])
+@pytest.mark.parametrize("n,k,m,t", [(2, 64, 48, 300), (8, 512, 256, 3999), (4, 256, 512, 2000)])
+def test_fp16x2_gemm_behind_an_affine_norm_takes_mapped_maxima(H, dev, n, k, m, t, scale):
+    """ps_conv1x1_f16x2_f32 with a per-channel affine prologue + PReLU and the input's maxima mapped by (max |scale| f,
+    max |shift| f), f = max(1, |slope|): as close to fp64 as the exact-fp32 kernel, for inputs of very different size."""
+    from puresound_amd import _abi
+    x = (_rand((n, k, t), 1111) + 0.1) * scale
+    w, b = _rand((m, k), 1112, -0.2, 0.2), _rand((m,), 1113)
+    sc, sh = _rand((k,), 1114, -2.0, 2.0) / scale, _rand((k,), 1115, -0.5, 0.5)
+    for slope in (0.25, -1.7):
+        a = x.double() * sc.double().reshape(1, -1, 1) + sh.double().reshape(1, -1, 1)
+        a = torch.where(a >= 0, a, a * slope)
+        ref = torch.matmul(w.double(), a) + b.double().reshape(1, -1, 1)
+        xd = H.pad_rows(x.to(dev))
+        keep = (sc.to(dev), sh.to(dev), torch.tensor([slope], device=dev))
+        pro = H.make_prologue(_abi.PS_NORM_AFFINE, True, None, 0.0, 0.0, *keep)
+        y32, _ = H.conv1x1(xd, t, H.pack_wt(w.to(dev)), m, pro, b.to(dev))
+        wf, we = H.pack_wt_f16x2(w.to(dev))
+        f = max(1.0, abs(slope))
+        y, _, _ = H.conv1x1_f16x2(xd, t, wf, we, m, pro, b.to(dev), x_amax=H.absmax(xd, t),
+                                  amax_map=(float(sc.abs().max()) * f, float(sh.abs().max()) * f))
+        rms = float(ref.pow(2).mean().sqrt())
+        e32 = float((y32[..., :t].cpu().double() - ref).pow(2).mean().sqrt()) / rms
+        err = float((y[..., :t].cpu().double() - ref).pow(2).mean().sqrt()) / rms
+        assert torch.isfinite(y[..., :t]).all()
+        assert err < 1.5 * e32 + 1e-8, (slope, err, e32)
+
+
+def test_causal_bn_preset_runs_its_blocks_in_fp16x2(PA, dev, golden_dir):
+    """td_tse_conv_tasnet_v0_causal (bN1d TCN blocks): with the default arithmetic every such block plans gemm_planes = 2;
+    the result matches the reference's golden vector as before and the exact-fp32 arithmetic to 1e-5."""
+    import puresound_amd.nnet.conv_tasnet as CT
+    name = "cfg3_causal_short"
+    c = cases.CASES[name]
+    g = np.load(f"{golden_dir}/{name}.npz")
+    noisy = det_wave(c["seed"], c["B"], c["L"]).to(dev)
+    enroll = det_wave(c["seed"] + 1, c["B"], c["L_enroll"]).to(dev)
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    bn = [m for m in model.masker.modules() if isinstance(m, CT.TCN) and isinstance(m.dconv[0].depthwise[1], torch.nn.BatchNorm1d)]
+    assert len(bn) == 24 and all(m.gemm_planes_for_plan() == 2 for m in bn)
+    got = model.inference(noisy, enroll)
+    model.set_gemm_precision("fp32")
+    exact = model.inference(noisy, enroll)
+    assert _l2rel(got.cpu().numpy(), exact.cpu().numpy()) < 1e-5
+    assert rel_max(got.cpu().numpy(), g["wav"]) < 2e-5
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 1e6])
+@pytest.mark.parametrize("dilation", [1, 8, 128])
+def test_bn_block_in_fp16x2_over_input_scales(PA, dev, scale, dilation):
+    """One causal bN1d block with checkpoint-like weights ("wild": BatchNorm gains over 2^-4 .. 2^4, PReLU slopes up to 3,
+    weight rows spanning 2^18) on inputs of very different size: the fp16x2 arithmetic (maxima measured by the depthwise /
+    pointwise kernels, mapped through the norm) equals the exact-fp32 arithmetic to fp32 rounding.  (A whole STACK of such
+    blocks with such weights diverges in every arithmetic -- nothing normalises -- so the preset test uses plain weights.)"""
+    import puresound_amd.nnet.conv_tasnet as CT
+    blk = CT.TCN(256, 512, 3, dilation, causal=True, tcn_norm="bN1d", dconv_norm="bN1d").eval()
+    blk.load_state_dict(det_state_dict(blk, mode="wild"))
+    blk.to(dev)
+    x = (_rand((3, 256, 1500), 1201) * scale).to(dev)
+    outs = {}
+    for prec in ("fp32", "fp16x2"):
+        blk.gemm_precision = prec
+        blk._plan = None
+        assert blk.gemm_planes_for_plan() == (2 if prec == "fp16x2" else 0)
+        outs[prec] = blk(x)
+    assert torch.isfinite(outs["fp16x2"]).all()
+    assert rel_max(outs["fp16x2"].cpu().numpy(), outs["fp32"].cpu().numpy()) < 4e-6
