@@ -66,6 +66,19 @@ def cfg3(dev, steps=5, warmup=2, modes=("fp16x2", "bf16"), batch=32):
         out[prec] = {"ms": ms, "samples_s": batch * L / ms * 1e3,
                      "l2_rel_vs_fp32": float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref)),
                      "algorithmic_bytes": alg[prec], "roofline_frac": alg[prec] / (ms * 1e-3) / 8e12}
+    if "fp16x2" in modes:
+        # td_tse_conv_tasnet_v0_causal (egs/tse/model.py:142-183: bN1d blocks, causal): same bytes, the fp16x2 ranges behind
+        # the folded BatchNorms come from maxima the producing kernels measure
+        del model
+        causal = _build("cfg3_causal_short", dev)
+        causal.hip_streams = 1
+        causal.set_gemm_precision("fp32")
+        ref = causal.inference(noisy, enroll)
+        causal.set_gemm_precision("fp16x2")
+        ms, y = _timed(lambda: causal.inference(noisy, enroll), steps, warmup)
+        out["causal_bn_fp16x2"] = {"workload": "td_tse_conv_tasnet_v0_causal", "ms": ms, "samples_s": batch * L / ms * 1e3,
+                                   "l2_rel_vs_fp32": float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref)),
+                                   "algorithmic_bytes": alg["fp16x2"], "roofline_frac": alg["fp16x2"] / (ms * 1e-3) / 8e12}
     return out
 
 
