@@ -1436,8 +1436,9 @@ def test_simo_wrapper_matches_reference_on_hip(PA, dev, golden_dir, name):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["tiny_free", "tiny_free_relu_causal", "tiny_stft", "cfg1_short", "cfg2_short", "cfg3_short",
                                   "cfg4_short", "cfg4_tse_short", "tse_unet_tcn_causal_short", "tse_unet_tcn_short",
-                                  "ns_dpcrn_short", "ns_dparn_short", "tse_skim_causal_short", "tse_skim_fbank_short"])
-@pytest.mark.parametrize("gemm", ["fp32", "bf16x3"])
+                                  "ns_dpcrn_short", "ns_dparn_short", "tse_skim_causal_short", "tse_skim_fbank_short",
+                                  "cfg3_causal_short"])
+@pytest.mark.parametrize("gemm", ["fp32", "bf16x3", "fp16x2"])
 def test_results_do_not_depend_on_uninitialised_memory(PA, dev, golden_dir, name, gemm):
     c = cases.CASES[name]
     g = _load(golden_dir, name)
@@ -1463,7 +1464,7 @@ def test_results_do_not_depend_on_uninitialised_memory(PA, dev, golden_dir, name
 # ------------------------------------------------------------------------------------------------
 # hipGraph replay of a whole inference call (small batches)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["tiny_free", "cfg2_short", "cfg3_short", "cfg4_short"])
+@pytest.mark.parametrize("name", ["tiny_free", "cfg2_short", "cfg3_short", "cfg4_short", "cfg3_causal_short"])
 def test_graphed_inference_is_bit_identical(PA, dev, name):
     from puresound_amd.graphs import GraphedInference
     c = cases.CASES[name]
