@@ -243,9 +243,14 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
             loss = SDRLoss.init_mode("sisnr")
         if not isinstance(loss, SDRLoss) or loss.source_aggregated:
             raise NotImplementedError("inference_scored: an SDRLoss on [N, L] signals (not a source-aggregated mode)")
-        hip.require_device(ref_clean, "SoTaskWrapModule.inference_scored")
         if ref_clean.dim() != 2 or ref_clean.shape[0] != noisy.shape[0]:
             raise RuntimeError("inference_scored: ref_clean must be [N, L_ref] with the batch of `noisy`")
+        if noisy.device.type == "cpu":  # (the recipes' --backend cpu: stock ATen forward, the moments as five fp64 sums)
+            enh = self.inference(noisy, enroll)
+            a, b = enh.double(), hip.align_reference(ref_clean, enh.shape[-1]).double()
+            moments = torch.stack([a.sum(-1), b.sum(-1), (a * a).sum(-1), (b * b).sum(-1), (a * b).sum(-1)], -1)
+            return enh, loss.from_moments(moments, enh.shape[-1], inactive_labels)
+        hip.require_device(ref_clean, "SoTaskWrapModule.inference_scored")
         enh, moments = self._inference(noisy, enroll, ref_clean.float())
         return enh, loss.from_moments(moments, enh.shape[-1], inactive_labels)
 

@@ -109,3 +109,23 @@ def test_a_traced_cpu_module_replays():
     buf.seek(0)
     again = torch.jit.load(buf)
     assert torch.equal(again(x), enc(x))
+
+
+def test_inference_scored_on_cpu_tensors(PA):
+    """wrapper.inference_scored on CPU tensors: the waveform of inference() and the SI-SNR (loss/sdr.py:104-183 with the
+    "sisnr" flags) of it against a shorter, left-padded reference (base_nn.py:398-412), written out here in fp64."""
+    name = "tiny_free"
+    c = cases.CASES[name]
+    model = _model(PA, name)
+    noisy = det_wave(c["seed"], c["B"], c["L"])
+    want = model.inference(noisy)
+    ref = (0.6 * want + 0.05 * det_wave(c["seed"] + 5, c["B"], want.shape[-1]))[:, :-7]
+    enh, score = model.inference_scored(noisy, ref, loss_func=PA.NS.SDRLoss.init_mode("sisnr", reduction=False))
+    assert torch.equal(enh, want)
+    a = want.double()
+    b = torch.nn.functional.pad(ref, (7, 0)).double()
+    a, b = a - a.mean(-1, keepdim=True), b - b.mean(-1, keepdim=True)
+    alpha = (a * b).sum(-1, keepdim=True) / ((b * b).sum(-1, keepdim=True) + 1e-8)
+    tgt = alpha * b
+    snr = 10 * torch.log10((tgt * tgt).sum(-1, keepdim=True) / (((a - tgt) ** 2).sum(-1, keepdim=True) + 1e-8) + 1e-8)
+    np.testing.assert_allclose(score.numpy(), (-snr).float().numpy(), atol=2e-3, rtol=0)
