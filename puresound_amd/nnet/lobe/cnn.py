@@ -49,8 +49,6 @@ class DepthwiseSeparableConv1d(nn.Module):
         """x [N, C, T] -> [N, out_channels, T] (cnn.py:84-106): [in_conv] -> depthwise -> pointwise (each conv + norm +
         PReLU) [+ skip_conv(x)].  Causal: the reference pads both sides and cuts the tail, i.e. left padding only."""
         hip.require_device(x, "DepthwiseSeparableConv1d.forward")
-        if self.stride != 1 and self.causal:
-            raise NotImplementedError("DepthwiseSeparableConv1d on HIP: stride != 1 with causal=True (no recipe strides at all)")
         if self.stride != 1 and self.skip:
             # the reference adds skip_conv(x) of length T to a result of length ~T / stride: torch's broadcasting error
             raise RuntimeError("The size of tensor a must match the size of tensor b at non-singleton dimension 2 "
@@ -100,8 +98,18 @@ class DepthwiseSeparableConv1d(nn.Module):
                 # Conv1d(stride=s) is every s-th frame of the stride-1 result (cnn.py:62-71): the stride-1 kernel, a strided
                 # copy (no recipe takes this path), the norm's statistics over the frames that remain
                 lf = t + 2 * self.padding - self.dilation * (self.kernel - 1)      # stride-1 output length
-                y = hip.pad_rows(y[..., :lf][..., ::self.stride].contiguous())
-                t = (lf + self.stride - 1) // self.stride
+                keep_t = (lf + self.stride - 1) // self.stride
+                if self.causal:
+                    # both-sided padding, every s-th frame, the last `padding` frames cut at the end (cnn.py:100-101).  The
+                    # causal norms are frame-local (gLN / gGN are refused by the constructor), so cutting here is the same;
+                    # every frame that is kept lies inside the T frames the left-padded stride-1 kernel produces
+                    keep_t -= self.padding
+                    if keep_t <= 0:
+                        raise RuntimeError(f"DepthwiseSeparableConv1d(causal, stride={self.stride}): {t} frames leave "
+                                           f"none behind the cut of {self.padding} (the reference returns an empty tensor)")
+                    lf = t
+                y = hip.pad_rows(y[..., :lf][..., ::self.stride][..., :keep_t].contiguous())
+                t = keep_t
                 ldt = y.shape[-1]
                 st = hip.row_stats(y, t) if nk[0] == PS_NORM_GLOBAL else None
             a, pro = settle(y, st, nk, slope, h)

@@ -257,6 +257,12 @@ CASES = {
                             kw=dict(hid_channels=18, norm_cls="gLN", kernel=3, dilation=2, stride=2), B=2, T=71, seed=65),
     "dsc_stride3_cln": dict(kind="lobe", cls="DepthwiseSeparableConv1d", args=(10, 14),
                             kw=dict(norm_cls="cLN", kernel=5, dilation=1, stride=3), B=2, T=50, seed=66),
+    # causal with a stride: both-sided padding, every s-th frame, the last `padding` frames cut (cnn.py:62-71, 100-101)
+    "dsc_stride2_causal_bn": dict(kind="lobe", cls="DepthwiseSeparableConv1d", args=(10, 12),
+                                  kw=dict(hid_channels=16, norm_cls="bN1d", kernel=3, dilation=2, stride=2, causal=True),
+                                  B=2, T=53, seed=67, bn_stats=True),
+    "dsc_stride3_causal_cln": dict(kind="lobe", cls="DepthwiseSeparableConv1d", args=(10, 14),
+                                   kw=dict(norm_cls="cLN", kernel=2, dilation=3, stride=3, causal=True), B=2, T=40, seed=68),
     # ---- recurrent maskers, module level: T mod K in {0, 1, K-1}, causal / bidirectional, FiLM / Gate
     # conditioning, embedding-free TSE (embed = enrolment features), overlapped segments
     "dprnn_causal_r0": dict(kind="rnn", cls="DPRNN", args=(16, 8, 16), kw=dict(n_blocks=2, seg_size=5, causal=True),
