@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 20
+#define PS_ABI_VERSION 21
 
 #define PS_E_INVALID (-1)     /* bad shape / null pointer / unsupported combination */
 #define PS_E_ALIGN (-2)       /* ldt or a pointer violates the alignment contract */
@@ -395,6 +395,17 @@ int ps_lstm_fmajor_ok(const ps_lstm_args* args, int ldm);
  * state_shift as ps_lstm_f32.  hout [N][D*H][ldt]. */
 int ps_lstm_fmajor_h256_ok(const ps_lstm_args* args, int ldm);
 int ps_lstm_fmajor_h256_f16x2_f32(const ps_lstm_args* args, int ldm, const void* whh_image, const float* acc_scale, void* stream);
+/* The same recurrence for FEW sequences and many steps (the speaker LSTM of tse_skim_v1: SingleRNN over all frames,
+ * lobe/rnn.py:9-55; SkiM's Mem-LSTMs, skim.py:117-170): every group of 16 sequences is spread over H / 32 workgroups on
+ * CUs of their own, each holding its 32 hidden units' rows of W_hh in registers for the whole launch and exchanging h' with
+ * the others through L2 every step (one counter per group, bounded polls: a launch whose workgroups are not all resident at
+ * once -- the launcher refuses such grids -- would raise the error word behind the counters instead of hanging).  Same
+ * arguments, weight image and results class as ps_lstm_fmajor_h256_f16x2_f32, plus a scratch buffer of
+ * ps_lstm_fmajor_coop_workspace_bytes(args, ldm) bytes, 256-byte aligned; 0 bytes = the launch does not qualify (more than
+ * CUs / (D * H / 32) groups, or fewer than two steps): PS_E_UNSUPPORTED, take the streamed kernel. */
+size_t ps_lstm_fmajor_coop_workspace_bytes(const ps_lstm_args* args, int ldm);
+int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, const void* whh_image, const float* acc_scale,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 int ps_lstm_fmajor_f16x2_f32(const ps_lstm_args* args, int ldm, void* stream);
 
 /* 50 % overlapped segmentation of the dual-path maskers (SplitMerge.split / merge, lobe/trivial.py:178-241; SkiM.split /

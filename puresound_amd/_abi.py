@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PURESOUND_HIP_LIB: an experimental build of the same library (tools/build_variant.sh); kernel experiments only
 LIB_PATH = os.environ.get("PURESOUND_HIP_LIB") or os.path.join(_HERE, "libpuresound_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 PS_NORM_NONE, PS_NORM_GLOBAL, PS_NORM_AFFINE = 0, 1, 2
 PS_ACT = {"linear": 0, "relu": 1, "sigmoid": 2}
@@ -119,6 +119,8 @@ SIGNATURES = {
     "ps_lstm_fmajor_f16x2_f32": (C.c_int, [C.POINTER(LstmArgs), C.c_int, _vp]),
     "ps_lstm_fmajor_h256_ok": (C.c_int, [C.POINTER(LstmArgs), C.c_int]),
     "ps_lstm_fmajor_h256_f16x2_f32": (C.c_int, [C.POINTER(LstmArgs), C.c_int, _vp, C.POINTER(C.c_float), _vp]),
+    "ps_lstm_fmajor_coop_workspace_bytes": (C.c_size_t, [C.POINTER(LstmArgs), C.c_int]),
+    "ps_lstm_fmajor_coop_f16x2_f32": (C.c_int, [C.POINTER(LstmArgs), C.c_int, _vp, C.POINTER(C.c_float), _vp, C.c_size_t, _vp]),
     "ps_unfold_taps_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 7 + [_vp, _vp, _vp, C.c_int, _vp]),
     "ps_unfold_taps_out_f32": (C.c_int, [_vp, _vp] + [C.c_int] * 8 + [_vp, _vp, _vp, C.c_int, _vp]),
     "ps_gated_product_f32": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 4 + [C.POINTER(Prologue), C.POINTER(Prologue), _vp]),

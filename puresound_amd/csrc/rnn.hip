@@ -1160,6 +1160,7 @@ typedef unsigned u32x4l __attribute__((ext_vector_type(4)));
 #include "lstm_fm.inc"
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #include "lstm_fm256.inc"
+#include "lstm_coop.inc"
 
 }  // namespace ps
 
@@ -1224,6 +1225,73 @@ extern "C" int ps_lstm_fmajor_h256_f16x2_f32(const ps_lstm_args* args, int ldm, 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("ps_lstm_fmajor_h256_f16x2_f32: launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+// the cooperative kernel: the streamed kernel's shapes, few enough sequence groups that every slice of every group gets a CU
+// of its own at the same time (the group barrier spins: co-residency is a correctness condition, not a tuning choice)
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* p, int n) {
+  for (int i = threadIdx.x; i < n; i += 256) p[i] = 0u;
+}
+
+static int lstm_coop_groups(const ps_lstm_args& a, int ldm) {
+  if (!lstm_h256_fits(a, ldm) || a.steps < 2) return 0;
+  const long long groups = ((long long)a.N * a.Q + 15) / 16;
+  return (groups * a.D + 7) / 8 * 8 * (a.H / 32) <= device_cus() ? (int)groups : 0;
+}
+
+extern "C" size_t ps_lstm_fmajor_coop_workspace_bytes(const ps_lstm_args* args, int ldm) {
+  const int groups = args ? lstm_coop_groups(*args, ldm) : 0;
+  if (!groups) return 0;
+  const size_t hx = align_up((size_t)2 * args->D * groups * 2 * 16 * (args->H + 8) * sizeof(_Float16), 256);
+  return hx + align_up((size_t)(args->D * groups * (2 + args->H / 32) + 1) * sizeof(unsigned), 256);
+}
+
+extern "C" int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, const void* whh_image, const float* acc_scale,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+  if (!args || !whh_image || !acc_scale || !workspace || ((uintptr_t)whh_image & 15) || ((uintptr_t)workspace & 255)) {
+    set_error("ps_lstm_fmajor_coop_f16x2_f32: null argument, unaligned weight image or workspace (256 bytes)");
+    return PS_E_INVALID;
+  }
+  const size_t need = ps_lstm_fmajor_coop_workspace_bytes(args, ldm);
+  if (!need) {
+    set_error("ps_lstm_fmajor_coop_f16x2_f32: ps_lstm_fmajor_h256_f16x2_f32's shapes with at most %d / (D * H / 32) groups of 16 "
+              "sequences and at least two steps (ps_lstm_fmajor_coop_workspace_bytes = 0)", device_cus());
+    return PS_E_UNSUPPORTED;
+  }
+  if (workspace_bytes < need) {
+    set_error("ps_lstm_fmajor_coop_f16x2_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return PS_E_INVALID;
+  }
+  const ps_lstm_args& a = *args;
+  const int groups = lstm_coop_groups(a, ldm);
+  const size_t hx = align_up((size_t)2 * a.D * groups * 2 * 16 * (a.H + 8) * sizeof(_Float16), 256);
+  LstmCoop k{a, ldm, whh_image, {acc_scale[0], a.D > 1 ? acc_scale[1] : acc_scale[0]}, (_Float16*)workspace,
+             (unsigned*)((char*)workspace + hx), groups, (g_debug_flags & (1 << 19)) ? 0 : 1, (g_debug_flags & (1 << 18)) ? 1 : 0};
+  if (!(k.up[0] > 0.f) || !(k.up[1] > 0.f)) {
+    set_error("ps_lstm_fmajor_coop_f16x2_f32: accumulator scales must be positive");
+    return PS_E_INVALID;
+  }
+  // (a kernel, not hipMemsetAsync: inside a replayed graph a memset node does not have to go through the L2 the counters'
+  //  atomics work in -- the first graph replays of this launch computed with the previous replay's counts)
+  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, k.sync, (int)((need - hx) / sizeof(unsigned)));
+  hipError_t e;
+  {
+    LaunchTimer timer("lstm", (hipStream_t)stream);
+    // clusters (direction, group) in rounds of 8, one per XCD; H / 32 slices each
+    dim3 grid((unsigned)((a.D * groups + 7) / 8 * (a.H / 32) * 8));
+    if (a.H == 256)
+      hipLaunchKernelGGL((lstm_coop_kernel<256>), grid, dim3(128), 0, (hipStream_t)stream, k);
+    else
+      hipLaunchKernelGGL((lstm_coop_kernel<192>), grid, dim3(128), 0, (hipStream_t)stream, k);
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("ps_lstm_fmajor_coop_f16x2_f32: launch failed: %s", hipGetErrorString(e));
     return (int)e;
   }
   return 0;

@@ -617,9 +617,48 @@ def lstm_fmajor_h256(gx_fm: torch.Tensor, whh_image: torch.Tensor, acc_scale, di
     a.N, a.H, a.D, a.Q, a.q_stride, a.steps, a.step_stride = n, hidden, dirs, q, q_stride, steps, step_stride
     a.ldt, a.ldq, a.state_shift = ldt, ldq, state_shift
     sc = (C.c_float * 2)(float(acc_scale[0]), float(acc_scale[-1]))
-    check(lib().ps_lstm_fmajor_h256_f16x2_f32(C.byref(a), ldm, ptr(whh_image), sc, stream_ptr(gx_fm.device)),
-          "ps_lstm_fmajor_h256_f16x2_f32")
+    # few sequence groups (a speaker LSTM over all frames, SkiM's Mem-LSTMs): the cooperative kernel -- W_hh resident in the
+    # registers of H / 32 CUs per group -- instead of streaming 1 MiB of it through one CU every step
+    ws_bytes = lib().ps_lstm_fmajor_coop_workspace_bytes(C.byref(a), ldm) if COOP_LSTM else 0
+    if ws_bytes:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=gx_fm.device)
+        check(lib().ps_lstm_fmajor_coop_f16x2_f32(C.byref(a), ldm, ptr(whh_image), sc, ptr(ws), ws_bytes,
+                                                  stream_ptr(gx_fm.device)), "ps_lstm_fmajor_coop_f16x2_f32")
+        _COOP_LAST[0] = ws   # (tests read the error word behind the counters: its last four bytes' block)
+    else:
+        check(lib().ps_lstm_fmajor_h256_f16x2_f32(C.byref(a), ldm, ptr(whh_image), sc, stream_ptr(gx_fm.device)),
+              "ps_lstm_fmajor_h256_f16x2_f32")
     return (hout, (h_last, c_last)) if h_last is not None else (hout, None)
+
+
+COOP_LSTM = os.environ.get("PS_COOP_LSTM", "1") != "0"   # 0: always the streamed-weight kernel
+_COOP_LAST = [None]
+
+
+def coop_lstm_error_word(dirs: int, groups: int, hidden: int) -> int:
+    """The error word of the last cooperative LSTM launch's workspace (1 = a group barrier gave up waiting); synchronises."""
+    ws = _COOP_LAST[0]
+    if ws is None:
+        return 0
+    hx = (2 * dirs * groups * 2 * 16 * (hidden + 8) * 2 + 255) // 256 * 256
+    return int(ws.view(torch.int32)[hx // 4 + dirs * groups])
+
+
+def coop_lstm_xcd_ids(dirs: int, groups: int, hidden: int) -> torch.Tensor:
+    """[D * groups, H / 32]: the XCD every slice of the last cooperative launch ran on (the light group barrier needs each
+    row constant: tests check it on the target part)."""
+    ws = _COOP_LAST[0]
+    hx = (2 * dirs * groups * 2 * 16 * (hidden + 8) * 2 + 255) // 256 * 256
+    first = hx // 4 + dirs * groups + 1
+    return ws.view(torch.int32)[first:first + dirs * groups * (hidden // 32)].reshape(dirs * groups, hidden // 32).cpu()
+
+
+def coop_lstm_xcd_masks(dirs: int, groups: int, hidden: int) -> torch.Tensor:
+    """[D * groups]: per cluster the OR of 1 << XCD over its slices (one bit = the cluster took the light barrier)."""
+    ws = _COOP_LAST[0]
+    hx = (2 * dirs * groups * 2 * 16 * (hidden + 8) * 2 + 255) // 256 * 256
+    first = hx // 4 + dirs * groups + 1 + dirs * groups * (hidden // 32)
+    return ws.view(torch.int32)[first:first + dirs * groups].cpu()
 
 
 def chan_layernorm(x: torch.Tensor, t: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float,

@@ -335,11 +335,43 @@ def test_unfold2d_batches_beyond_the_grid_limit(H, dev):
     (False, 2, 3, 30, 0, 1e-3, 256),   # vanishing recurrent weights, more steps
     (True, 3, 1, 90, 0, 1.0, 192),     # H = 192 (6 waves): one sequence per utterance over 90 frames, both directions
     (False, 2, 4, 9, 0, 1.0, 192),
+    (True, 32, 1, 300, 0, 1.0, 192),   # the speaker LSTM of tse_skim_v1 in small: 32 sequences (two groups), 300 steps
 ])
-def test_lstm_h256_streamed_weights_kernel(H, dev, bi, n, s, k, shift, wscale, hid):
+@pytest.mark.parametrize("coop", [False, True, "agent-scope fences", "scattered"])
+def test_lstm_h256_streamed_weights_kernel(H, dev, bi, n, s, k, shift, wscale, hid, coop):
     """ps_lstm_fmajor_h256_f16x2_f32 (H = 256: W_hh streamed from its packed image, frame-major pre-activations, initial and
     final states) on SkiM's segment layout (q = segment, k consecutive frames each) against the oracle's LSTM and the generic
-    fp32 kernel."""
+    fp32 kernel -- and the same launches on ps_lstm_fmajor_coop_f16x2_f32 (W_hh resident in the registers of H / 32 CUs per
+    group of 16 sequences, h' exchanged through L2 every step; its error word must stay 0)."""
+    from puresound_amd import _abi
+    old_coop = H.COOP_LSTM
+    H.COOP_LSTM = bool(coop)
+    H._COOP_LAST[0] = None
+    # bit 19: the memory model's agent-scope fences at every barrier; bit 18: a cluster's slices on consecutive workgroup ids,
+    # i.e. on different XCDs -- the kernel must notice (more than one bit in the cluster's mask) and take those fences itself
+    old_flags = _abi.lib().ps_debug_flags({"agent-scope fences": 1 << 19, "scattered": 1 << 18}.get(coop, 0))
+    try:
+        _lstm_h256_case(H, dev, bi, n, s, k, shift, wscale, hid)
+        if coop:
+            assert H._COOP_LAST[0] is not None, "the cooperative kernel did not run"
+            d, groups = 2 if bi else 1, (n * s + 15) // 16
+            assert H.coop_lstm_error_word(d, groups, hid) == 0
+            ids = H.coop_lstm_xcd_ids(d, groups, hid)   # the XCD every slice ran on, and per cluster the OR of 1 << XCD
+            masks = H.coop_lstm_xcd_masks(d, groups, hid)
+            for row, m in zip(ids.tolist(), masks.tolist()):
+                assert m == sum(1 << x for x in set(row)), (row, m)
+            if coop == "scattered":
+                assert all(len(set(row)) > 1 for row in ids.tolist()), ids    # (different XCDs: the heavy barrier was taken)
+            elif coop is True:
+                assert all(len(set(row)) == 1 for row in ids.tolist()), ids   # alone on the chip: one XCD per cluster
+        else:
+            assert H._COOP_LAST[0] is None
+    finally:
+        H.COOP_LSTM = old_coop
+        _abi.lib().ps_debug_flags(old_flags)
+
+
+def _lstm_h256_case(H, dev, bi, n, s, k, shift, wscale, hid):
     import torch.nn as nn
     from oracle import dualpath_oracle as DP
     from puresound_amd.nnet._plans import lstm_plan
@@ -366,7 +398,7 @@ def test_lstm_h256_streamed_weights_kernel(H, dev, bi, n, s, k, shift, wscale, h
     hout, (hl, cl) = H.lstm_fmajor_h256(gx_fm, img, scale, d, s, k, k, 1, to_state(h0), to_state(c0), want_state=True,
                                         state_shift=shift)
     torch.cuda.synchronize()
-    tol = 2e-5 if k < 20 else 1e-4
+    tol = 2e-5 if k < 20 else (1e-4 if k < 200 else 3e-4)
     e = (rel_max(hout[..., :t].cpu().numpy(), base[..., :t].cpu().numpy()), rel_max(back(hl).numpy(), back(bh).numpy()),
          rel_max(back(cl).numpy(), back(bc).numpy()))
     assert max(e) < tol, e
