@@ -1271,7 +1271,8 @@ extern "C" int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, 
   const int groups = lstm_coop_groups(a, ldm);
   const size_t hx = align_up((size_t)2 * a.D * groups * 2 * 16 * (a.H + 8) * sizeof(_Float16), 256);
   LstmCoop k{a, ldm, whh_image, {acc_scale[0], a.D > 1 ? acc_scale[1] : acc_scale[0]}, (_Float16*)workspace,
-             (unsigned*)((char*)workspace + hx), groups, (g_debug_flags & (1 << 19)) ? 0 : 1, (g_debug_flags & (1 << 18)) ? 1 : 0};
+             (unsigned*)((char*)workspace + hx), groups, (g_debug_flags & (1 << 19)) ? 0 : 1, (g_debug_flags & (1 << 18)) ? 1 : 0,
+             (g_debug_flags & (1 << 17)) ? 1 : 0};
   if (!(k.up[0] > 0.f) || !(k.up[1] > 0.f)) {
     set_error("ps_lstm_fmajor_coop_f16x2_f32: accumulator scales must be positive");
     return PS_E_INVALID;

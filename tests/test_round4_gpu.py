@@ -782,3 +782,32 @@ def test_bn_block_in_fp16x2_over_input_scales(PA, dev, scale, dilation):
         outs[prec] = blk(x)
     assert torch.isfinite(outs["fp16x2"]).all()
     assert rel_max(outs["fp16x2"].cpu().numpy(), outs["fp32"].cpu().numpy()) < 4e-6
+
+
+def test_cooperative_lstm_gives_up_loudly(H, dev):
+    """A group barrier that one slice never reaches (ps_debug_flags bit 17) runs into its bound instead of spinning for
+    ever: the launch ends, the error word is set and the result is NaN from the first step on -- and the next launch is fine."""
+    import torch.nn as nn
+    from puresound_amd import _abi
+    from puresound_amd.nnet._plans import lstm_plan
+    hid, c, n, k = 256, 12, 4, 6
+    m = nn.LSTM(c, hid, num_layers=1, bidirectional=False, batch_first=True)
+    m.load_state_dict({kk: _rand(tuple(v.shape), 1300 + i, -0.2, 0.2) for i, (kk, v) in enumerate(m.state_dict().items())})
+    p = lstm_plan(m.to(dev), torch.device(dev))
+    xp = H.pad_rows(_rand((n, c, k), 1310).to(dev))
+    gx, _ = H.conv1x1(xp, k, p["wih"], p["rows"], None, p["bias"])
+    gx_fm = gx.transpose(1, 2).contiguous()
+    img, scale = H.pack_whh_h256(p["whh_t"])
+    assert H.COOP_LSTM
+    good, _ = H.lstm_fmajor_h256(gx_fm, img, scale, 1, 1, k, k, 1)
+    assert H.coop_lstm_error_word(1, 1, hid) == 0 and torch.isfinite(good[..., :k]).all()
+    old = _abi.lib().ps_debug_flags(1 << 17)
+    try:
+        bad, _ = H.lstm_fmajor_h256(gx_fm, img, scale, 1, 1, k, k, 1)
+        torch.cuda.synchronize()
+    finally:
+        _abi.lib().ps_debug_flags(old)
+    assert H.coop_lstm_error_word(1, 1, hid) == 1
+    assert torch.isnan(bad[..., :k]).all()
+    again, _ = H.lstm_fmajor_h256(gx_fm, img, scale, 1, 1, k, k, 1)
+    assert H.coop_lstm_error_word(1, 1, hid) == 0 and torch.equal(again[..., :k], good[..., :k])
