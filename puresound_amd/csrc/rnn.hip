@@ -1238,17 +1238,24 @@ __global__ __launch_bounds__(256) void zero_words_kernel(unsigned* p, int n) {
   for (int i = threadIdx.x; i < n; i += 256) p[i] = 0u;
 }
 
-static int lstm_coop_groups(const ps_lstm_args& a, int ldm) {
+// waves per workgroup (= 16-unit row blocks per slice): 2 when the launch then still fits the chip -- more, smaller slices
+// measured faster per step with a handful of groups (the speaker LSTM: 9.5 ms against 13.6) -- else 4, else 0 (does not fit)
+static int lstm_coop_waves(const ps_lstm_args& a, int ldm, int* groups_out) {
   if (!lstm_h256_fits(a, ldm) || a.steps < 2) return 0;
   const long long groups = ((long long)a.N * a.Q + 15) / 16;
-  return (groups * a.D + 7) / 8 * 8 * (a.H / 32) <= device_cus() ? (int)groups : 0;
+  const long long rounds = (groups * a.D + 7) / 8 * 8;
+  if (groups_out) *groups_out = (int)groups;
+  if (rounds * (a.H / 32) <= device_cus()) return 2;
+  if (rounds * (a.H / 64) <= device_cus()) return 4;
+  return 0;
 }
 
 extern "C" size_t ps_lstm_fmajor_coop_workspace_bytes(const ps_lstm_args* args, int ldm) {
-  const int groups = args ? lstm_coop_groups(*args, ldm) : 0;
-  if (!groups) return 0;
+  int groups = 0;
+  const int wv = args ? lstm_coop_waves(*args, ldm, &groups) : 0;
+  if (!wv) return 0;
   const size_t hx = align_up((size_t)2 * args->D * groups * 2 * 16 * (args->H + 8) * sizeof(_Float16), 256);
-  return hx + align_up((size_t)(args->D * groups * (2 + args->H / 32) + 1) * sizeof(unsigned), 256);
+  return hx + align_up((size_t)(args->D * groups * (2 + args->H / (16 * wv)) + 1) * sizeof(unsigned), 256);
 }
 
 extern "C" int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, const void* whh_image, const float* acc_scale,
@@ -1259,7 +1266,7 @@ extern "C" int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, 
   }
   const size_t need = ps_lstm_fmajor_coop_workspace_bytes(args, ldm);
   if (!need) {
-    set_error("ps_lstm_fmajor_coop_f16x2_f32: ps_lstm_fmajor_h256_f16x2_f32's shapes with at most %d / (D * H / 32) groups of 16 "
+    set_error("ps_lstm_fmajor_coop_f16x2_f32: ps_lstm_fmajor_h256_f16x2_f32's shapes with at most %d / (D * H / 64) groups of 16 "
               "sequences and at least two steps (ps_lstm_fmajor_coop_workspace_bytes = 0)", device_cus());
     return PS_E_UNSUPPORTED;
   }
@@ -1268,7 +1275,8 @@ extern "C" int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, 
     return PS_E_INVALID;
   }
   const ps_lstm_args& a = *args;
-  const int groups = lstm_coop_groups(a, ldm);
+  int groups = 0;
+  const int wv = lstm_coop_waves(a, ldm, &groups);
   const size_t hx = align_up((size_t)2 * a.D * groups * 2 * 16 * (a.H + 8) * sizeof(_Float16), 256);
   LstmCoop k{a, ldm, whh_image, {acc_scale[0], a.D > 1 ? acc_scale[1] : acc_scale[0]}, (_Float16*)workspace,
              (unsigned*)((char*)workspace + hx), groups, (g_debug_flags & (1 << 19)) ? 0 : 1, (g_debug_flags & (1 << 18)) ? 1 : 0,
@@ -1284,11 +1292,15 @@ extern "C" int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, 
   {
     LaunchTimer timer("lstm", (hipStream_t)stream);
     // clusters (direction, group) in rounds of 8, one per XCD; H / 32 slices each
-    dim3 grid((unsigned)((a.D * groups + 7) / 8 * (a.H / 32) * 8));
-    if (a.H == 256)
-      hipLaunchKernelGGL((lstm_coop_kernel<256>), grid, dim3(128), 0, (hipStream_t)stream, k);
+    dim3 grid((unsigned)((a.D * groups + 7) / 8 * (a.H / (16 * wv)) * 8));
+    if (a.H == 256 && wv == 2)
+      hipLaunchKernelGGL((lstm_coop_kernel<256, 2>), grid, dim3(128), 0, (hipStream_t)stream, k);
+    else if (a.H == 256)
+      hipLaunchKernelGGL((lstm_coop_kernel<256, 4>), grid, dim3(256), 0, (hipStream_t)stream, k);
+    else if (wv == 2)
+      hipLaunchKernelGGL((lstm_coop_kernel<192, 2>), grid, dim3(128), 0, (hipStream_t)stream, k);
     else
-      hipLaunchKernelGGL((lstm_coop_kernel<192>), grid, dim3(128), 0, (hipStream_t)stream, k);
+      hipLaunchKernelGGL((lstm_coop_kernel<192, 4>), grid, dim3(256), 0, (hipStream_t)stream, k);
   }
   e = hipGetLastError();
   if (e != hipSuccess) {

@@ -635,6 +635,13 @@ COOP_LSTM = os.environ.get("PS_COOP_LSTM", "1") != "0"   # 0: always the streame
 _COOP_LAST = [None]
 
 
+def _coop_slices(dirs: int, groups: int, hidden: int) -> int:
+    """slices per group the launcher picks: H / 32 (two waves each) while the launch fits the chip, else H / 64"""
+    rounds = (groups * dirs + 7) // 8 * 8
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    return hidden // 32 if rounds * (hidden // 32) <= cus else hidden // 64
+
+
 def coop_lstm_error_word(dirs: int, groups: int, hidden: int) -> int:
     """The error word of the last cooperative LSTM launch's workspace (1 = a group barrier gave up waiting); synchronises."""
     ws = _COOP_LAST[0]
@@ -645,19 +652,20 @@ def coop_lstm_error_word(dirs: int, groups: int, hidden: int) -> int:
 
 
 def coop_lstm_xcd_ids(dirs: int, groups: int, hidden: int) -> torch.Tensor:
-    """[D * groups, H / 32]: the XCD every slice of the last cooperative launch ran on (the light group barrier needs each
+    """[D * groups, slices]: the XCD every slice of the last cooperative launch ran on (the light group barrier needs each
     row constant: tests check it on the target part)."""
     ws = _COOP_LAST[0]
     hx = (2 * dirs * groups * 2 * 16 * (hidden + 8) * 2 + 255) // 256 * 256
     first = hx // 4 + dirs * groups + 1
-    return ws.view(torch.int32)[first:first + dirs * groups * (hidden // 32)].reshape(dirs * groups, hidden // 32).cpu()
+    ns = _coop_slices(dirs, groups, hidden)
+    return ws.view(torch.int32)[first:first + dirs * groups * ns].reshape(dirs * groups, ns).cpu()
 
 
 def coop_lstm_xcd_masks(dirs: int, groups: int, hidden: int) -> torch.Tensor:
     """[D * groups]: per cluster the OR of 1 << XCD over its slices (one bit = the cluster took the light barrier)."""
     ws = _COOP_LAST[0]
     hx = (2 * dirs * groups * 2 * 16 * (hidden + 8) * 2 + 255) // 256 * 256
-    first = hx // 4 + dirs * groups + 1 + dirs * groups * (hidden // 32)
+    first = hx // 4 + dirs * groups + 1 + dirs * groups * _coop_slices(dirs, groups, hidden)
     return ws.view(torch.int32)[first:first + dirs * groups].cpu()
 
 
