@@ -1280,7 +1280,7 @@ extern "C" int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, 
   const size_t hx = align_up((size_t)2 * a.D * groups * 2 * 16 * (a.H + 8) * sizeof(_Float16), 256);
   LstmCoop k{a, ldm, whh_image, {acc_scale[0], a.D > 1 ? acc_scale[1] : acc_scale[0]}, (_Float16*)workspace,
              (unsigned*)((char*)workspace + hx), groups, (g_debug_flags & (1 << 19)) ? 0 : 1, (g_debug_flags & (1 << 18)) ? 1 : 0,
-             (g_debug_flags & (1 << 17)) ? 1 : 0};
+             (g_debug_flags & (1 << 17)) ? 1 : 0, (int)((g_debug_flags >> 24) & 15)};
   if (!(k.up[0] > 0.f) || !(k.up[1] > 0.f)) {
     set_error("ps_lstm_fmajor_coop_f16x2_f32: accumulator scales must be positive");
     return PS_E_INVALID;
@@ -1293,14 +1293,24 @@ extern "C" int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, 
     LaunchTimer timer("lstm", (hipStream_t)stream);
     // clusters (direction, group) in rounds of 8, one per XCD; H / 32 slices each
     dim3 grid((unsigned)((a.D * groups + 7) / 8 * (a.H / (16 * wv)) * 8));
-    if (a.H == 256 && wv == 2)
-      hipLaunchKernelGGL((lstm_coop_kernel<256, 2>), grid, dim3(128), 0, (hipStream_t)stream, k);
-    else if (a.H == 256)
-      hipLaunchKernelGGL((lstm_coop_kernel<256, 4>), grid, dim3(256), 0, (hipStream_t)stream, k);
-    else if (wv == 2)
-      hipLaunchKernelGGL((lstm_coop_kernel<192, 2>), grid, dim3(128), 0, (hipStream_t)stream, k);
-    else
-      hipLaunchKernelGGL((lstm_coop_kernel<192, 4>), grid, dim3(256), 0, (hipStream_t)stream, k);
+    // (the streamed kernel's rule for 8-byte h' stores; bit 20 keeps the 4-byte ones: tests run both)
+    const bool pairs = a.step_stride == 1 && a.q_stride % 2 == 0 && a.ldt % 2 == 0 && !((uintptr_t)a.hout & 7) &&
+                       (a.D == 1 || a.steps % 2 == 0) && !(g_debug_flags & (1 << 20));
+#define PS_COOP(HH, WW)                                                                                            \
+  if (pairs)                                                                                                       \
+    hipLaunchKernelGGL((lstm_coop_kernel<HH, WW, 2>), grid, dim3(64 * WW), 0, (hipStream_t)stream, k);             \
+  else                                                                                                             \
+    hipLaunchKernelGGL((lstm_coop_kernel<HH, WW, 1>), grid, dim3(64 * WW), 0, (hipStream_t)stream, k);
+    if (a.H == 256 && wv == 2) {
+      PS_COOP(256, 2)
+    } else if (a.H == 256) {
+      PS_COOP(256, 4)
+    } else if (wv == 2) {
+      PS_COOP(192, 2)
+    } else {
+      PS_COOP(192, 4)
+    }
+#undef PS_COOP
   }
   e = hipGetLastError();
   if (e != hipSuccess) {

@@ -337,7 +337,7 @@ def test_unfold2d_batches_beyond_the_grid_limit(H, dev):
     (False, 2, 4, 9, 0, 1.0, 192),
     (True, 32, 1, 300, 0, 1.0, 192),   # the speaker LSTM of tse_skim_v1 in small: 32 sequences (two groups), 300 steps
 ])
-@pytest.mark.parametrize("coop", [False, True, "agent-scope fences", "scattered"])
+@pytest.mark.parametrize("coop", [False, True, "agent-scope fences", "scattered", "4-byte stores"])
 def test_lstm_h256_streamed_weights_kernel(H, dev, bi, n, s, k, shift, wscale, hid, coop):
     """ps_lstm_fmajor_h256_f16x2_f32 (H = 256: W_hh streamed from its packed image, frame-major pre-activations, initial and
     final states) on SkiM's segment layout (q = segment, k consecutive frames each) against the oracle's LSTM and the generic
@@ -349,7 +349,8 @@ def test_lstm_h256_streamed_weights_kernel(H, dev, bi, n, s, k, shift, wscale, h
     H._COOP_LAST[0] = None
     # bit 19: the memory model's agent-scope fences at every barrier; bit 18: a cluster's slices on consecutive workgroup ids,
     # i.e. on different XCDs -- the kernel must notice (more than one bit in the cluster's mask) and take those fences itself
-    old_flags = _abi.lib().ps_debug_flags({"agent-scope fences": 1 << 19, "scattered": 1 << 18}.get(coop, 0))
+    # bit 20: 4-byte h' stores where the launch qualifies for 8-byte ones
+    old_flags = _abi.lib().ps_debug_flags({"agent-scope fences": 1 << 19, "scattered": 1 << 18, "4-byte stores": 1 << 20}.get(coop, 0))
     try:
         _lstm_h256_case(H, dev, bi, n, s, k, shift, wscale, hid)
         if coop:
@@ -362,7 +363,7 @@ def test_lstm_h256_streamed_weights_kernel(H, dev, bi, n, s, k, shift, wscale, h
                 assert m == sum(1 << x for x in set(row)), (row, m)
             if coop == "scattered":
                 assert all(len(set(row)) > 1 for row in ids.tolist()), ids    # (different XCDs: the heavy barrier was taken)
-            elif coop is True:
+            elif coop is True or coop == "4-byte stores":
                 assert all(len(set(row)) == 1 for row in ids.tolist()), ids   # alone on the chip: one XCD per cluster
         else:
             assert H._COOP_LAST[0] is None
@@ -811,3 +812,36 @@ def test_cooperative_lstm_gives_up_loudly(H, dev):
     assert torch.isnan(bad[..., :k]).all()
     again, _ = H.lstm_fmajor_h256(gx_fm, img, scale, 1, 1, k, k, 1)
     assert H.coop_lstm_error_word(1, 1, hid) == 0 and torch.equal(again[..., :k], good[..., :k])
+
+
+@pytest.mark.parametrize("flags,what", [(0, "light barrier, 8-byte stores"), (1 << 20, "light barrier, 4-byte stores"),
+                                        (1 << 19, "agent-scope fences")])
+def test_cooperative_lstm_many_groups_back_to_back(H, dev, flags, what):
+    """SkiM's segment-LSTM launch (864 sequences x 150 steps, H = 256: 54 groups x 4 slices on 216 CUs) eight times back to
+    back without a synchronisation in between, every launch against the streamed-weight kernel.  This is the test the light
+    barrier's missing vmcnt(0) failed once in a few launches (the counter overtook the h' stores: 5e-6 .. 4e-2 off)."""
+    from puresound_amd import _abi
+    n, q, steps, hid, d = 32, 27, 150, 256, 1
+    t = q * steps
+    g = torch.Generator().manual_seed(3)
+    gx = (torch.rand(n, H.padded_frames(t), d * 4 * hid, generator=g) - 0.5).to(dev)
+    whh = ((torch.rand(d, hid, 4 * hid, generator=g) - 0.5) * 0.2).to(dev)
+    img, scale = H.pack_whh_h256(whh)
+    old_coop = H.COOP_LSTM
+    try:
+        H.COOP_LSTM = False
+        ref, _ = H.lstm_fmajor_h256(gx, img, scale, d, q, steps, steps, 1)
+        H.COOP_LSTM = True
+        old = _abi.lib().ps_debug_flags(flags)
+        try:
+            outs = [H.lstm_fmajor_h256(gx, img, scale, d, q, steps, steps, 1)[0] for _ in range(8)]
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
+        groups = (n * q + 15) // 16
+        assert H.coop_lstm_error_word(d, groups, hid) == 0
+        diffs = [float((o[..., :t] - ref[..., :t]).abs().max()) for o in outs]
+        assert max(diffs) < 2e-6, (what, diffs)
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), what
+    finally:
+        H.COOP_LSTM = old_coop

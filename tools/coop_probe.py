@@ -42,6 +42,24 @@ def main():
         ref = out if not coop else ref
         if coop:
             print("max |coop - streamed| =", float((out[..., :t] - ref[..., :t]).abs().max()))
+    # where a step's time goes: the same launch with parts removed (ps_debug_flags bits 24..27; results are wrong by design)
+    from puresound_amd import _abi
+    H.COOP_LSTM = True
+    for bits, what in ((1, "no h' output stores"), (2, "no MFMAs"), (4, "no exchange loads"), (8, "no barriers"), (15, "none of them")):
+        old = _abi.lib().ps_debug_flags(bits << 24)
+        try:
+            for _ in range(2):
+                H.lstm_fmajor_h256(gx, img, scale, d, q, steps, steps, 1)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                H.lstm_fmajor_h256(gx, img, scale, d, q, steps, steps, 1)
+            b.record()
+            torch.cuda.synchronize()
+        finally:
+            _abi.lib().ps_debug_flags(old)
+        print(f"  {what:22s} {a.elapsed_time(b) / 5 / steps * 1e3:6.2f} us per step", flush=True)
 
 
 if __name__ == "__main__":
