@@ -1247,13 +1247,16 @@ static int lstm_coop_waves(const ps_lstm_args& a, int ldm, int* groups_out) {
   if (groups_out) *groups_out = (int)groups;
   if (rounds * (a.H / 32) <= device_cus()) return 2;
   if (rounds * (a.H / 64) <= device_cus()) return 4;
+  // both directions do not fit at once: one launch per direction, if a direction does
+  if (a.D == 2 && (groups + 7) / 8 * 8 * (a.H / 64) <= device_cus()) return -4;
   return 0;
 }
 
 extern "C" size_t ps_lstm_fmajor_coop_workspace_bytes(const ps_lstm_args* args, int ldm) {
   int groups = 0;
-  const int wv = args ? lstm_coop_waves(*args, ldm, &groups) : 0;
+  int wv = args ? lstm_coop_waves(*args, ldm, &groups) : 0;
   if (!wv) return 0;
+  wv = wv < 0 ? -wv : wv;
   const size_t hx = align_up((size_t)2 * args->D * groups * 2 * 16 * (args->H + 8) * sizeof(_Float16), 256);
   return hx + align_up((size_t)(args->D * groups * (2 + args->H / (16 * wv)) + 1) * sizeof(unsigned), 256);
 }
@@ -1276,11 +1279,13 @@ extern "C" int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, 
   }
   const ps_lstm_args& a = *args;
   int groups = 0;
-  const int wv = lstm_coop_waves(a, ldm, &groups);
+  int wv = lstm_coop_waves(a, ldm, &groups);
+  const bool per_direction = wv < 0;
+  wv = wv < 0 ? -wv : wv;
   const size_t hx = align_up((size_t)2 * a.D * groups * 2 * 16 * (a.H + 8) * sizeof(_Float16), 256);
   LstmCoop k{a, ldm, whh_image, {acc_scale[0], a.D > 1 ? acc_scale[1] : acc_scale[0]}, (_Float16*)workspace,
              (unsigned*)((char*)workspace + hx), groups, (g_debug_flags & (1 << 19)) ? 0 : 1, (g_debug_flags & (1 << 18)) ? 1 : 0,
-             (g_debug_flags & (1 << 17)) ? 1 : 0, (int)((g_debug_flags >> 24) & 15)};
+             (g_debug_flags & (1 << 17)) ? 1 : 0, 0, a.D, (int)((g_debug_flags >> 24) & 15)};
   if (!(k.up[0] > 0.f) || !(k.up[1] > 0.f)) {
     set_error("ps_lstm_fmajor_coop_f16x2_f32: accumulator scales must be positive");
     return PS_E_INVALID;
@@ -1292,7 +1297,9 @@ extern "C" int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, 
   {
     LaunchTimer timer("lstm", (hipStream_t)stream);
     // clusters (direction, group) in rounds of 8, one per XCD; H / 32 slices each
-    dim3 grid((unsigned)((a.D * groups + 7) / 8 * (a.H / (16 * wv)) * 8));
+    for (int d0 = 0; d0 < (per_direction ? a.D : 1); ++d0) {
+    if (per_direction) k.d0 = d0, k.nd = 1;
+    dim3 grid((unsigned)((k.nd * groups + 7) / 8 * (a.H / (16 * wv)) * 8));
     // (the streamed kernel's rule for 8-byte h' stores; bit 20 keeps the 4-byte ones: tests run both)
     const bool pairs = a.step_stride == 1 && a.q_stride % 2 == 0 && a.ldt % 2 == 0 && !((uintptr_t)a.hout & 7) &&
                        (a.D == 1 || a.steps % 2 == 0) && !(g_debug_flags & (1 << 20));
@@ -1309,6 +1316,7 @@ extern "C" int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, 
       PS_COOP(192, 2)
     } else {
       PS_COOP(192, 4)
+    }
     }
 #undef PS_COOP
   }

@@ -637,7 +637,7 @@ _COOP_LAST = [None]
 
 def _coop_slices(dirs: int, groups: int, hidden: int) -> int:
     """slices per group the launcher picks: H / 32 (two waves each) while the launch fits the chip, else H / 64"""
-    rounds = (groups * dirs + 7) // 8 * 8
+    rounds = (groups * dirs + 7) // 8 * 8   # (both directions in one launch; one launch per direction beyond that: H / 64 too)
     cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     return hidden // 32 if rounds * (hidden // 32) <= cus else hidden // 64
 

@@ -816,12 +816,14 @@ def test_cooperative_lstm_gives_up_loudly(H, dev):
 
 @pytest.mark.parametrize("flags,what", [(0, "light barrier, 8-byte stores"), (1 << 20, "light barrier, 4-byte stores"),
                                         (1 << 19, "agent-scope fences")])
-def test_cooperative_lstm_many_groups_back_to_back(H, dev, flags, what):
+@pytest.mark.parametrize("d", [1, 2])
+def test_cooperative_lstm_many_groups_back_to_back(H, dev, flags, what, d):
     """SkiM's segment-LSTM launch (864 sequences x 150 steps, H = 256: 54 groups x 4 slices on 216 CUs) eight times back to
     back without a synchronisation in between, every launch against the streamed-weight kernel.  This is the test the light
     barrier's missing vmcnt(0) failed once in a few launches (the counter overtook the h' stores: 5e-6 .. 4e-2 off)."""
     from puresound_amd import _abi
-    n, q, steps, hid, d = 32, 27, 150, 256, 1
+    # d = 2 (the non-causal presets: 108 clusters do not fit the chip at once): one launch per direction, 50 steps here
+    n, q, steps, hid = 32, 27, (150 if d == 1 else 50), 256
     t = q * steps
     g = torch.Generator().manual_seed(3)
     gx = (torch.rand(n, H.padded_frames(t), d * 4 * hid, generator=g) - 0.5).to(dev)
@@ -842,6 +844,6 @@ def test_cooperative_lstm_many_groups_back_to_back(H, dev, flags, what):
         assert H.coop_lstm_error_word(d, groups, hid) == 0
         diffs = [float((o[..., :t] - ref[..., :t]).abs().max()) for o in outs]
         assert max(diffs) < 2e-6, (what, diffs)
-        assert all(torch.equal(outs[0], o) for o in outs[1:]), what
+        assert all(torch.equal(outs[0][..., :t], o[..., :t]) for o in outs[1:]), what   # (frames past t are never written)
     finally:
         H.COOP_LSTM = old_coop
