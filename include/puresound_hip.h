@@ -402,7 +402,10 @@ int ps_lstm_fmajor_h256_f16x2_f32(const ps_lstm_args* args, int ldm, const void*
  * once -- the launcher refuses such grids -- would raise the error word behind the counters instead of hanging).  Same
  * arguments, weight image and results class as ps_lstm_fmajor_h256_f16x2_f32, plus a scratch buffer of
  * ps_lstm_fmajor_coop_workspace_bytes(args, ldm) bytes, 256-byte aligned; 0 bytes = the launch does not qualify (more than
- * CUs / (D * H / 32) groups, or fewer than two steps): PS_E_UNSUPPORTED, take the streamed kernel. */
+ * CUs / (D * H / 32) groups, or fewer than two steps): PS_E_UNSUPPORTED, take the streamed kernel.
+ * ONE such launch in flight per device at a time: its workgroups wait for each other, so two of them on different streams can
+ * each hold CUs the other needs until both give up (NaN results and the error word, not a hang).  The Python mirror's batch
+ * lanes (hip_streams > 1) therefore take the streamed kernel. */
 size_t ps_lstm_fmajor_coop_workspace_bytes(const ps_lstm_args* args, int ldm);
 int ps_lstm_fmajor_coop_f16x2_f32(const ps_lstm_args* args, int ldm, const void* whh_image, const float* acc_scale,
                                   void* workspace, size_t workspace_bytes, void* stream);

@@ -352,16 +352,22 @@ class SoTaskWrapModule(EncDecMaskerBaseModel):
         self._prepare_plans(dev)
         first = not getattr(self, "_lanes_warm", False)
         object.__setattr__(self, "_lanes_warm", True)
-        for i, s in enumerate(pool):
-            s.wait_stream(cur)
-            if first and i > 0:
-                s.wait_stream(pool[i - 1])
-            with torch.cuda.stream(s):
-                got = run(noisy[bounds[i]:bounds[i + 1]], i, out[bounds[i]:bounds[i + 1]],
-                          None if enroll is None else enroll[bounds[i]:bounds[i + 1]],
-                          None if ref is None else ref[bounds[i]:bounds[i + 1]])
-                if ref is not None:
-                    moments[bounds[i]:bounds[i + 1]] = got[1]
+        # (the cooperative LSTM's workgroups spin on each other and must all be resident at once: two lanes launching it side
+        #  by side could each hold CUs the other is waiting for until both give up -- the lanes take the streamed kernel)
+        coop, hip.COOP_LSTM = hip.COOP_LSTM, False
+        try:
+            for i, s in enumerate(pool):
+                s.wait_stream(cur)
+                if first and i > 0:
+                    s.wait_stream(pool[i - 1])
+                with torch.cuda.stream(s):
+                    got = run(noisy[bounds[i]:bounds[i + 1]], i, out[bounds[i]:bounds[i + 1]],
+                              None if enroll is None else enroll[bounds[i]:bounds[i + 1]],
+                              None if ref is None else ref[bounds[i]:bounds[i + 1]])
+                    if ref is not None:
+                        moments[bounds[i]:bounds[i + 1]] = got[1]
+        finally:
+            hip.COOP_LSTM = coop
         for s in pool:
             cur.wait_stream(s)
         return out if ref is None else (out, moments)

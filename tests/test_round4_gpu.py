@@ -847,3 +847,22 @@ def test_cooperative_lstm_many_groups_back_to_back(H, dev, flags, what, d):
         assert all(torch.equal(outs[0][..., :t], o[..., :t]) for o in outs[1:]), what   # (frames past t are never written)
     finally:
         H.COOP_LSTM = old_coop
+
+
+def test_two_lanes_keep_off_the_cooperative_lstm(PA, H, dev):
+    """hip_streams = 2 on a SkiM preset: two lanes must not launch the cooperative LSTM side by side (their workgroups would
+    wait for CUs the other lane's workgroups hold): the lanes run the streamed kernel, the result is that of one lane."""
+    name = "tse_skim_v0_short"
+    model = cases.build(PA.NS, name).eval()
+    model.load_state_dict(det_state_dict(model))
+    model.to(dev)
+    noisy = det_wave(77, 16, 16000).to(dev)
+    enroll = det_wave(78, 16, 16000).to(dev)
+    assert H.COOP_LSTM
+    one = model.inference(noisy, enroll)
+    H._COOP_LAST[0] = None
+    model.hip_streams = 2
+    two = model.inference(noisy, enroll)
+    assert H._COOP_LAST[0] is None and H.COOP_LSTM     # no cooperative launch inside the lanes; the switch is back on
+    assert torch.isfinite(two).all()
+    assert rel_max(two.cpu().numpy(), one.cpu().numpy()) < 2e-5
